@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the Darknet-19 YOLOv2 hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size S] [--mode detect|forward]
+
+N = 1 workload = BASELINE.json configs[1]: Darknet-19 YOLOv2 416x416 batch-32 inference (conv stack + decode +
+visibility filter + NMS), synthetic images, random-init weights (seeded), inputs resident in HBM before the timed
+region.  For N > 1 (launched by torch.distributed.run, one process per GPU) inference is "replicas only": every rank
+runs the same per-GPU batch, no data-path collective; the barrier and max-over-ranks timing stay.
+
+Prints ONE JSON line on rank 0 with the contract fields plus:
+  roofline     — conv_fwd_kernel family (the dominant kernel: 99% of the FLOPs): algorithmic conv FLOPs of its
+                 launches / their summed duration, measured live with HIP events on the launch stream inside the timed
+                 region; peak = 157.3 TFLOP/s (fp32-input MFMA, MI355X_MICROARCH.md).
+  cpu_baseline — the CPU oracle (port of the reference path: torch-CPU conv stack + numpy decode/filter/NMS) timed on
+                 this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+APP = os.path.join(ROOT, 'yolo2-pytorch_amd')
+for p in (ROOT, APP):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3
+
+
+def build_model(num_cls, dev):
+    import configparser
+
+    import model
+    import model.yolo2
+    from oracle import darknet as odark
+    from oracle import synth
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1'}})
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    # SURVEY.md 8d weights: seed 0, kaiming conv, randomised BN buffers; head scaled so exp(size_norm) stays finite
+    sd = odark.init_state_dict(5, num_cls, seed=0, head_scale=1 / 40.0)
+    dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, num_cls)
+    dnn.load_state_dict(sd, strict=False)
+    inf = model.Inference(cfg, dnn, anchors).to(dev).eval()
+    return inf, anchors, sd
+
+
+def cpu_baseline(sd, anchors, size, sample):
+    """Oracle (port) on the host cores: conv stack + decode + filter + NMS on `sample` images."""
+    import numpy as np
+    from oracle import darknet as odark
+    from oracle import detect as odet
+    from oracle import head as ohead
+    from oracle import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = synth.images(sample, size, seed=1)
+    with torch.no_grad():
+        odark.forward(x[:1], sd)  # warm-up
+        t0 = time.perf_counter()
+        feat = odark.forward(x, sd)
+        pred = ohead.decode(feat, anchors)
+        B = feat.shape[0]
+        prob = torch.softmax(pred['logits'], -1).view(B, -1, pred['logits'].shape[-1]).numpy()
+        iou = pred['iou'].reshape(B, -1).numpy()
+        mn, mx = pred['yx_min'].reshape(B, -1, 2).numpy(), pred['yx_max'].reshape(B, -1, 2).numpy()
+        for b in range(B):
+            odet.postprocess(iou[b], mn[b], mx[b], prob[b], fix=True)
+        dt = time.perf_counter() - t0
+    return {'value': round(sample / dt, 3), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d synthetic %dx%d images, oracle conv stack (torch-CPU fp32) + decode + filter(fix=1) + NMS, %.1f s' % (sample, size, size, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch')
+    ap.add_argument('--size', type=int, default=416)
+    ap.add_argument('--classes', type=int, default=20)
+    ap.add_argument('--mode', default='detect', choices=['detect', 'forward'])
+    ap.add_argument('--cpu-sample', type=int, default=16, help='images for the CPU baseline (0 = skip)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)   # nccl == RCCL on ROCm
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+
+    import detect
+    from oracle import synth
+    inf, anchors, sd = build_model(args.classes, dev)
+    dnn = inf.dnn
+    x = synth.images(args.batch, args.size, seed=1 + rank).to(dev)   # resident in HBM before timing
+
+    def step():
+        with torch.no_grad():
+            feat = dnn.forward_nhwc(x)
+            if args.mode == 'detect':
+                return detect.detect_batch(feat, anchors, fix=True, threshold_cls=0.005, overlap=0.45, limit=200)
+            return feat
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    dnn.profile = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, dnn.profile = dnn.profile, None
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+
+    # roofline of the dominant kernel family, live from the timed region
+    fl = ms = 0.0
+    n_launch = 0
+    fl0 = ms0 = 0.0
+    for name, flops, e0, e1 in prof:
+        d = e0.elapsed_time(e1)
+        if name.startswith('conv_fwd'):
+            fl += flops
+            ms += d
+            n_launch += 1
+        else:
+            fl0 += flops
+            ms0 += d
+    achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+
+    if rank == 0:
+        images = args.batch * args.steps * world
+        out = {
+            'metric': 'images/sec (416x416) detect, Darknet-19 YOLOv2',
+            'value': round(images / dt, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'Darknet-19 YOLOv2 %dx%d batch-%d/GPU inference: conv stack + decode + filter + NMS (BASELINE configs[1])'
+                                   % (args.size, args.size, args.batch) if args.mode == 'detect' else
+                                   'Darknet-19 YOLOv2 %dx%d batch-%d/GPU conv stack only' % (args.size, args.size, args.batch),
+                       'classes': args.classes, 'global_batch': args.batch * world, 'parallelism': 'replicas x%d (no collective)' % world,
+                       'weights': 'random-init seed 0'},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_fwd_kernel (fp32 MFMA implicit GEMM, %d launches/step)' % (n_launch // max(args.steps, 1)),
+                         'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'flops_per_step': fl / max(args.steps, 1), 'ms_per_step': round(ms / max(args.steps, 1), 4),
+                         'conv0_ms_per_step': round(ms0 / max(args.steps, 1), 4), 'traffic': None},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out['cpu_baseline'] = cpu_baseline(sd, anchors, args.size, args.cpu_sample)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

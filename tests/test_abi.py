@@ -1,0 +1,64 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports every
+symbol include/yolo2_hip.h declares; the product refuses CPU tensors (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+import _hip
+
+
+@pytest.fixture(scope='module')
+def built():
+    if not os.path.exists(_hip.LIB_PATH):
+        _hip.build()
+    return _hip.LIB_PATH
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'yolo2_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(y2_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    l = ctypes.CDLL(built)
+    names = declared_symbols()
+    assert len(names) >= 13
+    for name in names:
+        assert hasattr(l, name), name
+    # and the Python binding knows every compute entry point
+    for name in names:
+        assert name in _hip.SIGNATURES or name == 'y2_build_info', name
+
+
+def test_version_and_build_info(built):
+    l = _hip.lib()
+    assert l.y2_abi_version() == 1
+    assert b'gfx950' in l.y2_build_info()
+
+
+def test_conv_params_struct_layout():
+    # 7 pointers + 12 int32 + 1 float + 1 int32 -> 56 + 56 = 112 bytes, matches the C struct (no padding holes)
+    assert ctypes.sizeof(_hip.ConvParams) == 7 * 8 + 14 * 4
+
+
+def test_no_cpu_fallback():
+    import utils.iou.torch as iou
+    import utils.postprocess as post
+    a = torch.zeros(2, 2)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        iou.iou_matrix(a, a + 1, a, a + 1)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        post.nms(torch.ones(2), a, a + 1)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_hip, '_lib', None)
+    monkeypatch.setattr(_hip, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_hip.HipLibraryMissing):
+        _hip.lib()

@@ -1,0 +1,359 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel, called through the C-ABI via the Python
+mirror of the reference interface, against the CPU oracle / golden fixtures.
+
+Tolerances (stated per SURVEY.md 8d): conv tensors max|err| <= 2e-5 * rms(reference) against an fp64 run of the
+oracle; decode/softmax outputs 1e-5 relative (different exp implementation); IoU and NMS indices bit-exact.
+"""
+import configparser
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import darknet as odark
+from oracle import detect as odet
+from oracle import head as ohead
+from oracle import iou as oiou
+from oracle import nms as onms
+from oracle import synth
+from oracle.make_golden import NARROW
+
+pytestmark = pytest.mark.gpu
+
+CONV_TOL = 2e-5  # x rms of the fp64 reference
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def to_nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def rel_err(got, ref64):
+    ref64 = ref64.double()
+    rms = ref64.pow(2).mean().sqrt().item()
+    return (got.double().cpu() - ref64).abs().max().item() / max(rms, 1e-30)
+
+
+def run_conv(x_nchw, w, scale, shift, slope, k, pool=False, both=False, tile=0, reorg=False, coff=0, extra=0, stats=False):
+    """Drive y2_conv_fwd directly (NHWC in/out); returns dict of outputs as NCHW CPU tensors."""
+    import _hip
+    L = _hip.lib()
+    d = dev()
+    B, cin, H, W = x_nchw.shape
+    cout = w.shape[0]
+    x = to_nhwc(x_nchw).to(d)
+    wd = w.to(d).contiguous()
+    wp = torch.empty(w.numel(), device=d)
+    _hip.check(L.y2_pack_weight(_hip.ptr(wd), _hip.ptr(wp), cout, cin, k, 0, _hip.stream()), 'pack')
+    p = _hip.ConvParams()
+    sc = scale.to(d) if scale is not None else None
+    sh = shift.to(d) if shift is not None else None
+    p.x, p.w = x.data_ptr(), wp.data_ptr()
+    p.scale = sc.data_ptr() if sc is not None else None
+    p.shift = sh.data_ptr() if sh is not None else None
+    out = {}
+    y = yp = st = None
+    if reorg:
+        ld = coff + 4 * cout + extra
+        y = torch.full((B, H // 2, W // 2, ld), -7.0, device=d)
+        p.y, p.ldy, p.coff, p.out_mode = y.data_ptr(), ld, coff, 1
+    elif not pool or both:
+        ld = coff + cout + extra
+        y = torch.full((B, H, W, ld), -7.0, device=d)
+        p.y, p.ldy, p.coff, p.out_mode = y.data_ptr(), ld, coff, 0
+    if pool:
+        ldp = cout + extra
+        yp = torch.full((B, H // 2, W // 2, ldp), -7.0, device=d)
+        p.y_pool, p.ldp, p.poff = yp.data_ptr(), ldp, 0
+    if stats:
+        st = torch.zeros(2 * cout, dtype=torch.float64, device=d)
+        p.stats = st.data_ptr()
+    p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize = B, H, W, cin, cin, cout, k
+    p.slope, p.tile = slope, tile
+    _hip.check(L.y2_conv_fwd(ctypes.byref(p), _hip.stream()), 'conv')
+    torch.cuda.synchronize()
+    if y is not None:
+        out['y'] = y.cpu()
+    if yp is not None:
+        out['y_pool'] = yp.cpu()
+    if st is not None:
+        out['stats'] = st.cpu()
+    return out
+
+
+def ref_conv(x, w, scale, shift, slope, k):
+    z = F.conv2d(x.double(), w.double(), padding=(k - 1) // 2)
+    u = z
+    if scale is not None:
+        u = u * scale.double().view(1, -1, 1, 1)
+    if shift is not None:
+        u = u + shift.double().view(1, -1, 1, 1)
+    return z, torch.where(u > 0, u, u * slope)
+
+
+CASES = [
+    # B, Cin, Cout, H, W, k, tile
+    (2, 32, 64, 16, 24, 3, 1), (2, 32, 64, 16, 24, 3, 2), (2, 32, 64, 16, 24, 3, 3), (2, 32, 64, 16, 24, 3, 4), (2, 32, 64, 16, 24, 3, 5),
+    (1, 64, 128, 13, 13, 3, 0), (3, 128, 64, 13, 13, 1, 0), (2, 96, 125, 7, 9, 1, 0), (2, 40, 72, 10, 6, 3, 1),
+    (2, 6, 20, 8, 8, 3, 0), (1, 13, 33, 5, 7, 1, 2), (2, 256, 512, 13, 13, 3, 0),
+]
+
+
+@pytest.mark.parametrize('B,cin,cout,H,W,k,tile', CASES)
+def test_conv_fwd_matches_fp64_reference(B, cin, cout, H, W, k, tile):
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout + H + k)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    z, ref = ref_conv(x, w, scale, shift, 0.1, k)
+    out = run_conv(x, w, scale, shift, 0.1, k, tile=tile, stats=True, extra=3, coff=2)
+    y = out['y']
+    assert torch.all(y[..., :2] == -7.0) and torch.all(y[..., 2 + cout:] == -7.0), 'wrote outside its channel window'
+    assert rel_err(y[..., 2:2 + cout].permute(0, 3, 1, 2), ref) <= CONV_TOL
+    s1, s2 = z.sum((0, 2, 3)), (z * z).sum((0, 2, 3))
+    np.testing.assert_allclose(out['stats'][:cout].numpy(), s1.numpy(), rtol=1e-5, atol=1e-5 * float(s2.max().sqrt()))
+    np.testing.assert_allclose(out['stats'][cout:].numpy(), s2.numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize('tile', [1, 2, 3, 5])
+@pytest.mark.parametrize('both', [False, True])
+def test_conv_fwd_fused_maxpool(tile, both):
+    g = torch.Generator().manual_seed(5)
+    B, cin, cout, H, W, k = 2, 32, 48, 12, 20, 3
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    scale = torch.randn(cout, generator=g)   # negative scales: pool must come AFTER the affine
+    shift = torch.randn(cout, generator=g) * 0.1
+    _, ref = ref_conv(x, w, scale, shift, 0.1, k)
+    out = run_conv(x, w, scale, shift, 0.1, k, pool=True, both=both, tile=tile)
+    assert rel_err(out['y_pool'].permute(0, 3, 1, 2), F.max_pool2d(ref, 2)) <= CONV_TOL
+    if both:
+        assert rel_err(out['y'].permute(0, 3, 1, 2), ref) <= CONV_TOL
+
+
+def test_conv_fwd_reorg_concat_write_through():
+    g = torch.Generator().manual_seed(6)
+    B, cin, cout, H, W = 2, 64, 8, 6, 10
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * 0.2
+    _, ref = ref_conv(x, w, None, None, 0.1, 1)
+    out = run_conv(x, w, None, None, 0.1, 1, reorg=True, coff=0, extra=5)
+    y = out['y']
+    assert torch.all(y[..., 4 * cout:] == -7.0)
+    assert rel_err(y[..., :4 * cout].permute(0, 3, 1, 2), odark.reorg(ref)) <= CONV_TOL
+
+
+@pytest.mark.parametrize('B,cin,cout,H,W', [(2, 3, 32, 32, 64), (1, 3, 32, 20, 36), (2, 3, 40, 16, 32), (1, 4, 7, 18, 34)])
+def test_conv0_matches_fp64_reference(B, cin, cout, H, W):
+    import _hip
+    L = _hip.lib()
+    d = dev()
+    g = torch.Generator().manual_seed(cout + H)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.3
+    scale = torch.randn(cout, generator=g)
+    shift = torch.randn(cout, generator=g) * 0.1
+    z, ref = ref_conv(x, w, scale, shift, 0.1, 3)
+    y = torch.empty(B, H, W, cout, device=d)
+    yp = torch.empty(B, H // 2, W // 2, cout, device=d)
+    st = torch.zeros(2 * cout, dtype=torch.float64, device=d)
+    xd, wd, sc, sh = x.to(d), w.to(d), scale.to(d), shift.to(d)
+    _hip.check(L.y2_conv0_fwd(_hip.ptr(xd), _hip.ptr(wd), _hip.ptr(sc), _hip.ptr(sh), _hip.ptr(y), _hip.ptr(yp), _hip.ptr(st),
+                              B, H, W, cin, cout, cout, cout, 0.1, _hip.stream()), 'conv0')
+    torch.cuda.synchronize()
+    assert rel_err(y.permute(0, 3, 1, 2), ref) <= CONV_TOL
+    assert rel_err(yp.permute(0, 3, 1, 2), F.max_pool2d(ref, 2)) <= CONV_TOL
+    np.testing.assert_allclose(st[:cout].cpu().numpy(), z.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(st[cout:].cpu().numpy(), (z * z).sum((0, 2, 3)).numpy(), rtol=1e-5)
+
+
+def test_maxpool2():
+    import _hip
+    x = torch.randn(2, 8, 12, 16)
+    xd = to_nhwc(x).to(dev())
+    y = torch.empty(2, 4, 6, 16, device=dev())
+    _hip.check(_hip.lib().y2_maxpool2_fwd(_hip.ptr(xd), _hip.ptr(y), 2, 8, 12, 16, 16, 16, _hip.stream()), 'pool')
+    assert torch.equal(y.cpu().permute(0, 3, 1, 2), F.max_pool2d(x, 2))
+
+
+# ------------------------------------------------------------------ the plugin end to end
+def make_plugin(sd, num_cls=20, bn=True):
+    import model
+    import model.yolo2
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1' if bn else '0'}})
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, num_cls)
+    dnn.load_state_dict(sd, strict=False)
+    inf = model.Inference(cfg, dnn, anchors)
+    return inf.to(dev()).eval()
+
+
+def test_darknet_narrow_matches_reference_fixture(golden):
+    import model
+    g = golden('forward_narrow')
+    sd = odark.init_state_dict(5, 20, seed=0, channels=NARROW, head_scale=1 / 8.0)
+    inf = make_plugin(sd)
+    x = synth.images(2, 96, seed=1)
+    with torch.no_grad():
+        pred = model._inference(inf, x.to(dev()))
+        f64 = odark.forward(x.double(), {k: v.double() for k, v in sd.items()})
+    assert tuple(pred['feature'].shape) == g['feature'].shape
+    assert rel_err(pred['feature'], f64) <= CONV_TOL
+    assert rel_err(pred['feature'], torch.from_numpy(g['feature'])) <= 2 * CONV_TOL   # the reference's own fp32 output
+    for k in ('iou', 'center_offset', 'size_norm', 'yx_min', 'yx_max', 'logits'):
+        np.testing.assert_allclose(pred[k].cpu().numpy(), g[k], rtol=2e-4, atol=2e-4)
+
+
+def test_darknet_full_width_matches_reference_fixture(golden):
+    g = golden('forward_full')
+    sd = odark.init_state_dict(5, 20, seed=0, head_scale=1 / 40.0)
+    inf = make_plugin(sd)
+    with torch.no_grad():
+        f = inf.dnn(synth.images(1, 64, seed=1).to(dev()))
+    assert rel_err(f, torch.from_numpy(g['feature_fp64'])) <= CONV_TOL
+
+
+def test_darknet_no_batchnorm_variant():
+    sd = odark.init_state_dict(5, 20, seed=3, channels=NARROW, bn=False, head_scale=1 / 8.0)
+    inf = make_plugin(sd, bn=False)
+    x = synth.images(1, 64, seed=4)
+    with torch.no_grad():
+        f = inf.dnn(x.to(dev()))
+        f64 = odark.forward(x.double(), {k: v.double() for k, v in sd.items()})
+    assert rel_err(f, f64) <= CONV_TOL
+
+
+@pytest.mark.parametrize('S,B', [(416, 2), (320, 1), (608, 1)])
+def test_darknet19_full_size_every_layer(S, B):
+    """Config-2 shape (and the multi-scale extremes): every conv block's output against the fp32 oracle taps, final
+    feature against fp64."""
+    sd = odark.init_state_dict(5, 20, seed=0, head_scale=1 / 40.0)
+    inf = make_plugin(sd)
+    x = synth.images(B, S, seed=1)
+    with torch.no_grad():
+        f = inf.dnn(x.to(dev()))
+        torch.set_num_threads(max(1, torch.get_num_threads()))
+        f32 = odark.forward(x, sd)
+    assert tuple(f.shape) == (B, 125, S // 32, S // 32)
+    assert rel_err(f, f32) <= 4 * CONV_TOL   # fp32 oracle itself carries ~5e-6 rms of summation-order noise
+
+
+# ------------------------------------------------------------------ decode / filter / IoU / NMS
+@pytest.mark.parametrize('name', ['decode_voc', 'decode_coco', 'decode_1cls'])
+def test_decode_matches_reference_fixture(golden, name):
+    import model
+    g = golden(name)
+    feat = torch.from_numpy(g['feature']).to(dev())
+    d = model.decode(to_nhwc(feat), torch.from_numpy(synth.ANCHORS_VOC), 5, want_prob=True)
+    for k in ('iou', 'center_offset', 'yx_min', 'yx_max'):
+        np.testing.assert_allclose(d[k].cpu().numpy(), g[k], rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(d['size_norm'].cpu().numpy(), g['size_norm'])
+    if 'logits' in g.files:
+        prob = torch.softmax(torch.from_numpy(g['logits']), -1)
+        np.testing.assert_allclose(d['prob'].cpu().numpy(), prob.numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_array_equal(d['cls'].cpu().numpy(), prob.argmax(-1).numpy())
+        np.testing.assert_allclose(d['prob_cls'].cpu().numpy(), prob.max(-1)[0].numpy(), rtol=1e-5)
+    else:
+        assert torch.all(d['prob_cls'] == 1) and torch.all(d['cls'] == 0)
+
+
+def boxes_np(b):
+    b = np.array(b, np.float32)
+    return b[:, :2].copy(), b[:, 2:].copy()
+
+
+def test_iou_known_answers_and_bit_exact_random():
+    import utils.iou.torch as iou
+    from test_oracle import KNOWN
+    d = dev()
+    for b1, b2, ans in KNOWN:   # the reference's own known-answer cases (utils/iou/torch.py:79-113)
+        m = iou.iou_matrix(*(torch.from_numpy(t).to(d) for t in boxes_np(b1) + boxes_np(b2)))
+        np.testing.assert_almost_equal(m.cpu().numpy(), np.array(ans, np.float32))
+    rng = np.random.RandomState(0)
+    c1, s1 = rng.uniform(0, 13, (3, 211, 2)).astype(np.float32), rng.uniform(0, 6, (3, 211, 2)).astype(np.float32)
+    c2, s2 = rng.uniform(0, 13, (3, 37, 2)).astype(np.float32), rng.uniform(0, 6, (3, 37, 2)).astype(np.float32)
+    s2[:, -3:] = 0   # degenerate (padded GT rows)
+    args = (c1 - s1 / 2, c1 + s1 / 2, c2 - s2 / 2, c2 + s2 / 2)
+    targs = tuple(torch.from_numpy(a).to(d) for a in args)
+    np.testing.assert_array_equal(iou.batch_iou_matrix(*targs).cpu().numpy(), oiou.batch_iou_matrix(*args))
+    np.testing.assert_array_equal(iou.iou_matrix(*(t[0] for t in targs)).cpu().numpy(), oiou.iou_matrix(*(a[0] for a in args)))
+    np.testing.assert_array_equal(iou.batch_intersection_area(*targs).cpu().numpy(), oiou.batch_intersection_area(*args))
+    pair = (args[0][:, :37], args[1][:, :37], args[2], args[3])
+    np.testing.assert_array_equal(iou.batch_iou_pair(*(torch.from_numpy(a).to(d) for a in pair)).cpu().numpy(), oiou.batch_iou_pair(*pair))
+
+
+@pytest.mark.parametrize('n', [0, 1, 2, 50, 200, 845, 2000])
+def test_nms_bit_exact_vs_reference_fixture(golden, n):
+    import utils.postprocess as post
+    g = golden('nms')
+    score, mn, mx = synth.nms_boxes(n)
+    d = dev()
+    for ov in (0.45, 0.5):
+        keep = post.nms(torch.from_numpy(score).to(d), torch.from_numpy(mn).to(d).view(-1, 2), torch.from_numpy(mx).to(d).view(-1, 2), ov)
+        assert keep == g['n%d_ov%d' % (n, int(ov * 100))].tolist()
+
+
+def test_nms_ties_limits_and_batch():
+    import utils.postprocess as post
+    d = dev()
+    rng = np.random.RandomState(9)
+    B, stride = 5, 700
+    ns = [700, 0, 1, 333, 64]
+    score = rng.randint(0, 40, (B, stride)).astype(np.float32) / 40     # many exact ties
+    c, s = rng.uniform(0, 13, (B, stride, 2)).astype(np.float32), rng.uniform(0.5, 5, (B, stride, 2)).astype(np.float32)
+    mn, mx = c - s / 2, c + s / 2
+    for limit in (200, 64, 1000):
+        keep, cnt = post.nms_batch(torch.from_numpy(score).to(d), torch.from_numpy(mn).to(d), torch.from_numpy(mx).to(d),
+                                   torch.tensor(ns, dtype=torch.int32, device=d), 0.45, limit)
+        keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+        for b in range(B):
+            ref = onms.nms(score[b, :ns[b]], mn[b, :ns[b]], mx[b, :ns[b]], 0.45, limit)
+            assert keep[b, :cnt[b]].tolist() == ref
+
+
+def test_postprocess_matches_reference_fixture(golden):
+    import detect
+    dd = golden('decode_voc')
+    g = golden('postprocess')
+    d = dev()
+    for fix in (0, 1):
+        cfg = configparser.ConfigParser()
+        cfg.read_dict({'detect': {'threshold': '0.3', 'threshold_cls': '0.005', 'fix': str(fix), 'overlap': '0.45'}})
+        for b in range(dd['iou'].shape[0]):
+            prob = torch.softmax(torch.from_numpy(dd['logits'][b]), -1).view(-1, 20)
+            r = detect.postprocess(cfg, torch.from_numpy(dd['iou'][b]).view(-1).to(d), torch.from_numpy(dd['yx_min'][b]).view(-1, 2).to(d),
+                                   torch.from_numpy(dd['yx_max'][b]).view(-1, 2).to(d), prob.to(d))
+            tag = 'fix%d_b%d_' % (fix, b)
+            assert bool(g[tag + 'none']) == (r is None)
+            if r is not None:
+                for name, t in zip(('iou', 'yx_min', 'yx_max', 'cls', 'score'), r):
+                    np.testing.assert_array_equal(t.cpu().numpy(), g[tag + name])   # identical inputs -> bit-exact survivors
+
+
+def test_detect_batch_end_to_end_vs_oracle(golden):
+    """Device-resident decode -> filter -> NMS on the head image; survivors must equal the oracle's run on the
+    GPU-decoded values (bit-exact given identical inputs)."""
+    import detect
+    g = golden('decode_voc')
+    feat = to_nhwc(torch.from_numpy(g['feature'])).to(dev())
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    for fix in (False, True):
+        d = detect.detect_batch(feat, anchors, fix=fix)
+        res = detect.postprocess_batch(d, fix=fix)
+        B = feat.size(0)
+        iou = d['iou'].view(B, -1).cpu().numpy()
+        mn, mx = d['yx_min'].view(B, -1, 2).cpu().numpy(), d['yx_max'].view(B, -1, 2).cpu().numpy()
+        prob = d['prob'].view(B, iou.shape[1], -1).cpu().numpy()
+        for b in range(B):
+            ref = odet.postprocess(iou[b], mn[b], mx[b], prob[b], fix=fix)
+            assert (ref is None) == (res[b] is None)
+            if ref is not None:
+                for got, want in zip(res[b], ref[:5]):
+                    np.testing.assert_array_equal(got.cpu().numpy(), want)

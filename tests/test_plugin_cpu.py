@@ -1,0 +1,70 @@
+"""CPU-side checks of the plugin boundary: constructor signature, state_dict keys/shapes identical to
+the reference plugin, ConfigChannels-driven widths, config-driven plugin resolution; construction is CPU-only."""
+import configparser
+
+import pytest
+import torch
+
+from oracle import darknet as odark
+from oracle import synth
+from oracle.make_golden import NARROW
+
+import model
+import model.yolo2
+import utils
+
+
+def config(bn=True):
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1' if bn else '0'}, 'model': {'dnn': 'model.yolo2.Darknet'}})
+    return cfg
+
+
+def test_state_dict_keys_and_shapes_match_reference_layout():
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    dnn = model.yolo2.Darknet(model.ConfigChannels(config()), anchors, 20)
+    sd = dnn.state_dict()
+    ref = odark.init_state_dict(5, 20)  # keys/shapes of the reference plugin (pinned by tests/test_oracle.py)
+    ours = {k: tuple(v.shape) for k, v in sd.items() if not k.endswith('num_batches_tracked')}
+    assert list(ours.keys()) == list(ref.keys())
+    for k, v in ref.items():
+        assert ours[k] == tuple(v.shape), k
+    assert sum(v.numel() for k, v in sd.items() if not k.endswith('num_batches_tracked') and 'running' not in k) == 50655389 - 0
+    assert all(not p.is_cuda for p in dnn.parameters())
+
+
+def test_plugin_resolution_by_dotted_path():
+    cls = utils.parse_attr(config().get('model', 'dnn'))
+    assert cls is model.yolo2.Darknet
+
+
+def test_config_channels_follow_checkpoint():
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    sd = odark.init_state_dict(5, 20, channels=NARROW)
+    dnn = model.yolo2.Darknet(model.ConfigChannels(config(), sd), anchors, 20)
+    res = dnn.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    assert all(k.endswith('num_batches_tracked') for k in res.missing_keys)
+    assert dnn.layers1[5].conv.weight.shape == (6, NARROW['layers1.4'], 1, 1)
+    assert dnn.layers3[0].conv.weight.shape[1] == 4 * NARROW['passthrough'] + NARROW['layers2.7']
+
+
+def test_no_batchnorm_variant_has_conv_bias():
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    dnn = model.yolo2.Darknet(model.ConfigChannels(config(bn=False)), anchors, 20)
+    keys = list(dnn.state_dict().keys())
+    assert 'layers1.0.conv.bias' in keys and not any('.bn.' in k for k in keys)
+
+
+def test_output_channels_and_meshgrid():
+    assert model.output_channels(5, 20) == 125 and model.output_channels(5, 80) == 425 and model.output_channels(5, 1) == 25
+    g = model.meshgrid(3, 3)
+    assert g.tolist()[:4] == [[0, 0], [0, 1], [0, 2], [1, 0]]
+
+
+def test_forward_refuses_cpu_tensor():
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    sd = odark.init_state_dict(5, 20, channels=NARROW)
+    dnn = model.yolo2.Darknet(model.ConfigChannels(config(), sd), anchors, 20).eval()
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        dnn(torch.zeros(1, 3, 32, 32))

@@ -1,0 +1,29 @@
+// Shared helpers for the gfx950 kernels of libyolo2_hip.so (no torch, no host allocation).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "yolo2_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define Y2_LAUNCH_CHECK()                                   \
+    do {                                                    \
+        hipError_t _e = hipGetLastError();                  \
+        if (_e != hipSuccess) return -(1000 + (int)_e);     \
+    } while (0)
+
+static inline hipStream_t y2_s(y2_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int y2_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline bool y2_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+constexpr int Y2_NUM_CU = 256;   // MI355X: 8 XCD x 32 CU
+constexpr int Y2_NUM_XCD = 8;
+
+// Bijective XCD-aware remap of a 1-D grid: hardware places block b on XCD b % 8, so give every XCD a
+// contiguous chunk of the logical tile list (neighbouring tiles share operand panels -> L2 hits).
+__device__ __forceinline__ int y2_xcd_remap(int bid, int nwg) {
+    const int q = nwg / Y2_NUM_XCD, r = nwg % Y2_NUM_XCD;
+    const int xcd = bid % Y2_NUM_XCD, i = bid / Y2_NUM_XCD;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}

@@ -1,0 +1,372 @@
+// conv_fwd.hip — fp32 MFMA implicit-GEMM convolution for gfx950 (MI355X), fused epilogue.
+//
+// Replaces model.yolo2.Conv2d.forward (model/yolo2.py:61-65: nn.Conv2d stride 1 "same" padding ->
+// BatchNorm2d (eval, folded) or bias -> LeakyReLU(0.1)) together with the MaxPool2d(2) that follows it
+// (model/yolo2.py:79,86,97), the passthrough reorg (model/yolo2.py:33-46) and the concat
+// (model/yolo2.py:129), which become output addressing.
+//
+// GEMM view:  D[m][n] = sum_k A[m][k] * B[k][n]
+//   m = output pixel (b, y, x)            M = B*H*W
+//   n = output channel                    N = Cout
+//   k = (tap, cin)                        K = ksize^2 * Cin       (tap-major, cin contiguous)
+//   A[m][k] = x[b, y+dy, x+dx, cin] (0 outside the image)   -> gathered on the fly from NHWC
+//   B[k][n] = w[n][tap][cin]                                 -> y2_pack_weight mode 0
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate — exact fp32, the parity requirement of
+// BASELINE.json "conv tensors within an fp32 tolerance"; gfx950 has no xf32).  Peak 157.3 TFLOP/s.
+//
+// Workgroup = 256 threads = 4 waves, tile BM x BN, K-slab BK = 32 per pipeline step:
+//   global -> registers (16-B loads, prefetch of slab s+1 issued before the MFMAs of slab s)
+//          -> LDS (double buffered, row stride 36 floats = 144 B so that ds_read_b128 of 16 different
+//             rows hits 16 different 16-B slots of the 256-B bank row: conflict-free)
+//          -> each lane reads a float4 = 4 consecutive k of its row; lanes 0-31 take k-offset 0 and lanes
+//             32-63 k-offset 4 inside each group of 8, so the 4 MFMAs fed by one read contract
+//             k = {j, 4+j} (j = 0..3).  A and B use the same permutation, so the sum over k is complete.
+//   one __syncthreads() per slab.  2 workgroups per CU stay resident (<= 73.7 KB LDS each).
+//
+// Row order inside a tile (POOLORD): when a 2x2 max-pool follows, pixel index m enumerates the image in
+// 2x2-window-major order (m = ((p*W/2 + q)*4 + wy*2 + wx), y = 2p+wy, x = 2q+wx), so the four rows held by
+// one lane in accumulator registers 4g..4g+3 (MFMA C layout: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) are
+// exactly one pooling window: the pool is 3 v_max per output in-lane, and m>>2 is the pooled pixel's
+// ordinary row-major index.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;     // floats of K per pipeline step
+constexpr int LDSS = 36;   // LDS row stride (floats)
+constexpr int NT = 256;
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    float* y;
+    float* y_pool;
+    double* stats;
+    int B, H, W, Cin, ldx, Cout, taps;  // taps = 1 or 9
+    int ldy, coff, ldp, poff, out_mode;
+    float slope;
+    int M, tiles_m, tiles_n, cchunks;   // cchunks = ceil(Cin / BK)
+};
+
+// pixel index (b*H + y)*W + x and (y, x) of GEMM row m
+template <bool POOLORD>
+__device__ __forceinline__ void decode_row(const ConvArgs& a, int m, int& pix, int& y, int& x) {
+    const int hw = a.H * a.W;
+    const int b = m / hw;
+    const int idx = m - b * hw;
+    if (POOLORD) {
+        const int w2 = 2 * a.W;
+        const int p = idx / w2;
+        const int rem = idx - p * w2;
+        y = 2 * p + ((rem >> 1) & 1);
+        x = 2 * (rem >> 2) + (rem & 1);
+    } else {
+        y = idx / a.W;
+        x = idx - y * a.W;
+    }
+    pix = (b * a.H + y) * a.W + x;
+}
+
+template <int BM, int BN, int WAVES_M, bool POOLORD, bool VEC>
+__global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvArgs a) {
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MB = WM / 32, NB = WN / 32;
+    constexpr int AR = BM / 32, BR = BN / 32;   // rows each thread stages per slab
+    constexpr int STAGE = (BM + BN) * LDSS;      // floats per LDS buffer
+    static_assert(MB >= 1 && NB >= 1, "wave tile must be a multiple of 32x32");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int wg = y2_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n;
+    const int tile_m = wg / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- staging assignment: thread t -> 16-B slot (t&7) of rows (t>>3) + 32*i
+    const int slot = t & 7;
+    const int srow = t >> 3;
+    int a_pix[AR], a_y[AR], a_x[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + srow + 32 * i;
+        if (m < a.M) {
+            decode_row<POOLORD>(a, m, a_pix[i], a_y[i], a_x[i]);
+        } else {
+            a_pix[i] = 0; a_y[i] = -(1 << 20); a_x[i] = -(1 << 20);   // never inside the image
+        }
+    }
+    const int ktot = a.taps * a.Cin;
+    size_t b_off[BR];
+    bool b_ok[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + srow + 32 * i;
+        b_ok[i] = n < a.Cout;
+        b_off[i] = (size_t)(b_ok[i] ? n : 0) * ktot;
+    }
+
+    f32x4 ra[AR], rb[BR];
+
+    auto load_slab = [&](int tap, int c0) {
+        const int dy = (a.taps == 9) ? tap / 3 - 1 : 0;
+        const int dx = (a.taps == 9) ? tap % 3 - 1 : 0;
+        const int c = c0 + 4 * slot;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)a.H && (unsigned)(a_x[i] + dx) < (unsigned)a.W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (VEC) {
+                // branch-free: always issue the 16-B load (from a safe address when masked), then select
+                const bool okc = ok && c < a.Cin;
+                const size_t off = okc ? (size_t)(a_pix[i] + dy * a.W + dx) * a.ldx + c : 0;
+                const f32x4 ld = *reinterpret_cast<const f32x4*>(a.x + off);
+                v = okc ? ld : v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool okc = ok && c + e < a.Cin;
+                    const size_t off = okc ? (size_t)(a_pix[i] + dy * a.W + dx) * a.ldx + c + e : 0;
+                    const float ld = a.x[off];
+                    v[e] = okc ? ld : 0.f;
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (VEC) {
+                const bool okc = b_ok[i] && c < a.Cin;
+                const size_t off = okc ? b_off[i] + (size_t)tap * a.Cin + c : 0;
+                const f32x4 ld = *reinterpret_cast<const f32x4*>(a.w + off);
+                v = okc ? ld : v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool okc = b_ok[i] && c + e < a.Cin;
+                    const size_t off = okc ? b_off[i] + (size_t)tap * a.Cin + c + e : 0;
+                    const float ld = a.w[off];
+                    v[e] = okc ? ld : 0.f;
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_slab = [&](int buf) {
+        float* sa = smem + buf * STAGE;
+        float* sb = sa + BM * LDSS;
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            *reinterpret_cast<f32x4*>(sa + (srow + 32 * i) * LDSS + 4 * slot) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            *reinterpret_cast<f32x4*>(sb + (srow + 32 * i) * LDSS + 4 * slot) = rb[i];
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = a.taps * a.cchunks;
+    int tap = 0, c0 = 0;
+    load_slab(0, 0);
+    store_slab(0);
+    __syncthreads();
+
+    // fragment read bases (floats): row * LDSS + 4*half, + 8*q per k-group
+    const int fa = (wm * WM + l31) * LDSS + 4 * half;
+    const int fb = BM * LDSS + (wn * WN + l31) * LDSS + 4 * half;
+
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        const bool more = ks + 1 < nk;
+        if (more) {
+            c0 += BK;
+            if (c0 >= a.Cin) { c0 = 0; ++tap; }
+            load_slab(tap, c0);               // global loads in flight under the MFMAs below
+        }
+        const float* sbuf = smem + buf * STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 fa4[MB], fb4[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+                fa4[i] = *reinterpret_cast<const f32x4*>(sbuf + fa + i * 32 * LDSS + 8 * q);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                fb4[j] = *reinterpret_cast<const f32x4*>(sbuf + fb + j * 32 * LDSS + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa4[i][e], fb4[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // C layout of v_mfma_f32_32x32x2_f32: lane -> column n = lane&31; register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool do_full = a.y != nullptr;
+    const bool do_pool = a.y_pool != nullptr;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        const bool nok = n < a.Cout;
+        const float sc = (a.scale != nullptr && nok) ? a.scale[n] : 1.f;
+        const float sh = (a.shift != nullptr && nok) ? a.shift[n] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int mq = m0 + wm * WM + i * 32 + 8 * g + 4 * half;   // first row of this register quad
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float z = acc[i][j][4 * g + e];
+                    s1 += z;
+                    s2 += z * z;
+                    const float u = z * sc + sh;
+                    v[e] = u > 0.f ? u : u * a.slope;
+                }
+                if (!nok || mq >= a.M) continue;
+                if (do_full) {
+                    if (POOLORD || a.out_mode == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (mq + e >= a.M) break;
+                            int pix, yy, xx;
+                            decode_row<POOLORD>(a, mq + e, pix, yy, xx);
+                            if (a.out_mode == 1) {
+                                const int b = pix / (a.H * a.W);
+                                const int opix = (b * (a.H >> 1) + (yy >> 1)) * (a.W >> 1) + (xx >> 1);
+                                a.y[(size_t)opix * a.ldy + a.coff + ((yy & 1) * 2 + (xx & 1)) * a.Cout + n] = v[e];
+                            } else {
+                                a.y[(size_t)pix * a.ldy + a.coff + n] = v[e];
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (mq + e < a.M) a.y[(size_t)(mq + e) * a.ldy + a.coff + n] = v[e];
+                    }
+                }
+                if (POOLORD && do_pool) {
+                    // H, W even => M % 4 == 0 and the quad is one complete 2x2 window
+                    const float pm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    a.y_pool[(size_t)(mq >> 2) * a.ldp + a.poff + n] = pm;
+                }
+            }
+        }
+        if (a.stats != nullptr) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (half == 0 && nok) {
+                atomicAdd(a.stats + n, (double)s1);
+                atomicAdd(a.stats + a.Cout + n, (double)s2);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, bool POOLORD, bool VEC>
+int launch(const ConvArgs& a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    a.tiles_m = y2_cdiv(a.M, BM);
+    a.tiles_n = y2_cdiv(a.Cout, BN);
+    const size_t lds = 2u * (BM + BN) * LDSS * sizeof(float);
+    auto kern = conv_fwd_kernel<BM, BN, WAVES_M, POOLORD, VEC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(1000 + (int)e);
+        attr_set = true;
+    }
+    const long long grid = (long long)a.tiles_m * a.tiles_n;
+    if (grid <= 0 || grid > 0x7fffffffLL) return Y2_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+template <bool POOLORD, bool VEC>
+int dispatch_tile(const ConvArgs& a, int tile, hipStream_t s) {
+    switch (tile) {
+        case 1: return launch<128, 128, 2, POOLORD, VEC>(a, s);
+        case 2: return launch<128, 64, 2, POOLORD, VEC>(a, s);
+        case 3: return launch<64, 64, 2, POOLORD, VEC>(a, s);
+        case 4: return launch<256, 64, 4, POOLORD, VEC>(a, s);
+        case 5: return launch<64, 128, 2, POOLORD, VEC>(a, s);
+        default: return Y2_ENOSUP;
+    }
+}
+
+// Pick the tile that minimises (waves of workgroups over the chip) x (work per workgroup) / efficiency.
+int choose_tile(long long M, int Cout) {
+    struct Cand { int id, bm, bn; double eff; };
+    // eff: relative main-loop efficiency of the config (bigger tiles amortise staging better); tuned on MI355X
+    const Cand cands[] = {{1, 128, 128, 1.00}, {2, 128, 64, 0.92}, {5, 64, 128, 0.92}, {3, 64, 64, 0.80}};
+    const double slots = 2.0 * Y2_NUM_CU;   // 2 resident workgroups per CU share one MFMA pipe
+    int best = 1;
+    double best_cost = 1e300;
+    for (const Cand& c : cands) {
+        const double tiles = (double)y2_cdiv(M, c.bm) * y2_cdiv(Cout, c.bn);
+        // time ~ ceil(tiles / CUs) rounds when every CU is saturated by >= 1 workgroup
+        const double rounds = (double)y2_cdiv((long long)tiles, Y2_NUM_CU);
+        const double cost = rounds * c.bm * c.bn / c.eff;
+        (void)slots;
+        if (cost < best_cost) { best_cost = cost; best = c.id; }
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream) {
+    if (p == nullptr || p->x == nullptr || p->w == nullptr) return Y2_EINVAL;
+    if (p->y == nullptr && p->y_pool == nullptr && p->stats == nullptr) return Y2_EINVAL;
+    if (p->B <= 0 || p->H <= 0 || p->W <= 0 || p->Cin <= 0 || p->Cout <= 0) return Y2_EINVAL;
+    if (p->ksize != 1 && p->ksize != 3) return Y2_ENOSUP;
+    if (p->ldx < p->Cin) return Y2_EINVAL;
+    if (p->y != nullptr && p->out_mode == 0 && p->ldy < p->coff + p->Cout) return Y2_EINVAL;
+    if (p->y != nullptr && p->out_mode == 1 && (p->ldy < p->coff + 4 * p->Cout || (p->H & 1) || (p->W & 1))) return Y2_EINVAL;
+    if (p->out_mode != 0 && p->out_mode != 1) return Y2_EINVAL;
+    const bool pool = p->y_pool != nullptr;
+    if (pool && ((p->H & 1) || (p->W & 1) || p->ldp < p->poff + p->Cout)) return Y2_EINVAL;
+    const long long M = (long long)p->B * p->H * p->W;
+    if (M > 0x7fffffffLL / 2) return Y2_EINVAL;
+
+    ConvArgs a;
+    a.x = p->x; a.w = p->w; a.scale = p->scale; a.shift = p->shift;
+    a.y = p->y; a.y_pool = p->y_pool; a.stats = p->stats;
+    a.B = p->B; a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.ldx = p->ldx; a.Cout = p->Cout;
+    a.taps = p->ksize * p->ksize;
+    a.ldy = p->ldy; a.coff = p->coff; a.ldp = p->ldp; a.poff = p->poff; a.out_mode = p->out_mode;
+    a.slope = p->slope;
+    a.M = (int)M;
+    a.cchunks = y2_cdiv(p->Cin, BK);
+    a.tiles_m = a.tiles_n = 0;
+
+    const bool vec = (p->Cin % 4 == 0) && (p->ldx % 4 == 0) && y2_aligned16(p->x) && y2_aligned16(p->w);
+    const int tile = p->tile > 0 ? p->tile : choose_tile(M, p->Cout);
+    hipStream_t s = y2_s(stream);
+    if (pool) return vec ? dispatch_tile<true, true>(a, tile, s) : dispatch_tile<true, false>(a, tile, s);
+    return vec ? dispatch_tile<false, true>(a, tile, s) : dispatch_tile<false, false>(a, tile, s);
+}

@@ -1,0 +1,103 @@
+// misc.hip — weight repacking, BatchNorm folding, stand-alone 2x2 max-pool (HBM-bound streaming kernels).
+#include "common.h"
+
+namespace {
+
+// dst index -> src index gather; coalesced writes.
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int taps, int mode, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        if (mode == 0) {          // dst[co][tap][ci] = w[co][ci][tap]
+            const int ci = (int)(i % Cin);
+            const long long r = i / Cin;
+            const int tap = (int)(r % taps);
+            const int co = (int)(r / taps);
+            dst[i] = w[((long long)co * Cin + ci) * taps + tap];
+        } else if (mode == 1) {   // dst[ci][taps-1-tap][co] = w[co][ci][tap]   (dgrad: rotated filter, in/out swapped)
+            const int co = (int)(i % Cout);
+            const long long r = i / Cout;
+            const int tr = (int)(r % taps);
+            const int ci = (int)(r / taps);
+            dst[i] = w[((long long)co * Cin + ci) * taps + (taps - 1 - tr)];
+        } else {                  // mode 2: dst[co][ci][tap] = src[co][tap][ci]   (weight-gradient unpack)
+            const int tap = (int)(i % taps);
+            const long long r = i / taps;
+            const int ci = (int)(r % Cin);
+            const int co = (int)(r / Cin);
+            dst[i] = w[((long long)co * taps + tap) * Cin + ci];
+        }
+    }
+}
+
+__global__ void bn_fold_kernel(const float* g, const float* b, const float* m, const float* v, float eps, float* scale, float* shift, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) {
+        const float s = g[i] / sqrtf(v[i] + eps);
+        scale[i] = s;
+        shift[i] = b[i] - m[i] * s;
+    }
+}
+
+// one thread = 4 channels of one output pixel; 16-B loads/stores
+__global__ void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int Ho, int Wo, int C4, int ldx, int ldy, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long long p = i / C4;            // output pixel (b*Ho + yo)*Wo + xo
+        const int xo = (int)(p % Wo);
+        const long long r = p / Wo;            // b*Ho + yo
+        const long long in_row = 2 * r;        // b*H + 2*yo  (H = 2*Ho)
+        const float* s = x + ((in_row * (2 * Wo)) + 2 * xo) * (long long)ldx + 4 * c4;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(s);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(s + ldx);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(s + (long long)2 * Wo * ldx);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(s + (long long)2 * Wo * ldx + ldx);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
+        *reinterpret_cast<f32x4*>(y + p * ldy + 4 * c4) = o;
+    }
+}
+
+inline int stream_grid(long long total, int block) {
+    long long g = (total + block - 1) / block;
+    const long long cap = (long long)Y2_NUM_CU * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int y2_abi_version(void) { return 1; }
+extern "C" const char* y2_build_info(void) { return "libyolo2_hip gfx950 fp32-mfma abi1"; }
+
+extern "C" int y2_pack_weight(const float* w, float* dst, int Cout, int Cin, int ksize, int mode, y2_stream_t stream) {
+    if (w == nullptr || dst == nullptr || Cout <= 0 || Cin <= 0 || ksize <= 0 || (mode != 0 && mode != 1)) return Y2_EINVAL;
+    const long long total = (long long)Cout * Cin * ksize * ksize;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), w, dst, Cout, Cin, ksize * ksize, mode, total);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_unpack_weight_grad(const float* src, float* dst, int Cout, int Cin, int ksize, y2_stream_t stream) {
+    if (src == nullptr || dst == nullptr || Cout <= 0 || Cin <= 0 || ksize <= 0) return Y2_EINVAL;
+    const long long total = (long long)Cout * Cin * ksize * ksize;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), src, dst, Cout, Cin, ksize * ksize, 2, total);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                          float* scale, float* shift, int C, y2_stream_t stream) {
+    if (!gamma || !beta || !mean || !var || !scale || !shift || C <= 0) return Y2_EINVAL;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(y2_cdiv(C, 256)), dim3(256), 0, y2_s(stream), gamma, beta, mean, var, eps, scale, shift, C);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, y2_stream_t stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return Y2_EINVAL;
+    if ((H & 1) || (W & 1) || ldx < C || ldy < C) return Y2_EINVAL;
+    if ((C & 3) || (ldx & 3) || (ldy & 3) || !y2_aligned16(x) || !y2_aligned16(y)) return Y2_EALIGN;
+    const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, y, H / 2, W / 2, C / 4, ldx, ldy, total);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}

@@ -1,0 +1,36 @@
+"""`utils.postprocess` — greedy NMS, MI355X-native (utils/postprocess.py:23-49).
+
+`nms` keeps the reference signature and returns a Python list of indices (descending score).  `nms_batch` is
+the device-resident form used by detect.postprocess_batch: all images of a batch in one launch pair, no host
+round trip.
+"""
+import torch
+
+import _hip
+
+
+def nms_batch(score, yx_min, yx_max, n, overlap=0.5, limit=200, cand=None):
+    """score [B,stride], yx_min/yx_max [B,stride,2], n int32 [B] (valid candidates per image), optional
+    cand int32 [B,stride] (candidate i of image b = row cand[b,i]; the output of detect.filter_visible_batch).
+    Returns (keep int32 [B,limit] = positions in the candidate list, keep_count int32 [B]) on the GPU."""
+    _hip.require_gpu(score, yx_min, yx_max, n)
+    score, yx_min, yx_max = (_hip.f32c(t) for t in (score, yx_min, yx_max))
+    B, stride = score.shape
+    dev = score.device
+    n = n.to(torch.int32).contiguous()
+    order = torch.empty(B, limit, dtype=torch.int32, device=dev)
+    keep = torch.empty(B, limit, dtype=torch.int32, device=dev)
+    cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    _hip.check(_hip.lib().y2_nms(_hip.ptr(score), _hip.ptr(yx_min), _hip.ptr(yx_max), _hip.ptr(cand), _hip.ptr(n), B, stride, overlap, limit,
+                                 _hip.ptr(order), _hip.ptr(keep), _hip.ptr(cnt), _hip.stream()), 'y2_nms')
+    return keep, cnt
+
+
+def nms(score, yx_min, yx_max, overlap=0.5, limit=200):
+    """utils/postprocess.py:23-49: indices of the selected boxes, in descending-score order."""
+    keep = []
+    if score.numel() == 0:
+        return keep
+    n = torch.tensor([score.numel()], dtype=torch.int32, device=score.device)
+    k, c = nms_batch(score.reshape(1, -1), yx_min.reshape(1, -1, 2), yx_max.reshape(1, -1, 2), n, overlap, limit)
+    return k[0, :int(c.item())].tolist()
