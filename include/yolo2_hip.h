@@ -93,7 +93,7 @@ int y2_conv0_fwd(const float* x_nchw, const float* w, const float* scale, const 
                  float* y, float* y_pool, double* stats,
                  int B, int H, int W, int Cin, int Cout, int ldy, int ldp, float slope, y2_stream_t stream);
 
-/* nn.MaxPool2d(kernel_size=2) (model/yolo2.py:79,86,97) on NHWC; H, W even; C % 4 == 0. */
+/* nn.MaxPool2d(kernel_size=2) (model/yolo2.py:79,86,97) on NHWC; H, W even (16-B vector path when C, ldx, ldy are multiples of 4). */
 int y2_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, y2_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -175,11 +175,12 @@ def test_conv0_matches_fp64_reference(B, cin, cout, H, W):
 
 def test_maxpool2():
     import _hip
-    x = torch.randn(2, 8, 12, 16)
-    xd = to_nhwc(x).to(dev())
-    y = torch.empty(2, 4, 6, 16, device=dev())
-    _hip.check(_hip.lib().y2_maxpool2_fwd(_hip.ptr(xd), _hip.ptr(y), 2, 8, 12, 16, 16, 16, _hip.stream()), 'pool')
-    assert torch.equal(y.cpu().permute(0, 3, 1, 2), F.max_pool2d(x, 2))
+    for C in (16, 6):   # 16-B vector path and scalar path (pruned widths)
+        x = torch.randn(2, C, 8, 12)
+        xd = to_nhwc(x).to(dev())
+        y = torch.empty(2, 4, 6, C, device=dev())
+        _hip.check(_hip.lib().y2_maxpool2_fwd(_hip.ptr(xd), _hip.ptr(y), 2, 8, 12, C, C, C, _hip.stream()), 'pool')
+        assert torch.equal(y.cpu().permute(0, 3, 1, 2), F.max_pool2d(x, 2))
 
 
 # ------------------------------------------------------------------ the plugin end to end

@@ -37,9 +37,12 @@ constexpr int BK = 32;     // floats of K per pipeline step
 constexpr int LDSS = 36;   // LDS row stride (floats)
 constexpr int NT = 256;
 
+__device__ __attribute__((aligned(16))) float y2_zero16_storage[4] = {0.f, 0.f, 0.f, 0.f};
+
 struct ConvArgs {
     const float* x;
     const float* w;
+    const float* zeros;   // 16 B of zeros in global memory (masked loads read here; a kernarg pointer keeps them global_load)
     const float* scale;
     const float* shift;
     float* y;
@@ -124,42 +127,40 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)a.H && (unsigned)(a_x[i] + dx) < (unsigned)a.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            // Masked elements are fetched from a 16-B block of zeros instead of being selected after the load: the
+            // loaded registers then have no VALU consumer before the ds_write, so the compiler's s_waitcnt vmcnt
+            // lands AFTER the MFMAs of the current slab (the select form put it right behind the loads).
             if (VEC) {
-                // branch-free: always issue the 16-B load (from a safe address when masked), then select
                 const bool okc = ok && c < a.Cin;
-                const size_t off = okc ? (size_t)(a_pix[i] + dy * a.W + dx) * a.ldx + c : 0;
-                const f32x4 ld = *reinterpret_cast<const f32x4*>(a.x + off);
-                v = okc ? ld : v;
+                const float* src = okc ? a.x + ((size_t)(a_pix[i] + dy * a.W + dx) * a.ldx + c) : a.zeros;
+                ra[i] = *reinterpret_cast<const f32x4*>(src);
             } else {
+                f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const bool okc = ok && c + e < a.Cin;
-                    const size_t off = okc ? (size_t)(a_pix[i] + dy * a.W + dx) * a.ldx + c + e : 0;
-                    const float ld = a.x[off];
-                    v[e] = okc ? ld : 0.f;
+                    const float* src = okc ? a.x + ((size_t)(a_pix[i] + dy * a.W + dx) * a.ldx + c + e) : a.zeros;
+                    v[e] = *src;
                 }
+                ra[i] = v;
             }
-            ra[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (VEC) {
                 const bool okc = b_ok[i] && c < a.Cin;
-                const size_t off = okc ? b_off[i] + (size_t)tap * a.Cin + c : 0;
-                const f32x4 ld = *reinterpret_cast<const f32x4*>(a.w + off);
-                v = okc ? ld : v;
+                const float* src = okc ? a.w + (b_off[i] + (size_t)tap * a.Cin + c) : a.zeros;
+                rb[i] = *reinterpret_cast<const f32x4*>(src);
             } else {
+                f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const bool okc = b_ok[i] && c + e < a.Cin;
-                    const size_t off = okc ? b_off[i] + (size_t)tap * a.Cin + c + e : 0;
-                    const float ld = a.w[off];
-                    v[e] = okc ? ld : 0.f;
+                    const float* src = okc ? a.w + (b_off[i] + (size_t)tap * a.Cin + c + e) : a.zeros;
+                    v[e] = *src;
                 }
+                rb[i] = v;
             }
-            rb[i] = v;
         }
     };
     auto store_slab = [&](int buf) {
@@ -363,6 +364,14 @@ extern "C" int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream) {
     a.M = (int)M;
     a.cchunks = y2_cdiv(p->Cin, BK);
     a.tiles_m = a.tiles_n = 0;
+    static const float* zeros = nullptr;
+    if (zeros == nullptr) {
+        void* zp = nullptr;
+        hipError_t e = hipGetSymbolAddress(&zp, HIP_SYMBOL(y2_zero16_storage));
+        if (e != hipSuccess) return -(1000 + (int)e);
+        zeros = static_cast<const float*>(zp);
+    }
+    a.zeros = zeros;
 
     const bool vec = (p->Cin % 4 == 0) && (p->ldx % 4 == 0) && y2_aligned16(p->x) && y2_aligned16(p->w);
     const int tile = p->tile > 0 ? p->tile : choose_tile(M, p->Cout);

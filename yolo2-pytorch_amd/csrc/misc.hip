@@ -57,6 +57,19 @@ __global__ void maxpool2_kernel(const float* __restrict__ x, float* __restrict__
     }
 }
 
+// scalar variant for channel counts that are not a multiple of 4 (pruned checkpoints)
+__global__ void maxpool2_scalar_kernel(const float* __restrict__ x, float* __restrict__ y, int Ho, int Wo, int C, int ldx, int ldy, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long p = i / C;
+        const int xo = (int)(p % Wo);
+        const long long r = p / Wo;
+        const float* s = x + ((2 * r * (2 * Wo)) + 2 * xo) * (long long)ldx + c;
+        const long long row = (long long)2 * Wo * ldx;
+        y[p * ldy + c] = fmaxf(fmaxf(s[0], s[ldx]), fmaxf(s[row], s[row + ldx]));
+    }
+}
+
 inline int stream_grid(long long total, int block) {
     long long g = (total + block - 1) / block;
     const long long cap = (long long)Y2_NUM_CU * 8;
@@ -95,7 +108,12 @@ extern "C" int y2_bn_fold(const float* gamma, const float* beta, const float* me
 extern "C" int y2_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, y2_stream_t stream) {
     if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return Y2_EINVAL;
     if ((H & 1) || (W & 1) || ldx < C || ldy < C) return Y2_EINVAL;
-    if ((C & 3) || (ldx & 3) || (ldy & 3) || !y2_aligned16(x) || !y2_aligned16(y)) return Y2_EALIGN;
+    if ((C & 3) || (ldx & 3) || (ldy & 3) || !y2_aligned16(x) || !y2_aligned16(y)) {
+        const long long tot = (long long)B * (H / 2) * (W / 2) * C;
+        hipLaunchKernelGGL(maxpool2_scalar_kernel, dim3(stream_grid(tot, 256)), dim3(256), 0, y2_s(stream), x, y, H / 2, W / 2, C, ldx, ldy, tot);
+        Y2_LAUNCH_CHECK();
+        return Y2_OK;
+    }
     const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(maxpool2_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, y, H / 2, W / 2, C / 4, ldx, ldy, total);
     Y2_LAUNCH_CHECK();
