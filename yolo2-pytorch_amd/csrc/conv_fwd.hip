@@ -29,12 +29,12 @@
 // one lane in accumulator registers 4g..4g+3 (MFMA C layout: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) are
 // exactly one pooling window: the pool is 3 v_max per output in-lane, and m>>2 is the pooled pixel's
 // ordinary row-major index.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
 
-constexpr int BK = 32;     // floats of K per pipeline step
-constexpr int LDSS = 36;   // LDS row stride (floats)
+constexpr int BK_DEFAULT = 32;   // floats of K per pipeline step (template parameter BK of the kernel)
 constexpr int NT = 256;
 
 __device__ __attribute__((aligned(16))) float y2_zero16_storage[4] = {0.f, 0.f, 0.f, 0.f};
@@ -52,6 +52,7 @@ struct ConvArgs {
     int ldy, coff, ldp, poff, out_mode;
     float slope;
     int M, tiles_m, tiles_n, cchunks;   // cchunks = ceil(Cin / BK)
+    unsigned x_bytes, w_bytes;          // buffer-descriptor ranges of x and w (DMA kernel)
 };
 
 // pixel index (b*H + y)*W + x and (y, x) of GEMM row m
@@ -73,157 +74,10 @@ __device__ __forceinline__ void decode_row(const ConvArgs& a, int m, int& pix, i
     pix = (b * a.H + y) * a.W + x;
 }
 
-template <int BM, int BN, int WAVES_M, bool POOLORD, bool VEC>
-__global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvArgs a) {
-    constexpr int WAVES_N = 4 / WAVES_M;
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-    constexpr int MB = WM / 32, NB = WN / 32;
-    constexpr int AR = BM / 32, BR = BN / 32;   // rows each thread stages per slab
-    constexpr int STAGE = (BM + BN) * LDSS;      // floats per LDS buffer
-    static_assert(MB >= 1 && NB >= 1, "wave tile must be a multiple of 32x32");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = t >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int l31 = lane & 31, half = lane >> 5;
-
-    const int wg = y2_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = wg % a.tiles_n;
-    const int tile_m = wg / a.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // ---- staging assignment: thread t -> 16-B slot (t&7) of rows (t>>3) + 32*i
-    const int slot = t & 7;
-    const int srow = t >> 3;
-    int a_pix[AR], a_y[AR], a_x[AR];
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        const int m = m0 + srow + 32 * i;
-        if (m < a.M) {
-            decode_row<POOLORD>(a, m, a_pix[i], a_y[i], a_x[i]);
-        } else {
-            a_pix[i] = 0; a_y[i] = -(1 << 20); a_x[i] = -(1 << 20);   // never inside the image
-        }
-    }
-    const int ktot = a.taps * a.Cin;
-    size_t b_off[BR];
-    bool b_ok[BR];
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-        const int n = n0 + srow + 32 * i;
-        b_ok[i] = n < a.Cout;
-        b_off[i] = (size_t)(b_ok[i] ? n : 0) * ktot;
-    }
-
-    f32x4 ra[AR], rb[BR];
-
-    auto load_slab = [&](int tap, int c0) {
-        const int dy = (a.taps == 9) ? tap / 3 - 1 : 0;
-        const int dx = (a.taps == 9) ? tap % 3 - 1 : 0;
-        const int c = c0 + 4 * slot;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)a.H && (unsigned)(a_x[i] + dx) < (unsigned)a.W;
-            // Masked elements are fetched from a 16-B block of zeros instead of being selected after the load: the
-            // loaded registers then have no VALU consumer before the ds_write, so the compiler's s_waitcnt vmcnt
-            // lands AFTER the MFMAs of the current slab (the select form put it right behind the loads).
-            if (VEC) {
-                const bool okc = ok && c < a.Cin;
-                const float* src = okc ? a.x + ((size_t)(a_pix[i] + dy * a.W + dx) * a.ldx + c) : a.zeros;
-                ra[i] = *reinterpret_cast<const f32x4*>(src);
-            } else {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool okc = ok && c + e < a.Cin;
-                    const float* src = okc ? a.x + ((size_t)(a_pix[i] + dy * a.W + dx) * a.ldx + c + e) : a.zeros;
-                    v[e] = *src;
-                }
-                ra[i] = v;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            if (VEC) {
-                const bool okc = b_ok[i] && c < a.Cin;
-                const float* src = okc ? a.w + (b_off[i] + (size_t)tap * a.Cin + c) : a.zeros;
-                rb[i] = *reinterpret_cast<const f32x4*>(src);
-            } else {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool okc = b_ok[i] && c + e < a.Cin;
-                    const float* src = okc ? a.w + (b_off[i] + (size_t)tap * a.Cin + c + e) : a.zeros;
-                    v[e] = *src;
-                }
-                rb[i] = v;
-            }
-        }
-    };
-    auto store_slab = [&](int buf) {
-        float* sa = smem + buf * STAGE;
-        float* sb = sa + BM * LDSS;
-#pragma unroll
-        for (int i = 0; i < AR; ++i)
-            *reinterpret_cast<f32x4*>(sa + (srow + 32 * i) * LDSS + 4 * slot) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BR; ++i)
-            *reinterpret_cast<f32x4*>(sb + (srow + 32 * i) * LDSS + 4 * slot) = rb[i];
-    };
-
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = a.taps * a.cchunks;
-    int tap = 0, c0 = 0;
-    load_slab(0, 0);
-    store_slab(0);
-    __syncthreads();
-
-    // fragment read bases (floats): row * LDSS + 4*half, + 8*q per k-group
-    const int fa = (wm * WM + l31) * LDSS + 4 * half;
-    const int fb = BM * LDSS + (wn * WN + l31) * LDSS + 4 * half;
-
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        const bool more = ks + 1 < nk;
-        if (more) {
-            c0 += BK;
-            if (c0 >= a.Cin) { c0 = 0; ++tap; }
-            load_slab(tap, c0);               // global loads in flight under the MFMAs below
-        }
-        const float* sbuf = smem + buf * STAGE;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 fa4[MB], fb4[NB];
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-                fa4[i] = *reinterpret_cast<const f32x4*>(sbuf + fa + i * 32 * LDSS + 8 * q);
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-                fb4[j] = *reinterpret_cast<const f32x4*>(sbuf + fb + j * 32 * LDSS + 8 * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < MB; ++i)
-#pragma unroll
-                    for (int j = 0; j < NB; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa4[i][e], fb4[j][e], acc[i][j], 0, 0, 0);
-        }
-        if (more) store_slab(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---------------------------------------------------------------- epilogue
-    // C layout of v_mfma_f32_32x32x2_f32: lane -> column n = lane&31; register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5)
+// ------------------------------------------------------------------------------------------------ epilogue
+// C layout of v_mfma_f32_32x32x2_f32: lane -> column n = lane&31; register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int MB, int NB, int WM, int WN, bool POOLORD>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MB][NB], int m0, int n0, int wm, int wn, int l31, int half) {
     const bool do_full = a.y != nullptr;
     const bool do_pool = a.y_pool != nullptr;
 #pragma unroll
@@ -287,16 +141,324 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvArgs a) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, bool POOLORD, bool VEC>
+template <int BM, int BN, int WAVES_M, int BK, bool POOLORD, bool VEC, int ABLATE = 0>
+__global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvArgs a) {
+    constexpr int LDSS = BK + 4;                 // LDS row stride (floats): (BK+4)*4 B = odd multiple of 16 B -> conflict-free b128 reads
+    constexpr int SLOTS = BK / 4;                // 16-B slots per row
+    constexpr int RPP = NT / SLOTS;              // rows staged per pass of the 256 threads
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MB = WM / 32, NB = WN / 32;
+    constexpr int AR = BM / RPP, BR = BN / RPP;  // rows each thread stages per slab
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
+    constexpr int STAGE = (BM + BN) * LDSS;      // floats per LDS buffer
+    static_assert(MB >= 1 && NB >= 1, "wave tile must be a multiple of 32x32");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int wg = y2_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n;
+    const int tile_m = wg / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- staging assignment: thread t -> 16-B slot (t&7) of rows (t>>3) + 32*i
+    const int slot = t % SLOTS;
+    const int srow = t / SLOTS;
+    int a_pix[AR], a_y[AR], a_x[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + srow + RPP * i;
+        if (m < a.M) {
+            decode_row<POOLORD>(a, m, a_pix[i], a_y[i], a_x[i]);
+        } else {
+            a_pix[i] = 0; a_y[i] = -(1 << 20); a_x[i] = -(1 << 20);   // never inside the image
+        }
+    }
+    const int ktot = a.taps * a.Cin;
+    size_t b_off[BR];
+    bool b_ok[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + srow + RPP * i;
+        b_ok[i] = n < a.Cout;
+        b_off[i] = (size_t)(b_ok[i] ? n : 0) * ktot;
+    }
+
+    f32x4 ra[AR], rb[BR];
+
+    auto load_slab = [&](int tap, int c0) {
+        const int dy = (a.taps == 9) ? tap / 3 - 1 : 0;
+        const int dx = (a.taps == 9) ? tap % 3 - 1 : 0;
+        const int c = c0 + 4 * slot;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)a.H && (unsigned)(a_x[i] + dx) < (unsigned)a.W;
+            // Masked elements are fetched from a 16-B block of zeros instead of being selected after the load: the
+            // loaded registers then have no VALU consumer before the ds_write, so the compiler's s_waitcnt vmcnt
+            // lands AFTER the MFMAs of the current slab (the select form put it right behind the loads).
+            if (VEC) {
+                const bool okc = ok && c < a.Cin;
+                const float* src = okc ? a.x + ((size_t)(a_pix[i] + dy * a.W + dx) * a.ldx + c) : a.zeros;
+                ra[i] = *reinterpret_cast<const f32x4*>(src);
+            } else {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool okc = ok && c + e < a.Cin;
+                    const float* src = okc ? a.x + ((size_t)(a_pix[i] + dy * a.W + dx) * a.ldx + c + e) : a.zeros;
+                    v[e] = *src;
+                }
+                ra[i] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            if (VEC) {
+                const bool okc = b_ok[i] && c < a.Cin;
+                const float* src = okc ? a.w + (b_off[i] + (size_t)tap * a.Cin + c) : a.zeros;
+                rb[i] = *reinterpret_cast<const f32x4*>(src);
+            } else {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool okc = b_ok[i] && c + e < a.Cin;
+                    const float* src = okc ? a.w + (b_off[i] + (size_t)tap * a.Cin + c + e) : a.zeros;
+                    v[e] = *src;
+                }
+                rb[i] = v;
+            }
+        }
+    };
+    auto store_slab = [&](int buf) {
+        float* sa = smem + buf * STAGE;
+        float* sb = sa + BM * LDSS;
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            *reinterpret_cast<f32x4*>(sa + (srow + RPP * i) * LDSS + 4 * slot) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            *reinterpret_cast<f32x4*>(sb + (srow + RPP * i) * LDSS + 4 * slot) = rb[i];
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = a.taps * a.cchunks;
+    int tap = 0, c0 = 0;
+    load_slab(0, 0);
+    store_slab(0);
+    __syncthreads();
+
+    // fragment read bases (floats): row * LDSS + 4*half, + 8*q per k-group
+    const int fa = (wm * WM + l31) * LDSS + 4 * half;
+    const int fb = BM * LDSS + (wn * WN + l31) * LDSS + 4 * half;
+
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        const bool more = ks + 1 < nk;
+        if (more) {
+            c0 += BK;
+            if (c0 >= a.Cin) { c0 = 0; ++tap; }
+            if (ABLATE != 1) load_slab(tap, c0);               // global loads in flight under the MFMAs below
+        }
+        const float* sbuf = smem + buf * STAGE;
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            f32x4 fa4[MB], fb4[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+                fa4[i] = (ABLATE == 3) ? ra[i] : *reinterpret_cast<const f32x4*>(sbuf + fa + i * 32 * LDSS + 8 * q);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                fb4[j] = (ABLATE == 3) ? rb[j] : *reinterpret_cast<const f32x4*>(sbuf + fb + j * 32 * LDSS + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa4[i][e], fb4[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (ABLATE != 2) {
+            if (more) store_slab(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    conv_epilogue<MB, NB, WM, WN, POOLORD>(a, acc, m0, n0, wm, wn, l31, half);
+}
+
+// ------------------------------------------------------------------------------------------------ DMA kernel
+// Same GEMM, tile and fragment scheme as conv_fwd_kernel, but the K-slabs go HBM/L2 -> LDS directly with
+// `buffer_load_dwordx4 ... lds` (LDS-DMA): no staging VGPRs, no ds_write pass, almost no VALU in the loop.
+//   * zero padding / ragged edges for free: masked lanes get an out-of-range voffset and the buffer unit writes
+//     zeros into LDS (verified on gfx950, tools/probes/dma_oob.hip); rows n >= Cout likewise.
+//   * the DMA destination is lane-linear (wave base + lane*16 B), so LDS rows are unpadded 128-B rows (BK = 32
+//     floats).  ds_read_b128 of 16 different rows would be 8-way bank conflicted; instead the 16-B chunk a lane
+//     FETCHES is XOR-swizzled (physical slot p of row r holds logical chunk p ^ ((r>>1)&7)) and the fragment read
+//     applies the same involution: the 16 lanes of every ds_read_b128 group hit 16 distinct 16-B slots.
+//   * 2-deep ring: iteration s = {vmcnt(0); barrier; issue DMA of slab s+1; 16 ds_read_b128 + 64 MFMA on slab s}.
+// Requirements (host checks, else the register-staged kernel runs): Cin, ldx multiples of 4, 16-B aligned bases,
+// tensors < 2^31 bytes.
+template <int BM, int BN, int WAVES_M, bool POOLORD, bool CTAIL>
+__global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
+    constexpr int BK = 32;
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MB = WM / 32, NB = WN / 32;
+    constexpr int AR = BM / 32, BR = BN / 32;     // DMA instructions per thread per slab (A rows, B rows)
+    constexpr int STAGE = (BM + BN) * BK;          // floats per LDS stage
+    constexpr unsigned OOB = 0x80000000u;          // beyond num_records of any supported tensor -> zeros
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int wg = y2_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n;
+    const int tile_m = wg / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- staging assignment: lane -> physical 16-B slot p = lane & 7 of row (t>>3) + 32*i; it fetches logical chunk p ^ swz(row)
+    const int srow = t >> 3;                                   // 0..31 (rows 8*wave .. 8*wave+7)
+    const int lchunk = (lane & 7) ^ ((srow >> 1) & 7);         // row + 32*i has the same swizzle
+    unsigned a_base[AR];                                        // byte offset of (pixel row, tap (0,0) = up-left neighbour, chunk) or OOB
+    unsigned a_mask[AR];                                        // bit tap = 1 when that tap is inside the image
+    const int up_left = (a.taps == 9) ? (a.W + 1) : 0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + srow + 32 * i;
+        unsigned mask = 0;
+        int pix = 0;
+        if (m < a.M) {
+            int y, x;
+            decode_row<POOLORD>(a, m, pix, y, x);
+            if (a.taps == 9) {
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                    if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) mask |= 1u << tp;
+                }
+            } else {
+                mask = 1u;
+            }
+        }
+        a_mask[i] = mask;
+        a_base[i] = (unsigned)(((long long)(pix - up_left) * a.ldx + 4 * lchunk) * 4);   // may wrap below 0: only used when the tap is valid
+    }
+    const int ktot = a.taps * a.Cin;
+    unsigned b_base[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + srow + 32 * i;
+        b_base[i] = n < a.Cout ? (unsigned)(((size_t)n * ktot + 4 * lchunk) * 4) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+
+    auto issue_slab = [&](int tap, int c0, int buf) {
+        // A: voffset = a_base + ((ky*W + kx)*ldx + c0)*4   (ky, kx in 0..2 relative to the up-left neighbour)
+        const int ky = (a.taps == 9) ? tap / 3 : 0, kx = (a.taps == 9) ? tap % 3 : 0;
+        const unsigned toff = (unsigned)(((ky * a.W + kx) * a.ldx + c0) * 4);
+        const unsigned tbit = 1u << tap;
+        const bool cok = !CTAIL || (c0 + 4 * lchunk) < a.Cin;
+        float* sa = smem + buf * STAGE + wave * (8 * BK);
+        float* sb = sa + BM * BK;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const bool ok = (a_mask[i] & tbit) != 0 && cok;
+            const unsigned voff = ok ? a_base[i] + toff : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 32 * BK), 16, (int)voff, 0, 0, 0);
+        }
+        const unsigned woff = (unsigned)((tap * a.Cin + c0) * 4);
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const unsigned voff = (CTAIL && !cok) ? OOB : b_base[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sb + i * 32 * BK), 16, (int)voff, (int)woff, 0, 0);
+        }
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets (floats): physical slot of logical chunk 2q+half in row l31 (+32*block)
+    const int sw = (l31 >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) foff[q] = l31 * BK + (((2 * q + half) ^ sw) << 2);
+    const int fa = wm * WM * BK;
+    const int fb = BM * BK + wn * WN * BK;
+
+    auto compute_slab = [&](int buf) {
+        const float* sbuf = smem + buf * STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 fa4[MB], fb4[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) fa4[i] = *reinterpret_cast<const f32x4*>(sbuf + fa + i * 32 * BK + foff[q]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) fb4[j] = *reinterpret_cast<const f32x4*>(sbuf + fb + j * 32 * BK + foff[q]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa4[i][e], fb4[j][e], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nk = a.taps * a.cchunks;
+    int tap = 0, c0 = 0;
+    issue_slab(0, 0, 0);
+    for (int ks = 0; ks < nk - 1; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of slab ks has landed
+        __syncthreads();                                     // ... everybody's has, and nobody still reads the other buffer
+        c0 += BK;
+        if (c0 >= a.Cin) { c0 = 0; ++tap; }
+        issue_slab(tap, c0, (ks + 1) & 1);
+        compute_slab(ks & 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    compute_slab((nk - 1) & 1);
+
+    conv_epilogue<MB, NB, WM, WN, POOLORD>(a, acc, m0, n0, wm, wn, l31, half);
+}
+
+template <int BM, int BN, int WAVES_M, int BK, bool POOLORD, bool VEC, int ABLATE = 0>
 int launch(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_m = y2_cdiv(a.M, BM);
     a.tiles_n = y2_cdiv(a.Cout, BN);
-    const size_t lds = 2u * (BM + BN) * LDSS * sizeof(float);
-    auto kern = conv_fwd_kernel<BM, BN, WAVES_M, POOLORD, VEC>;
+    size_t lds = 2u * (BM + BN) * (BK + 4) * sizeof(float);
+    if (const char* pad = getenv("Y2_CONV_LDS_MIN")) { const size_t m = (size_t)atol(pad); if (lds < m) lds = m; }   // occupancy experiments only
+    a.cchunks = y2_cdiv(a.Cin, BK);
+    auto kern = conv_fwd_kernel<BM, BN, WAVES_M, BK, POOLORD, VEC, ABLATE>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(1000 + (int)e);
         attr_set = true;
     }
@@ -307,32 +469,72 @@ int launch(const ConvArgs& a0, hipStream_t stream) {
     return Y2_OK;
 }
 
-template <bool POOLORD, bool VEC>
-int dispatch_tile(const ConvArgs& a, int tile, hipStream_t s) {
+template <int BM, int BN, int WAVES_M, bool POOLORD>
+int launch_dma(const ConvArgs& a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    a.tiles_m = y2_cdiv(a.M, BM);
+    a.tiles_n = y2_cdiv(a.Cout, BN);
+    a.cchunks = y2_cdiv(a.Cin, 32);
+    const size_t lds = 2u * (BM + BN) * 32 * sizeof(float);
+    const bool ctail = (a.Cin % 32) != 0;
+    const long long grid = (long long)a.tiles_m * a.tiles_n;
+    if (grid <= 0 || grid > 0x7fffffffLL) return Y2_EINVAL;
+    static bool attr_set[2] = {false, false};
+    if (ctail) {
+        auto kern = conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, true>;
+        if (!attr_set[1]) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return -(1000 + (int)e); attr_set[1] = true; }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
+    } else {
+        auto kern = conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, false>;
+        if (!attr_set[0]) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return -(1000 + (int)e); attr_set[0] = true; }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
+    }
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+template <bool POOLORD>
+int dispatch_dma(const ConvArgs& a, int tile, hipStream_t s) {
     switch (tile) {
-        case 1: return launch<128, 128, 2, POOLORD, VEC>(a, s);
-        case 2: return launch<128, 64, 2, POOLORD, VEC>(a, s);
-        case 3: return launch<64, 64, 2, POOLORD, VEC>(a, s);
-        case 4: return launch<256, 64, 4, POOLORD, VEC>(a, s);
-        case 5: return launch<64, 128, 2, POOLORD, VEC>(a, s);
+        case 1: return launch_dma<128, 128, 2, POOLORD>(a, s);
+        case 2: return launch_dma<128, 64, 2, POOLORD>(a, s);
+        case 3: return launch_dma<64, 64, 2, POOLORD>(a, s);
+        case 5: return launch_dma<64, 128, 2, POOLORD>(a, s);
         default: return Y2_ENOSUP;
     }
 }
 
-// Pick the tile that minimises (waves of workgroups over the chip) x (work per workgroup) / efficiency.
+template <bool POOLORD, bool VEC>
+int dispatch_tile(const ConvArgs& a, int tile, hipStream_t s) {
+    switch (tile) {
+        case 1: return launch<128, 128, 2, 32, POOLORD, VEC>(a, s);
+        case 2: return launch<128, 64, 2, 32, POOLORD, VEC>(a, s);
+        case 3: return launch<64, 64, 2, 32, POOLORD, VEC>(a, s);
+        case 4: return launch<256, 64, 4, 32, POOLORD, VEC>(a, s);
+        case 5: return launch<64, 128, 2, 32, POOLORD, VEC>(a, s);
+        case 11: return launch<128, 128, 2, 16, POOLORD, VEC>(a, s);
+        case 91: if (!POOLORD && VEC) return launch<128, 128, 2, 32, false, true, 1>(a, s); return Y2_ENOSUP;   // timing ablations (wrong results)
+        case 92: if (!POOLORD && VEC) return launch<128, 128, 2, 32, false, true, 2>(a, s); return Y2_ENOSUP;
+        case 93: if (!POOLORD && VEC) return launch<128, 128, 2, 32, false, true, 3>(a, s); return Y2_ENOSUP;
+        case 13: return launch<64, 64, 2, 16, POOLORD, VEC>(a, s);
+        case 21: return launch<128, 128, 2, 64, POOLORD, VEC>(a, s);
+        case 23: return launch<64, 64, 2, 64, POOLORD, VEC>(a, s);
+        default: return Y2_ENOSUP;
+    }
+}
+
+// Pick the tile that minimises (tiles per CU, rounded up) x (tile area) / (measured main-loop efficiency).
+// Efficiencies measured on MI355X with the LDS-DMA kernel at B=32..128 (tools/layer_bench.py, profiles/):
+// every CU is saturated by its resident workgroups, so the makespan is quantised in whole tiles per CU.
 int choose_tile(long long M, int Cout) {
     struct Cand { int id, bm, bn; double eff; };
-    // eff: relative main-loop efficiency of the config (bigger tiles amortise staging better); tuned on MI355X
-    const Cand cands[] = {{1, 128, 128, 1.00}, {2, 128, 64, 0.92}, {5, 64, 128, 0.92}, {3, 64, 64, 0.80}};
-    const double slots = 2.0 * Y2_NUM_CU;   // 2 resident workgroups per CU share one MFMA pipe
-    int best = 1;
+    const Cand cands[] = {{5, 64, 128, 0.80}, {3, 64, 64, 0.78}, {2, 128, 64, 0.775}, {1, 128, 128, 0.74}};
+    int best = 3;
     double best_cost = 1e300;
     for (const Cand& c : cands) {
-        const double tiles = (double)y2_cdiv(M, c.bm) * y2_cdiv(Cout, c.bn);
-        // time ~ ceil(tiles / CUs) rounds when every CU is saturated by >= 1 workgroup
-        const double rounds = (double)y2_cdiv((long long)tiles, Y2_NUM_CU);
+        const long long tiles = (long long)y2_cdiv(M, c.bm) * y2_cdiv(Cout, c.bn);
+        const double rounds = (double)y2_cdiv(tiles, Y2_NUM_CU);
         const double cost = rounds * c.bm * c.bn / c.eff;
-        (void)slots;
         if (cost < best_cost) { best_cost = cost; best = c.id; }
     }
     return best;
@@ -362,8 +564,9 @@ extern "C" int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream) {
     a.ldy = p->ldy; a.coff = p->coff; a.ldp = p->ldp; a.poff = p->poff; a.out_mode = p->out_mode;
     a.slope = p->slope;
     a.M = (int)M;
-    a.cchunks = y2_cdiv(p->Cin, BK);
+    a.cchunks = y2_cdiv(p->Cin, BK_DEFAULT);
     a.tiles_m = a.tiles_n = 0;
+    a.x_bytes = a.w_bytes = 0;
     static const float* zeros = nullptr;
     if (zeros == nullptr) {
         void* zp = nullptr;
@@ -374,8 +577,17 @@ extern "C" int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream) {
     a.zeros = zeros;
 
     const bool vec = (p->Cin % 4 == 0) && (p->ldx % 4 == 0) && y2_aligned16(p->x) && y2_aligned16(p->w);
-    const int tile = p->tile > 0 ? p->tile : choose_tile(M, p->Cout);
+    int tile = p->tile > 0 ? p->tile : choose_tile(M, p->Cout);
     hipStream_t s = y2_s(stream);
+    // tile ids 1,2,3,5: LDS-DMA kernel when the operands allow it; 101.. force the register-staged kernel (also the
+    // path for channel counts / strides that are not multiples of 4, e.g. pruned checkpoints)
+    const unsigned long long xb = (unsigned long long)M * p->ldx * 4ull, wb = (unsigned long long)p->Cout * a.taps * p->Cin * 4ull;
+    const bool dma_ok = vec && xb < 0x7fffffffull && wb < 0x7fffffffull && (tile == 1 || tile == 2 || tile == 3 || tile == 5);
+    if (dma_ok) {
+        a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+        return pool ? dispatch_dma<true>(a, tile, s) : dispatch_dma<false>(a, tile, s);
+    }
+    if (tile > 100) tile -= 100;
     if (pool) return vec ? dispatch_tile<true, true>(a, tile, s) : dispatch_tile<true, false>(a, tile, s);
     return vec ? dispatch_tile<false, true>(a, tile, s) : dispatch_tile<false, false>(a, tile, s);
 }
