@@ -9,9 +9,9 @@ region.  For N > 1 (launched by torch.distributed.run, one process per GPU) infe
 runs the same per-GPU batch, no data-path collective; the barrier and max-over-ranks timing stay.
 
 Prints ONE JSON line on rank 0 with the contract fields plus:
-  roofline     — conv_fwd_kernel family (the dominant kernel: 99% of the FLOPs): algorithmic conv FLOPs of its
-                 launches / their summed duration, measured live with HIP events on the launch stream inside the timed
-                 region; peak = 157.3 TFLOP/s (fp32-input MFMA, MI355X_MICROARCH.md).
+  roofline     — conv_fwd_dma_kernel family (the dominant kernel: 99% of the FLOPs): algorithmic conv FLOPs of its 22
+                 launches per step / their duration, measured live with one HIP event pair per step on the launch stream
+                 inside the timed region; peak = 157.3 TFLOP/s (fp32-input MFMA, MI355X_MICROARCH.md).
   cpu_baseline — the CPU oracle (port of the reference path: torch-CPU conv stack + numpy decode/filter/NMS) timed on
                  this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -59,22 +59,31 @@ def cpu_baseline(sd, anchors, size, sample):
     from oracle import head as ohead
     from oracle import synth
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    x = synth.images(sample, size, seed=1)
+    x = synth.images(min(sample, 16), size, seed=1).repeat((sample + 15) // 16, 1, 1, 1)[:sample]
     with torch.no_grad():
-        odark.forward(x[:1], sd)  # warm-up
+        # pick the thread count that serves the oracle best on this host (oneDNN degrades when oversubscribed)
+        best = (1e30, cores)
+        for th in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}):
+            torch.set_num_threads(th)
+            odark.forward(x[:2], sd)  # warm-up
+            t0 = time.perf_counter()
+            odark.forward(x[:2], sd)
+            best = min(best, (time.perf_counter() - t0, th))
+        torch.set_num_threads(best[1])
         t0 = time.perf_counter()
-        feat = odark.forward(x, sd)
-        pred = ohead.decode(feat, anchors)
-        B = feat.shape[0]
-        prob = torch.softmax(pred['logits'], -1).view(B, -1, pred['logits'].shape[-1]).numpy()
-        iou = pred['iou'].reshape(B, -1).numpy()
-        mn, mx = pred['yx_min'].reshape(B, -1, 2).numpy(), pred['yx_max'].reshape(B, -1, 2).numpy()
-        for b in range(B):
-            odet.postprocess(iou[b], mn[b], mx[b], prob[b], fix=True)
+        for i0 in range(0, sample, 16):
+            xb = x[i0:i0 + 16]
+            feat = odark.forward(xb, sd)
+            pred = ohead.decode(feat, anchors)
+            B = feat.shape[0]
+            prob = torch.softmax(pred['logits'], -1).view(B, -1, pred['logits'].shape[-1]).numpy()
+            iou = pred['iou'].reshape(B, -1).numpy()
+            mn, mx = pred['yx_min'].reshape(B, -1, 2).numpy(), pred['yx_max'].reshape(B, -1, 2).numpy()
+            for b in range(B):
+                odet.postprocess(iou[b], mn[b], mx[b], prob[b], fix=True)
         dt = time.perf_counter() - t0
     return {'value': round(sample / dt, 3), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d synthetic %dx%d images, oracle conv stack (torch-CPU fp32) + decode + filter(fix=1) + NMS, %.1f s' % (sample, size, size, dt)}
+            'sample': '%d synthetic %dx%d images in batches of 16, oracle conv stack (torch-CPU fp32, best of %d/%d/%d/%d threads) + decode + filter(fix=1) + NMS, %.1f s' % (sample, size, size, cores, cores // 2, cores // 4, cores // 8, dt)}
 
 
 def main():
@@ -86,7 +95,7 @@ def main():
     ap.add_argument('--size', type=int, default=416)
     ap.add_argument('--classes', type=int, default=20)
     ap.add_argument('--mode', default='detect', choices=['detect', 'forward'])
-    ap.add_argument('--cpu-sample', type=int, default=16, help='images for the CPU baseline (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=192, help='images for the CPU baseline (0 = skip)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -161,7 +170,7 @@ def main():
                                    'Darknet-19 YOLOv2 %dx%d batch-%d/GPU conv stack only' % (args.size, args.size, args.batch),
                        'classes': args.classes, 'global_batch': args.batch * world, 'parallelism': 'replicas x%d (no collective)' % world,
                        'weights': 'random-init seed 0'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_fwd_kernel (fp32 MFMA implicit GEMM, %d launches/step)' % (n_launch // max(args.steps, 1)),
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_fwd_dma_kernel family (fp32 MFMA implicit GEMM; 22 launches per step timed as one event pair, inter-launch gaps included)',
                          'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          'flops_per_step': fl / max(args.steps, 1), 'ms_per_step': round(ms / max(args.steps, 1), 4),

@@ -85,6 +85,10 @@ typedef struct y2_conv_params {
 
 int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream);
 
+/* The same for `count` convolutions enqueued back to back (one host call for a whole Darknet stage chain;
+ * model/yolo2.py:125-130 runs them as separate nn.Module calls). Stops at the first error. */
+int y2_conv_fwd_batch(const y2_conv_params* params, int count, y2_stream_t stream);
+
 /* First layer (model/yolo2.py:78, 'layers1.0'): reads the plugin's NCHW fp32 input [B,Cin<=4,H,W] directly,
  * conv3x3 pad 1 -> affine -> LeakyReLU -> (optional 2x2 max-pool), writes NHWC.
  * w is the UNPACKED state_dict weight [Cout][Cin][3][3]; Cout <= 64.  y (full res, pixel stride ldy) and/or

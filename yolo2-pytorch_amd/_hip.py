@@ -35,6 +35,7 @@ SIGNATURES = {
     'y2_unpack_weight_grad': [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'y2_bn_fold': [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p],
     'y2_conv_fwd': [ctypes.POINTER(ConvParams), c_void_p],
+    'y2_conv_fwd_batch': [ctypes.POINTER(ConvParams), c_int, c_void_p],
     'y2_conv0_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     'y2_maxpool2_fwd': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

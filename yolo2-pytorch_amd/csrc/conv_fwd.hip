@@ -591,3 +591,14 @@ extern "C" int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream) {
     if (pool) return vec ? dispatch_tile<true, true>(a, tile, s) : dispatch_tile<true, false>(a, tile, s);
     return vec ? dispatch_tile<false, true>(a, tile, s) : dispatch_tile<false, false>(a, tile, s);
 }
+
+// Coarse entry: a whole chain of convolutions (the Darknet stages) in one call — the host enqueues the launches
+// back to back without returning to Python between layers (SURVEY.md 8e "coarse C-ABI entry").
+extern "C" int y2_conv_fwd_batch(const y2_conv_params* params, int count, y2_stream_t stream) {
+    if (params == nullptr || count < 0) return Y2_EINVAL;
+    for (int i = 0; i < count; ++i) {
+        const int rc = y2_conv_fwd(params + i, stream);
+        if (rc != Y2_OK) return rc;
+    }
+    return Y2_OK;
+}

@@ -48,6 +48,23 @@ def meshgrid(rows, cols, swap=False):
     return torch.cat([i, j], 1) if swap else torch.cat([j, i], 1)
 
 
+_ANCHOR_CACHE = {}
+
+
+def _device_anchors(anchors, dev):
+    """Device copy of the (host) anchor table, cached: a per-call H2D copy from pageable memory is synchronous."""
+    if anchors.is_cuda and anchors.dtype == torch.float32 and anchors.is_contiguous():
+        return anchors
+    key = (anchors.data_ptr(), anchors._version, tuple(anchors.shape), str(dev))
+    hit = _ANCHOR_CACHE.get(key)
+    if hit is None:
+        if len(_ANCHOR_CACHE) > 64:
+            _ANCHOR_CACHE.clear()
+        hit = (anchors.to(device=dev, dtype=torch.float32).contiguous(), anchors)   # keep the host tensor alive: data_ptr is the key
+        _ANCHOR_CACHE[key] = hit
+    return hit[0]
+
+
 def decode(feature_nhwc, anchors, num_anchors, want_prob=False):
     """y2_decode on a contiguous [B, rows, cols, A*(5+C)] head image.  Returns dict of fp32 GPU tensors."""
     _hip.require_gpu(feature_nhwc)
@@ -58,7 +75,7 @@ def decode(feature_nhwc, anchors, num_anchors, want_prob=False):
     C = E - 5
     cells = rows * cols
     dev = feature_nhwc.device
-    anchors = anchors.to(device=dev, dtype=torch.float32).contiguous()
+    anchors = _device_anchors(anchors, dev)
     new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     out = dict(iou=new(B, cells, A), center_offset=new(B, cells, A, 2), size_norm=new(B, cells, A, 2),
                yx_min=new(B, cells, A, 2), yx_max=new(B, cells, A, 2))

@@ -100,6 +100,247 @@ class Darknet(nn.Module):
 
         self.init()
         self._cache = None  # packed weights / folded BN for eval, keyed on parameter versions
+        self._plan_cache = None
+        self.profile = None  # bench.py: list receiving (kernel, flops, start_event, end_event) per conv launch
+
+    def init(self):
+        """model/yolo2.py:117-123."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def scope(self, name):
+        return '.'.join(name.split('.')[:-2])
+
+    def get_mapper(self, index):
+        if index == 94:
+            return lambda indices, channels: torch.cat([indices + i * channels for i in range(self.stride * self.stride)])
+
+    # ------------------------------------------------------------------ execution plan
+    def _blocks(self):
+        """[(name, Conv2d, pool_follows)] in execution order for the three sequential stages."""
+        def seq(prefix, s):
+            out = []
+            mods = list(s)
+            for i, m in enumerate(mods):
+                if isinstance(m, Conv2d):
+                    out.append(('%s.%d' % (prefix, i), m, i + 1 < len(mods) and isinstance(mods[i + 1], _Pool)))
+            return out
+        return seq('layers1', self.layers1), seq('layers2', self.layers2), seq('layers3', self.layers3)
+
+    def _versions(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def _prepare_eval(self, device):
+        """Pack weights to [Cout][tap][Cin] and fold BN once per parameter version (y2_pack_weight / y2_bn_fold)."""
+        ver = (device, self._versions())
+        if self._cache is not None and self._cache[0] == ver:
+            return self._cache[1]
+        L = _hip.lib()
+        st = _hip.stream()
+        prep = {}
+        first = self.layers1[0]
+        for blk in [m for m in self.modules() if isinstance(m, Conv2d)]:
+            w = blk.conv.weight.detach()
+            _hip.require_gpu(w)
+            cout, cin, k, _ = w.shape
+            w = _hip.f32c(w)
+            if blk is first:
+                wp = w  # y2_conv0_fwd reads the state_dict layout directly
+            else:
+                wp = torch.empty(cout * cin * k * k, dtype=torch.float32, device=device)
+                _hip.check(L.y2_pack_weight(_hip.ptr(w), _hip.ptr(wp), cout, cin, k, 0, st), 'y2_pack_weight')
+            if blk.bn is not None:
+                scale = torch.empty(cout, dtype=torch.float32, device=device)
+                shift = torch.empty(cout, dtype=torch.float32, device=device)
+                bn = blk.bn
+                _hip.check(L.y2_bn_fold(_hip.ptr(_hip.f32c(bn.weight.detach())), _hip.ptr(_hip.f32c(bn.bias.detach())),
+                                        _hip.ptr(_hip.f32c(bn.running_mean)), _hip.ptr(_hip.f32c(bn.running_var)),
+                                        BN_EPS, _hip.ptr(scale), _hip.ptr(shift), cout, st), 'y2_bn_fold')
+            else:
+                scale = None
+                shift = _hip.f32c(blk.conv.bias.detach()) if blk.conv.bias is not None else None
+            prep[blk] = (wp, scale, shift)
+        self._cache = (ver, prep)
+        return prep
+
+    def _conv_params(self, prep, blk, x, B, H, W, ldx, y=None, y_pool=None, ldy=0, coff=0, ldp=0, poff=0, out_mode=0):
+        wp, scale, shift = prep[blk]
+        cout, cin = blk.conv.weight.shape[:2]
+        p = _hip.ConvParams()
+        p.x, p.w, p.scale, p.shift = x.data_ptr(), wp.data_ptr(), (scale.data_ptr() if scale is not None else None), (shift.data_ptr() if shift is not None else None)
+        p.y = y.data_ptr() if y is not None else None
+        p.y_pool = y_pool.data_ptr() if y_pool is not None else None
+        p.stats = None
+        p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize = B, H, W, cin, ldx, cout, blk.kernel_size
+        p.ldy, p.coff, p.ldp, p.poff, p.out_mode = ldy, coff, ldp, poff, out_mode
+        p.slope = LEAKY if blk.has_act else 1.0
+        p.tile = 0
+        return p, 2.0 * cin * cout * blk.kernel_size ** 2 * B * H * W
+
+    def _plan(self, prep, dev, B, cin0, H, W):
+        """Execution plan for one input shape: intermediate NHWC buffers (never exposed, reused across calls) and the
+        y2_conv_params array of the 22 generic convolutions (model/yolo2.py:76-113 in execution order)."""
+        key = (id(prep), dev, B, cin0, H, W)
+        if self._plan_cache is not None and self._plan_cache[0] == key:
+            return self._plan_cache[1]
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        b1, b2, b3 = self._blocks()
+        plist, flops, keep = [], 0.0, []
+
+        def add(*args, **kw):
+            p, f = self._conv_params(prep, *args, **kw)
+            plist.append(p)
+            return f
+        name, blk0, pool = b1[0]
+        c = blk0.conv.weight.shape[0]
+        assert pool
+        first = new(B, H // 2, W // 2, c)
+        cur, h, w, ld = first, H // 2, W // 2, c
+        full_last = None
+        for i, (name, blk, pool) in enumerate(b1[1:], 1):
+            c = blk.conv.weight.shape[0]
+            if i == len(b1) - 1:
+                # output feeds both the passthrough (full res) and layers2's leading MaxPool (model/yolo2.py:97,126-128)
+                full_last = new(B, h, w, c)
+                pooled = new(B, h // 2, w // 2, c)
+                flops += add(blk, cur, B, h, w, ld, y=full_last, y_pool=pooled, ldy=c, ldp=c)
+                cur, fh, fw = pooled, h, w
+                h, w, ld = h // 2, w // 2, c
+            elif pool:
+                out = new(B, h // 2, w // 2, c)
+                flops += add(blk, cur, B, h, w, ld, y_pool=out, ldp=c)
+                cur, h, w, ld = out, h // 2, w // 2, c
+            else:
+                out = new(B, h, w, c)
+                flops += add(blk, cur, B, h, w, ld, y=out, ldy=c)
+                cur, ld = out, c
+            keep.append(cur)
+        # concat buffer [B, h, w, 4*c_pt + c_l2]; the passthrough writes its reorg'ed channels FIRST (model/yolo2.py:129)
+        c_pt = self.passthrough.conv.weight.shape[0]
+        c_l2 = b2[-1][1].conv.weight.shape[0]
+        cat = new(B, h, w, 4 * c_pt + c_l2)
+        flops += add(self.passthrough, full_last, B, fh, fw, full_last.shape[-1], y=cat, ldy=cat.shape[-1], coff=0, out_mode=1)
+        for i, (name, blk, pool) in enumerate(b2):
+            c = blk.conv.weight.shape[0]
+            if i == len(b2) - 1:
+                flops += add(blk, cur, B, h, w, ld, y=cat, ldy=cat.shape[-1], coff=4 * c_pt)
+            else:
+                out = new(B, h, w, c)
+                flops += add(blk, cur, B, h, w, ld, y=out, ldy=c)
+                cur, ld = out, c
+                keep.append(out)
+        cur, ld = cat, cat.shape[-1]
+        head_index = None
+        for i, (name, blk, pool) in enumerate(b3):
+            c = blk.conv.weight.shape[0]
+            if i == len(b3) - 1:
+                head_index = len(plist)          # output buffer is allocated per call (it is returned to the caller)
+                flops += add(blk, cur, B, h, w, ld, y=cur, ldy=c)
+                head_shape = (B, h, w, c)
+            else:
+                out = new(B, h, w, c)
+                flops += add(blk, cur, B, h, w, ld, y=out, ldy=c)
+                cur, ld = out, c
+                keep.append(out)
+        arr = (_hip.ConvParams * len(plist))(*plist)
+        plan = dict(arr=arr, n=len(plist), first=first, head_index=head_index, head_shape=head_shape, flops=flops,
+                    flops0=2.0 * cin0 * blk0.conv.weight.shape[0] * 9 * B * H * W, keep=(keep, full_last, cat, prep))
+        self._plan_cache = (key, plan)
+        return plan
+
+    def forward_nhwc(self, x):
+        """x [B,Cin,H,W] NCHW fp32 on the GPU -> head image [B, H/32, W/32, A*(5+C)] (NHWC, contiguous).
+        Inference path (folded BatchNorm): one y2_conv0_fwd + one y2_conv_fwd_batch call."""
+        _hip.require_gpu(x)
+        L = _hip.lib()
+        x = _hip.f32c(x)
+        B, cin0, H, W = x.shape
+        if H % 32 or W % 32:
+            raise ValueError('input size must be a multiple of 32 (got %dx%d)' % (H, W))
+        dev = x.device
+        prep = self._prepare_eval(dev)
+        plan = self._plan(prep, dev, B, cin0, H, W)
+        st = _hip.stream()
+        blk0 = self.layers1[0]
+        wp, scale, shift = prep[blk0]
+        c = blk0.conv.weight.shape[0]
+        out = torch.empty(plan['head_shape'], dtype=torch.float32, device=dev)
+        plan['arr'][plan['head_index']].y = out.data_ptr()
+        prof = self.profile
+        if prof is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+        _hip.check(L.y2_conv0_fwd(_hip.ptr(x), _hip.ptr(wp), _hip.ptr(scale), _hip.ptr(shift), None, _hip.ptr(plan['first']), None,
+                                  B, H, W, cin0, c, 0, c, LEAKY if blk0.has_act else 1.0, st), 'y2_conv0_fwd')
+        if prof is not None:
+            ev[1].record()
+        _hip.check(L.y2_conv_fwd_batch(plan['arr'], plan['n'], st), 'y2_conv_fwd_batch')
+        if prof is not None:
+            ev[2].record()
+            prof.append(('conv0', plan['flops0'], ev[0], ev[1]))
+            prof.append(('conv_fwd', plan['flops'], ev[1], ev[2]))
+        return out
+
+    def forward(self, x):
+        raise RuntimeError('model.yolo2.Conv2d is a parameter container; the network runs through Darknet.forward (HIP)')
+
+
+class _Pool(nn.Module):
+    """Placeholder keeping the reference's nn.Sequential indices (MaxPool2d has no parameters)."""
+
+    def forward(self, x):
+        raise RuntimeError('pooling is fused into the producing convolution')
+
+
+class Darknet(nn.Module):
+    def __init__(self, config_channels, anchors, num_cls, stride=2, ratio=1):
+        nn.Module.__init__(self)
+        assert stride == 2
+        self.stride = stride
+        channels = int(32 * ratio)
+        layers = []
+        bn = config_channels.config.getboolean('batch_norm', 'enable')
+        # layers1 — identical construction order to model/yolo2.py:76-96 (ConfigChannels is stateful)
+        for _ in range(2):
+            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
+            layers.append(_Pool())
+            channels *= 2
+        for _ in range(2):
+            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
+            layers.append(Conv2d(config_channels.channels, config_channels(channels // 2, 'layers1.%d.conv.weight' % len(layers)), 1, bn=bn))
+            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
+            layers.append(_Pool())
+            channels *= 2
+        for _ in range(2):
+            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
+            layers.append(Conv2d(config_channels.channels, config_channels(channels // 2, 'layers1.%d.conv.weight' % len(layers)), 1, bn=bn))
+        layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
+        self.layers1 = nn.Sequential(*layers)
+
+        layers = []
+        layers.append(_Pool())
+        channels *= 2
+        for _ in range(2):
+            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers2.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
+            layers.append(Conv2d(config_channels.channels, config_channels(channels // 2, 'layers2.%d.conv.weight' % len(layers)), 1, bn=bn))
+        for _ in range(3):
+            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers2.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
+        self.layers2 = nn.Sequential(*layers)
+
+        self.passthrough = Conv2d(self.layers1[-1].conv.weight.size(0), config_channels(int(64 * ratio), 'passthrough.conv.weight'), 1, bn=bn)
+
+        layers = []
+        layers.append(Conv2d(self.passthrough.conv.weight.size(0) * self.stride * self.stride + self.layers2[-1].conv.weight.size(0), config_channels(int(1024 * ratio), 'layers3.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
+        layers.append(Conv2d(config_channels.channels, model.output_channels(len(anchors), num_cls), 1, bn=False, act=False))
+        self.layers3 = nn.Sequential(*layers)
+
+        self.init()
+        self._cache = None  # packed weights / folded BN for eval, keyed on parameter versions
+        self._plan_cache = None
         self.profile = None  # bench.py: list receiving (kernel, flops, start_event, end_event) per conv launch
 
     def init(self):
