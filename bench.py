@@ -158,6 +158,14 @@ def main():
             ms0 += d
     achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 
+    traffic = None
+    try:   # HBM-side bytes per step of the same kernel family from the committed rocprofv3 PMC passes (separate runs)
+        import glob
+        tf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_detect_b32_traffic.json')))
+        if tf and args.batch == 32 and args.size == 416:
+            traffic = json.load(open(tf[-1]))['traffic_bytes_per_step']
+    except Exception:
+        traffic = None
     if rank == 0:
         images = args.batch * args.steps * world
         out = {
@@ -174,7 +182,8 @@ def main():
                          'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          'flops_per_step': fl / max(args.steps, 1), 'ms_per_step': round(ms / max(args.steps, 1), 4),
-                         'conv0_ms_per_step': round(ms0 / max(args.steps, 1), 4), 'traffic': None},
+                         'conv0_ms_per_step': round(ms0 / max(args.steps, 1), 4), 'traffic': traffic,
+                         'traffic_note': 'bytes per step (22 launches) from rocprofv3 PMC FETCH_SIZE(x2, gfx950 correction)+WRITE_SIZE, profiles/; L2 memory-side requests incl. Infinity-Cache hits'},
         }
         if world == 1 and args.cpu_sample > 0:
             out['cpu_baseline'] = cpu_baseline(sd, anchors, args.size, args.cpu_sample)
