@@ -147,6 +147,71 @@ int y2_iou_pair(const float* yx_min1, const float* yx_max1, const float* yx_min2
 int y2_nms(const float* score, const float* yx_min, const float* yx_max, const int32_t* cand, const int32_t* n, int B, int stride,
            float overlap, int limit, int32_t* order_ws, int32_t* keep, int32_t* keep_count, y2_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Training path.  The reference trains through torch autograd (train.py:344-357): conv / BN / LeakyReLU /
+ * MaxPool backward are PyTorch's; the kernels below are their MI355X-native equivalents, orchestrated by
+ * yolo2-pytorch_amd/model/train_graph.py behind the same Python surface (Darknet.forward, model.loss).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Weight gradient of a stride-1 "same" conv (autograd of nn.Conv2d, model/yolo2.py:57):
+ * dw[co][tap][ci] = sum_pixels dz[pixel][co] * x[pixel + tap][ci], written in the PACKED layout [Cout][k*k][Cin]
+ * (y2_unpack_weight_grad converts to [Cout,Cin,k,k]).  dw must be zero-filled (split-K partials are added atomically).
+ * Requires Cin, ldx, Cout, ldz multiples of 4 and 16-B aligned bases (else Y2_EALIGN). */
+int y2_conv_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int ldx, int Cout, int ldz,
+                  int ksize, y2_stream_t stream);
+
+/* Training-mode nn.BatchNorm2d(momentum 0.01, eps 1e-5) statistics (model/yolo2.py:58): stats = [sum z | sum z^2] per
+ * channel (fp64, accumulated by y2_conv_fwd / y2_conv0_fwd), count = B*H*W.  Writes the affine (scale, shift) used for
+ * normalisation (biased variance), saves mean / invstd for backward and updates the running statistics in place
+ * (unbiased variance) when running_mean != NULL. */
+int y2_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps,
+                   float* scale, float* shift, float* mean, float* invstd, int C, y2_stream_t stream);
+
+/* y = LeakyReLU(z*scale + shift) on NHWC (scale/shift NULL = identity), optionally with the following MaxPool2d(2)
+ * (y_pool) and/or the reorg/concat output addressing of y2_conv_params (out_mode, ldy, coff). */
+int y2_bn_act_fwd(const float* z, const float* scale, const float* shift, float slope, float* y, float* y_pool,
+                  int B, int H, int W, int C, int ldz, int ldy, int coff, int ldp, int poff, int out_mode, y2_stream_t stream);
+
+/* Backward of (BN train) -> LeakyReLU -> [MaxPool2d(2)]: from dy_full (gradient of the full-resolution activation;
+ * fmode 1: stored reorg'ed in a [B,H/2,W/2,ldf] buffer at channel foff) and/or dy_pool (gradient of the pooled
+ * activation, routed to the first maximal window element like nn.MaxPool2d) to dz (gradient of the raw conv output).
+ * sums [2C] (pre-zeroed fp64) receives sum(g) = d beta (or d bias) and sum(g*zhat) = d gamma.  has_bn = 0: plain
+ * bias + LeakyReLU block (dz = g). */
+int y2_bn_act_bwd(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,
+                  float slope, const float* dy_full, int ldf, int foff, int fmode, const float* dy_pool, int ldp, int poff,
+                  double* sums, float* dz, int ldd, int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream);
+
+/* out[c] += sum_m x[m*ld + c] (fp64; conv-bias gradient of the head, model/yolo2.py:112).  out pre-zeroed. */
+int y2_colsum(const float* x, long long M, int C, int ld, double* out, y2_stream_t stream);
+/* dst[i] = (float)(src[i] * mul) */
+int y2_f64_to_f32(const double* src, float* dst, int n, double mul, y2_stream_t stream);
+
+/* Gradient of the decode (model/__init__.py:122-135) w.r.t. the head image [boxes, 5+C] from the gradients of
+ * iou [boxes], center_offset / size_norm [boxes,2], logits [boxes,C] (any may be NULL = zero); yx_min / yx_max carry
+ * no gradient (the reference's loss detaches them, model/__init__.py:142). */
+int y2_decode_bwd(const float* iou, const float* center_offset, const float* d_iou, const float* d_center_offset, const float* d_size_norm,
+                  const float* d_logits, float* d_feature, int boxes, int C, y2_stream_t stream);
+
+/* model.loss (model/__init__.py:138-167) = iou_match (:59-73) + fit_positive (:76-95) + fill_norm (:98-103) + the five
+ * terms, each divided by cnt = B*cells*A; cls is the MEAN cross entropy over positives (gt_cls int64 [B,N]) or the
+ * summed squared error on softmax (gt_onehot [B,N,C]); C = 0: no cls term.  GT boxes [B,N,2] in cell units, zero rows =
+ * padding.  Outputs: loss_out[5] = foreground, background, center, size, cls; saved for backward: best_iou [B,n],
+ * best_idx [B,n], positive [B,n] (uint8), sums[6] (fp64: the five sums and the number of positives). n = rows*cols*A. */
+int y2_region_loss_fwd(const float* iou, const float* center_offset, const float* size_norm, const float* logits,
+                       const float* yx_min, const float* yx_max,
+                       const float* gt_yx_min, const float* gt_yx_max, const int64_t* gt_cls, const float* gt_onehot,
+                       const float* anchors, int B, int rows, int cols, int A, int C, int N, float threshold,
+                       float* best_iou, int32_t* best_idx, uint8_t* positive, double* sums, float* loss_out, y2_stream_t stream);
+
+/* Gradients of sum_k weights[k]*loss[k] (train.py:348-349) w.r.t. iou, center_offset, size_norm, logits. */
+int y2_region_loss_bwd(const float* iou, const float* center_offset, const float* size_norm, const float* logits,
+                       const float* gt_yx_min, const float* gt_yx_max, const int64_t* gt_cls, const float* gt_onehot,
+                       const float* anchors, int B, int rows, int cols, int A, int C, int N, float threshold,
+                       const float* best_iou, const int32_t* best_idx, const uint8_t* positive, const double* sums, const float* weights,
+                       float* d_iou, float* d_center_offset, float* d_size_norm, float* d_logits, y2_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

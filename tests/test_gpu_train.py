@@ -1,0 +1,236 @@
+"""GPU parity tests of the training path: weight/data gradients, BN+LeakyReLU+pool forward/backward, region loss and a
+full Darknet training step, against torch-CPU autograd in fp64 (oracle) and the reference-generated loss fixture."""
+import configparser
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import darknet as odark
+from oracle import head as ohead
+from oracle import loss as oloss
+from oracle import synth
+from oracle.make_golden import NARROW
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def rel(got, ref):
+    ref = ref.double()
+    rms = ref.pow(2).mean().sqrt().item()
+    return (got.double().cpu() - ref).abs().max().item() / max(rms, 1e-30)
+
+
+@pytest.mark.parametrize('B,cin,cout,H,W,k', [(2, 32, 64, 8, 12, 3), (3, 64, 8, 13, 13, 1), (2, 4, 32, 16, 16, 3), (3, 256, 128, 13, 13, 3), (1, 128, 256, 26, 26, 3), (2, 40, 72, 7, 5, 3)])
+def test_conv_wgrad_and_dgrad(B, cin, cout, H, W, k):
+    import _hip
+    L = _hip.lib()
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(B, cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(cout, cin, k, k, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    dz = torch.randn(B, cout, H, W, generator=g, dtype=torch.float64)
+    F.conv2d(x, w, padding=(k - 1) // 2).backward(dz)
+    d = dev()
+    xd, dzd = nhwc(x.detach().float()).to(d), nhwc(dz.float()).to(d)
+    dwp = torch.zeros(w.numel(), device=d)
+    _hip.check(L.y2_conv_wgrad(_hip.ptr(xd), _hip.ptr(dzd), _hip.ptr(dwp), B, H, W, cin, cin, cout, cout, k, _hip.stream()), 'wgrad')
+    dw = torch.empty(cout, cin, k, k, device=d)
+    _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cout, cin, k, _hip.stream()), 'unpack')
+    assert rel(dw, w.grad) <= TOL
+    # dgrad = forward kernel on rotated, in/out-swapped weights
+    wd = torch.empty(w.numel(), device=d)
+    wdev = w.detach().float().to(d).contiguous()
+    _hip.check(L.y2_pack_weight(_hip.ptr(wdev), _hip.ptr(wd), cout, cin, k, 1, _hip.stream()), 'pack1')
+    dx = torch.empty(B, H, W, cin, device=d)
+    p = _hip.ConvParams()
+    p.x, p.w, p.y = dzd.data_ptr(), wd.data_ptr(), dx.data_ptr()
+    p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize, p.ldy, p.slope = B, H, W, cout, cout, cin, k, cin, 1.0
+    _hip.check(L.y2_conv_fwd(ctypes.byref(p), _hip.stream()), 'dgrad')
+    assert rel(dx.permute(0, 3, 1, 2), x.grad) <= TOL
+
+
+@pytest.mark.parametrize('pool,both,C', [(False, False, 32), (True, False, 32), (True, True, 16), (False, False, 6), (True, True, 6)])
+def test_bn_act_forward_backward(pool, both, C):
+    import _hip
+    L = _hip.lib()
+    d = dev()
+    B, H, W = 3, 8, 12
+    g = torch.Generator().manual_seed(C + pool)
+    z = torch.randn(B, C, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    gamma = (torch.rand(C, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    y = F.leaky_relu(F.batch_norm(z, rm, rv, gamma, beta, True, 0.01, 1e-5), 0.1)
+    yp = F.max_pool2d(y, 2) if pool else None
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    dyp = torch.randn(yp.shape, generator=g, dtype=torch.float64) if pool else None
+    lossv = (y * dy).sum() * (1.0 if (both or not pool) else 0.0)
+    if pool:
+        lossv = lossv + (yp * dyp).sum()
+    lossv.backward()
+    # ---- ours
+    zd = nhwc(z.detach().float()).to(d)
+    stats = torch.stack([z.detach().sum((0, 2, 3)), (z.detach() ** 2).sum((0, 2, 3))]).reshape(-1).to(d)
+    scale, shift, mean, invstd = (torch.empty(C, device=d) for _ in range(4))
+    rmd, rvd = torch.zeros(C, device=d), torch.ones(C, device=d)
+    gd, bd = gamma.detach().float().to(d), beta.detach().float().to(d)
+    n = B * H * W
+    _hip.check(L.y2_bn_finalize(_hip.ptr(stats), float(n), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(rmd), _hip.ptr(rvd), 0.01, 1e-5,
+                                _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(mean), _hip.ptr(invstd), C, _hip.stream()), 'fin')
+    np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(rvd.cpu().numpy(), rv.numpy(), rtol=1e-5)
+    yo = torch.empty(B, H, W, C, device=d)
+    ypo = torch.empty(B, H // 2, W // 2, C, device=d) if pool else None
+    _hip.check(L.y2_bn_act_fwd(_hip.ptr(zd), _hip.ptr(scale), _hip.ptr(shift), 0.1, _hip.ptr(yo), _hip.ptr(ypo), B, H, W, C, C, C, 0, C, 0, 0, _hip.stream()), 'fwd')
+    assert rel(yo.permute(0, 3, 1, 2), y.detach()) <= TOL
+    if pool:
+        assert rel(ypo.permute(0, 3, 1, 2), yp.detach()) <= TOL
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=d)
+    dz = torch.empty(B, H, W, C, device=d)
+    dyf = nhwc(dy.float()).to(d) if (both or not pool) else None
+    dypd = nhwc(dyp.float()).to(d) if pool else None
+    _hip.check(L.y2_bn_act_bwd(_hip.ptr(zd), _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gd), 0.1,
+                               _hip.ptr(dyf), C, 0, 0, _hip.ptr(dypd), C, 0, _hip.ptr(sums), _hip.ptr(dz), C, B, H, W, C, C, 1, _hip.stream()), 'bwd')
+    assert rel(dz.permute(0, 3, 1, 2), z.grad) <= 5e-5
+    np.testing.assert_allclose(sums[:C].cpu().numpy(), beta.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(sums[C:].cpu().numpy(), gamma.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_bn_act_reorg_roundtrip():
+    """out_mode 1 (reorg into a concat buffer) forward, and fmode 1 gather in backward."""
+    import _hip
+    L = _hip.lib()
+    d = dev()
+    B, H, W, C = 2, 6, 10, 8
+    z = torch.randn(B, C, H, W)
+    zd = nhwc(z).to(d)
+    cat = torch.full((B, H // 2, W // 2, 4 * C + 12), -3.0, device=d)
+    _hip.check(L.y2_bn_act_fwd(_hip.ptr(zd), None, None, 0.1, _hip.ptr(cat), None, B, H, W, C, C, 4 * C + 12, 0, 0, 0, 1, _hip.stream()), 'fwd')
+    ref = odark.reorg(F.leaky_relu(z, 0.1))
+    assert torch.equal(cat[..., :4 * C].cpu().permute(0, 3, 1, 2), ref)
+    assert torch.all(cat[..., 4 * C:] == -3.0)
+    dcat = torch.randn(B, H // 2, W // 2, 4 * C + 12)
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=d)
+    dz = torch.empty(B, H, W, C, device=d)
+    dcd = dcat.to(d)
+    _hip.check(L.y2_bn_act_bwd(_hip.ptr(zd), None, None, None, None, None, 0.1, _hip.ptr(dcd), 4 * C + 12, 0, 1, None, 0, 0,
+                               _hip.ptr(sums), _hip.ptr(dz), C, B, H, W, C, C, 0, _hip.stream()), 'bwd')
+    zz = z.clone().requires_grad_(True)
+    (odark.reorg(F.leaky_relu(zz, 0.1)) * dcat[..., :4 * C].permute(0, 3, 1, 2)).sum().backward()
+    np.testing.assert_allclose(dz.cpu().permute(0, 3, 1, 2).numpy(), zz.grad.numpy(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('onehot', [False, True])
+def test_region_loss_matches_reference_fixture(golden, onehot):
+    import model
+    g = golden('loss')
+    tag = 'onehot_' if onehot else 'ce_'
+    gen = torch.Generator().manual_seed(11)
+    feat = 0.5 * torch.randn(2, 125, 13, 13, generator=gen)
+    f = feat.to(dev()).requires_grad_(True)
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+
+    class Id(torch.nn.Module):
+        def forward(self, t):
+            return t
+    inf = model.Inference(None, Id(), anchors)
+    pred = model._inference(inf, f)
+    data = synth.norm_data(synth.labels(2, 416, 20, seed=2, onehot=onehot), 416, 416, 13, 13)
+    loss, debug = model.loss(anchors, data, pred, 0.6)
+    total = sum(loss[k] * w for k, w in oloss.HPARAM.items())
+    total.backward()
+    for k in ('foreground', 'background', 'center', 'size', 'cls'):
+        np.testing.assert_allclose(loss[k].item(), g[tag + k], rtol=2e-5)
+    np.testing.assert_array_equal(debug['positive'].cpu().numpy(), g[tag + 'positive'].astype(bool))
+    np.testing.assert_array_equal(debug['negative'].cpu().numpy(), g[tag + 'negative'].astype(bool))
+    np.testing.assert_allclose(debug['iou'].cpu().numpy(), g[tag + 'best_iou'], rtol=1e-5, atol=1e-7)
+    gr = g[tag + 'grad']
+    np.testing.assert_allclose(f.grad.cpu().numpy(), gr, rtol=2e-4, atol=1e-6 * np.abs(gr).max())
+
+
+def test_region_loss_coco_and_single_class_vs_oracle():
+    import model
+    for C, A in ((80, 5), (0, 5)):
+        gen = torch.Generator().manual_seed(5 + C)
+        ch = A * (5 + C)
+        feat = 0.5 * torch.randn(3, ch, 10, 10, generator=gen)
+        anchors = torch.from_numpy(synth.ANCHORS_VOC)
+        data = synth.norm_data(synth.labels(3, 320, max(C, 1), seed=4), 320, 320, 10, 10)
+        fo = feat.clone().double().requires_grad_(True)
+        lo, _ = oloss.loss(anchors.double(), {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}, ohead.decode(fo, anchors.double()), 0.6)
+        oloss.total(lo).backward()
+
+        class Id(torch.nn.Module):
+            def forward(self, t):
+                return t
+        f = feat.to(dev()).requires_grad_(True)
+        pred = model._inference(model.Inference(None, Id(), anchors), f)
+        l, _ = model.loss(anchors, data, pred, 0.6)
+        sum(l[k] * oloss.HPARAM[k] for k in l).backward()
+        assert set(l.keys()) == set(lo.keys())
+        for k in l:
+            np.testing.assert_allclose(l[k].item(), lo[k].item(), rtol=5e-5)
+        gr = fo.grad.numpy()
+        np.testing.assert_allclose(f.grad.cpu().numpy(), gr, rtol=5e-4, atol=2e-6 * np.abs(gr).max())
+
+
+def build(sd, num_cls=20, bn=True):
+    import model
+    import model.yolo2
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1' if bn else '0'}})
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, num_cls)
+    dnn.load_state_dict(sd, strict=False)
+    return model.Inference(cfg, dnn, anchors).to(dev()), anchors
+
+
+@pytest.mark.parametrize('bn', [True, False])
+def test_darknet_training_step_matches_oracle_autograd(bn):
+    """fwd (batch-stat BN) + region loss + bwd on a narrow Darknet: every parameter gradient and the running statistics
+    against the oracle's fp64 autograd (train.py:344-351 semantics)."""
+    import model
+    widths = dict(NARROW)
+    widths['layers1.5'] = 8   # wgrad/dgrad DMA path needs channel counts that are multiples of 4
+    sd = odark.init_state_dict(5, 20, seed=0, channels=widths, head_scale=1 / 8.0, bn=bn)
+    inf, anchors = build(sd, bn=bn)
+    inf.train()
+    S, B = 96, 3
+    x = synth.images(B, S, seed=1)
+    data = synth.norm_data(synth.labels(B, S, 20, seed=2), S, S, S // 32, S // 32)
+    pred = model._inference(inf, x.to(dev()))
+    loss, _ = model.loss(anchors, data, pred, 0.6)
+    total = sum(loss[k] * oloss.HPARAM[k] for k in loss)
+    total.backward()
+    # ---- oracle in fp64
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    stats = {}
+    f = odark.forward(x.double(), sd64, training=True, stats=stats)
+    lo, _ = oloss.loss(anchors.double(), {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}, ohead.decode(f, anchors.double()), 0.6)
+    oloss.total(lo).backward()
+    for k in lo:
+        np.testing.assert_allclose(loss[k].item(), lo[k].item(), rtol=1e-4)
+    ours = dict(inf.dnn.named_parameters())
+    worst = 0.0
+    for k, v in sd64.items():
+        if v.requires_grad:
+            assert ours[k].grad is not None, k
+            e = rel(ours[k].grad, v.grad)
+            worst = max(worst, e)
+            assert e <= 2e-3, (k, e)   # gradients pass through up to 23 BN layers in fp32; fp64 oracle
+    bufs = dict(inf.dnn.named_buffers())
+    for prefix, (rm, rv) in stats.items():
+        np.testing.assert_allclose(bufs[prefix + '.bn.running_mean'].cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(bufs[prefix + '.bn.running_var'].cpu().numpy(), rv.numpy(), rtol=1e-4)
+    print('worst relative gradient error', worst)

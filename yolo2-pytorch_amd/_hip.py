@@ -44,6 +44,16 @@ SIGNATURES = {
     'y2_filter_visible': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     'y2_iou_matrix': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     'y2_iou_pair': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p],
+    'y2_conv_wgrad': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'y2_bn_finalize': [c_void_p, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    'y2_bn_act_fwd': [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'y2_bn_act_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
+                      c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'y2_colsum': [c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p, c_void_p],
+    'y2_f64_to_f32': [c_void_p, c_void_p, c_int, ctypes.c_double, c_void_p],
+    'y2_decode_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    'y2_region_loss_fwd': [c_void_p] * 11 + [c_int] * 6 + [c_float] + [c_void_p] * 5 + [c_void_p],
+    'y2_region_loss_bwd': [c_void_p] * 9 + [c_int] * 6 + [c_float] + [c_void_p] * 5 + [c_void_p] * 4 + [c_void_p],
     'y2_nms': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
 }
 

@@ -1,0 +1,612 @@
+// train.hip — training-side streaming kernels for gfx950: BatchNorm statistics/finalise, BN+LeakyReLU(+MaxPool) forward
+// and backward, detection-head decode backward, and the fused region loss (matching, masks, 5 terms, gradient).
+//
+// All of these are HBM-bound (one or two passes over an activation tensor) or tiny (the loss touches ~100 KB per
+// image): 16-B vector accesses along the NHWC channel axis, per-channel reductions staged through LDS atomics and
+// finished with one fp64 global atomic per channel per workgroup, wave64 shuffles for scalar reductions.
+// -ffp-contract=off (build.sh) keeps the IoU arithmetic identical to the reference's fp32 sequence.
+#include "common.h"
+
+namespace {
+
+inline int stream_grid(long long total, int block, int cap_mult = 8) {
+    long long g = (total + block - 1) / block;
+    const long long cap = (long long)Y2_NUM_CU * cap_mult;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ------------------------------------------------------------------------------------------------ BN finalise
+// nn.BatchNorm2d(momentum=0.01, eps=1e-5) in training mode (model/yolo2.py:58): biased batch variance normalises,
+// running stats take the unbiased variance.
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double n, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps,
+                                   float* scale, float* shift, float* mean_out, float* invstd_out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = stats[c] / n;
+    double var = stats[C + c] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float s = gamma[c] * invstd;
+    scale[c] = s;
+    shift[c] = beta[c] - (float)mean * s;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    if (running_mean != nullptr) {
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BN + act forward
+struct ActArgs {
+    const float* z; const float* scale; const float* shift;   // scale/shift may be NULL (identity)
+    float* y; float* y_pool;
+    int B, H, W, C, ldz, ldy, coff, ldp, poff, out_mode;
+    float slope;
+};
+
+__device__ __forceinline__ float act1(float z, float sc, float sh, float slope) {
+    const float u = z * sc + sh;
+    return u > 0.f ? u : u * slope;
+}
+
+// one thread = CV channels (4 with 16-B accesses, or 1) of one pixel (POOL = false) or of one 2x2 window (POOL = true)
+template <bool POOL, int CV>
+__global__ void bn_act_fwd_kernel(const ActArgs a, long long total) {
+    const int Cg = a.C / CV;
+    const int Wo = POOL ? a.W / 2 : a.W, Ho = POOL ? a.H / 2 : a.H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cg) * CV;
+        const long long p = i / Cg;                 // (b*Ho + yo)*Wo + xo
+        const int xo = (int)(p % Wo);
+        const long long r = p / Wo;
+        const int yo = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float sc[CV], sh[CV];
+#pragma unroll
+        for (int e = 0; e < CV; ++e) { sc[e] = a.scale ? a.scale[c + e] : 1.f; sh[e] = a.shift ? a.shift[c + e] : 0.f; }
+        float pm[CV];
+#pragma unroll
+        for (int q = 0; q < (POOL ? 4 : 1); ++q) {
+            const int yy = POOL ? 2 * yo + (q >> 1) : yo, xx = POOL ? 2 * xo + (q & 1) : xo;
+            const long long pix = ((long long)b * a.H + yy) * a.W + xx;
+            float v[CV];
+            if (CV == 4) {
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(a.z + pix * a.ldz + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act1(zz[e], sc[e], sh[e], a.slope);
+            } else {
+                v[0] = act1(a.z[pix * a.ldz + c], sc[0], sh[0], a.slope);
+            }
+            if (a.y != nullptr) {
+                long long o;
+                if (a.out_mode == 1) {   // reorg (model/yolo2.py:33-46): channel block ((y&1)*2 + (x&1)) of pixel (y/2, x/2)
+                    o = (((long long)b * (a.H >> 1) + (yy >> 1)) * (a.W >> 1) + (xx >> 1)) * a.ldy + a.coff + ((yy & 1) * 2 + (xx & 1)) * a.C + c;
+                } else {
+                    o = pix * a.ldy + a.coff + c;
+                }
+                if (CV == 4) { f32x4 w = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(a.y + o) = w; }
+                else a.y[o] = v[0];
+            }
+#pragma unroll
+            for (int e = 0; e < CV; ++e) pm[e] = (q == 0) ? v[e] : fmaxf(pm[e], v[e]);
+        }
+        if (POOL && a.y_pool != nullptr) {
+            const long long o = p * a.ldp + a.poff + c;
+            if (CV == 4) { f32x4 w = {pm[0], pm[1], pm[2], pm[3]}; *reinterpret_cast<f32x4*>(a.y_pool + o) = w; }
+            else a.y_pool[o] = pm[0];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BN + act backward
+// g = dL/du (u = BN output before LeakyReLU) from up to two gradient sources: dy_full (grad of the full-resolution
+// activation; out_mode 1 = gathered through the reorg mapping) and dy_pool (grad of the 2x2 max-pooled activation, routed
+// to the first maximal element of the window like nn.MaxPool2d).  Pass 1 reduces sum(g) and sum(g*zhat) per channel;
+// pass 2 writes dz = gamma*invstd*(g - mean(g) - zhat*mean(g*zhat))   (dz = g when there is no BN).
+struct ActBwdArgs {
+    const float* z; const float* scale; const float* shift; const float* mean; const float* invstd; const float* gamma;
+    const float* dy_full; const float* dy_pool;
+    double* sums;      // [2C]: sum g, sum g*zhat
+    float* dz;         // [B,H,W,C] stride ldd
+    int B, H, W, C, ldz, ldf, foff, fmode, ldp, poff, ldd;
+    float slope;
+    double n;
+    int has_bn;
+};
+
+template <bool POOL, int CV, bool APPLY>
+__global__ void bn_act_bwd_kernel(const ActBwdArgs a, long long total) {
+    extern __shared__ float red[];   // [2*C] block partials (pass 1)
+    const int Cg = a.C / CV;
+    if (!APPLY) {
+        for (int i = threadIdx.x; i < 2 * a.C; i += blockDim.x) red[i] = 0.f;
+        __syncthreads();
+    }
+    const int Wo = POOL ? a.W / 2 : a.W, Ho = POOL ? a.H / 2 : a.H;
+    // total threads is a multiple of Cg (host guarantees): every thread keeps the same channel group over its loop
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    const int c = (int)(tid % Cg) * CV;
+    float sc[CV], sh[CV], mu[CV], is[CV], gs[CV], ma[CV], mb[CV];
+#pragma unroll
+    for (int e = 0; e < CV; ++e) {
+        sc[e] = a.scale ? a.scale[c + e] : 1.f; sh[e] = a.shift ? a.shift[c + e] : 0.f;
+        mu[e] = a.has_bn ? a.mean[c + e] : 0.f; is[e] = a.has_bn ? a.invstd[c + e] : 1.f;
+        if (APPLY && a.has_bn) {
+            gs[e] = a.gamma[c + e] * is[e];
+            ma[e] = (float)(a.sums[c + e] / a.n);
+            mb[e] = (float)(a.sums[a.C + c + e] / a.n);
+        } else { gs[e] = 1.f; ma[e] = 0.f; mb[e] = 0.f; }
+    }
+    float s1[CV], s2[CV];
+#pragma unroll
+    for (int e = 0; e < CV; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+
+    for (long long i = tid; i < total; i += nthreads) {
+        const long long p = i / Cg;
+        const int xo = (int)(p % Wo);
+        const long long r = p / Wo;
+        const int yo = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float zv[POOL ? 4 : 1][CV], yv[POOL ? 4 : 1][CV];
+        long long pixs[POOL ? 4 : 1];
+#pragma unroll
+        for (int q = 0; q < (POOL ? 4 : 1); ++q) {
+            const int yy = POOL ? 2 * yo + (q >> 1) : yo, xx = POOL ? 2 * xo + (q & 1) : xo;
+            pixs[q] = ((long long)b * a.H + yy) * a.W + xx;
+            if (CV == 4) {
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(a.z + pixs[q] * a.ldz + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zv[q][e] = zz[e];
+            } else zv[q][0] = a.z[pixs[q] * a.ldz + c];
+#pragma unroll
+            for (int e = 0; e < CV; ++e) yv[q][e] = zv[q][e] * sc[e] + sh[e];   // u (pre-activation)
+        }
+        // pooled gradient -> first maximal activated value in scan order
+        float dp[CV];
+        int arg[CV];
+        if (POOL) {
+            const long long o = p * a.ldp + a.poff + c;
+            if (CV == 4) { const f32x4 d = *reinterpret_cast<const f32x4*>(a.dy_pool + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dp[e] = d[e]; }
+            else dp[0] = a.dy_pool[o];
+#pragma unroll
+            for (int e = 0; e < CV; ++e) {
+                float best = 0.f; int bi = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float u = yv[q][e];
+                    const float v = u > 0.f ? u : u * a.slope;
+                    if (q == 0 || v > best) { best = v; bi = q; }
+                }
+                arg[e] = bi;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < (POOL ? 4 : 1); ++q) {
+            float g[CV];
+#pragma unroll
+            for (int e = 0; e < CV; ++e) g[e] = (POOL && arg[e] == q) ? dp[e] : 0.f;
+            if (a.dy_full != nullptr) {
+                const int yy = POOL ? 2 * yo + (q >> 1) : yo, xx = POOL ? 2 * xo + (q & 1) : xo;
+                long long o;
+                if (a.fmode == 1) o = (((long long)b * (a.H >> 1) + (yy >> 1)) * (a.W >> 1) + (xx >> 1)) * a.ldf + a.foff + ((yy & 1) * 2 + (xx & 1)) * a.C + c;
+                else o = pixs[q] * a.ldf + a.foff + c;
+                if (CV == 4) { const f32x4 d = *reinterpret_cast<const f32x4*>(a.dy_full + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] += d[e]; }
+                else g[0] += a.dy_full[o];
+            }
+            float outv[CV];
+#pragma unroll
+            for (int e = 0; e < CV; ++e) {
+                const float ge = g[e] * (yv[q][e] > 0.f ? 1.f : a.slope);      // through LeakyReLU
+                const float zh = (zv[q][e] - mu[e]) * is[e];
+                if (!APPLY) { s1[e] += ge; s2[e] += ge * zh; }
+                else outv[e] = gs[e] * (ge - ma[e] - zh * mb[e]);
+            }
+            if (APPLY) {
+                const long long o = pixs[q] * a.ldd + c;
+                if (CV == 4) { f32x4 w = {outv[0], outv[1], outv[2], outv[3]}; *reinterpret_cast<f32x4*>(a.dz + o) = w; }
+                else a.dz[o] = outv[0];
+            }
+        }
+    }
+    if (!APPLY) {
+#pragma unroll
+        for (int e = 0; e < CV; ++e) { atomicAdd(&red[c + e], s1[e]); atomicAdd(&red[a.C + c + e], s2[e]); }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * a.C; i += blockDim.x) {
+            const float v = red[i];
+            if (v != 0.f) atomicAdd(a.sums + i, (double)v);
+        }
+    }
+}
+
+// per-channel column sums of a [M, C] (stride ld) matrix -> fp64 atomics (conv-bias gradient of blocks without BN)
+__global__ void colsum_kernel(const float* __restrict__ x, long long M, int C, int ld, double* out) {
+    extern __shared__ float red[];
+    for (int i = threadIdx.x; i < C; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    const long long total = M * C;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+    const int c = (int)(tid % C);
+    float s = 0.f;
+    for (long long i = tid; i < total; i += nth) s += x[(i / C) * ld + c];
+    atomicAdd(&red[c], s);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += blockDim.x) if (red[i] != 0.f) atomicAdd(out + i, (double)red[i]);
+}
+
+__global__ void f64_to_f32_kernel(const double* s, float* d, int n, double mul) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = (float)(s[i] * mul);
+}
+
+// ------------------------------------------------------------------------------------------------ decode backward
+// Gradient of model.Inference's decode (model/__init__.py:122-135) w.r.t. the head image, from the gradients of
+// iou / center_offset / size_norm / logits (the reference's loss detaches yx_min / yx_max, model/__init__.py:142).
+__global__ void decode_bwd_kernel(const float* __restrict__ iou, const float* __restrict__ co, const float* __restrict__ d_iou,
+                                  const float* __restrict__ d_co, const float* __restrict__ d_sn, const float* __restrict__ d_logits,
+                                  float* __restrict__ dfeat, int total, int C) {
+    const int E = 5 + C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)total * E; i += (long long)gridDim.x * blockDim.x) {
+        const int box = (int)(i / E), k = (int)(i % E);
+        float v;
+        if (k == 0) { const float s = iou[box]; v = d_iou ? d_iou[box] * s * (1.f - s) : 0.f; }
+        else if (k < 3) { const float s = co[2 * (size_t)box + k - 1]; v = d_co ? d_co[2 * (size_t)box + k - 1] * s * (1.f - s) : 0.f; }
+        else if (k < 5) v = d_sn ? d_sn[2 * (size_t)box + k - 3] : 0.f;
+        else v = d_logits ? d_logits[(size_t)box * C + k - 5] : 0.f;
+        dfeat[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ region loss
+__device__ __forceinline__ float iou_box(float ymin1, float xmin1, float ymax1, float xmax1,
+                                         float ymin2, float xmin2, float ymax2, float xmax2) {
+    // utils/iou/torch.py:126-153 operation order
+    const float ih = fmaxf(fminf(ymax1, ymax2) - fmaxf(ymin1, ymin2), 0.f);
+    const float iw = fmaxf(fminf(xmax1, xmax2) - fmaxf(xmin1, xmin2), 0.f);
+    const float inter = ih * iw;
+    const float a1 = (ymax1 - ymin1) * (xmax1 - xmin1);
+    const float a2 = (ymax2 - ymin2) * (xmax2 - xmin2);
+    const float uni = fmaxf((a1 + a2) - inter, 1.1920929e-07f);
+    return inter / uni;
+}
+
+// model.iou_match (model/__init__.py:59-73): best IoU of every (cell, anchor) slot over the image's GT boxes; first max.
+__global__ __launch_bounds__(256) void loss_match_kernel(const float* __restrict__ yx_min, const float* __restrict__ yx_max,
+                                                         const float* __restrict__ gt_min, const float* __restrict__ gt_max,
+                                                         int n, int N, float* best_iou, int32_t* best_idx) {
+    __shared__ float g[4 * 256];
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float y0 = 0, x0 = 0, y1 = 0, x1 = 0;
+    if (i < n) {
+        const size_t o = ((size_t)b * n + i) * 2;
+        y0 = yx_min[o]; x0 = yx_min[o + 1]; y1 = yx_max[o]; x1 = yx_max[o + 1];
+    }
+    float best = 0.f; int arg = 0; bool first = true;
+    for (int j0 = 0; j0 < N; j0 += 256) {
+        const int cnt = min(256, N - j0);
+        __syncthreads();
+        if (threadIdx.x < cnt) {
+            const size_t o = ((size_t)b * N + j0 + threadIdx.x) * 2;
+            g[4 * threadIdx.x] = gt_min[o]; g[4 * threadIdx.x + 1] = gt_min[o + 1];
+            g[4 * threadIdx.x + 2] = gt_max[o]; g[4 * threadIdx.x + 3] = gt_max[o + 1];
+        }
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            const float v = iou_box(y0, x0, y1, x1, g[4 * j], g[4 * j + 1], g[4 * j + 2], g[4 * j + 3]);
+            if (first || v > best) { best = v; arg = j0 + j; first = false; }
+        }
+    }
+    if (i < n) { best_iou[(size_t)b * n + i] = best; best_idx[(size_t)b * n + i] = arg; }
+}
+
+// model.fit_positive (model/__init__.py:76-95): each valid GT marks (cell of its centre, best-shape anchor).
+__global__ void loss_positive_kernel(const float* __restrict__ gt_min, const float* __restrict__ gt_max, const float* __restrict__ anchors,
+                                     int B, int N, int rows, int cols, int A, uint8_t* positive) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * N) return;
+    const int b = i / N;
+    const float y0 = gt_min[2 * (size_t)i], x0 = gt_min[2 * (size_t)i + 1], y1 = gt_max[2 * (size_t)i], x1 = gt_max[2 * (size_t)i + 1];
+    if (!(y0 < y1 && x0 < x1)) return;                            // :80
+    const float cy = (y0 + y1) / 2.f, cx = (x0 + x1) / 2.f;
+    const int ci = (int)floorf(cy), cj = (int)floorf(cx);
+    if (ci < 0 || ci >= rows || cj < 0 || cj >= cols) return;      // the reference would raise an IndexError here
+    float best = 0.f; int arg = 0;
+    for (int k = 0; k < A; ++k) {
+        const float ah = anchors[2 * k] / 2.f, aw = anchors[2 * k + 1] / 2.f;
+        const float v = iou_box(y0 - cy, x0 - cx, y1 - cy, x1 - cx, -ah, -aw, ah, aw);   // :86
+        if (k == 0 || v > best) { best = v; arg = k; }
+    }
+    positive[((size_t)b * rows * cols + (size_t)ci * cols + cj) * A + arg] = 1;
+}
+
+struct LossArgs {
+    const float* iou; const float* co; const float* sn; const float* logits;      // predictions [B,n], [B,n,2], [B,n,2], [B,n,C]
+    const float* best_iou; const int32_t* best_idx; const uint8_t* positive;
+    const float* gt_min; const float* gt_max; const int64_t* gt_cls; const float* gt_onehot;   // one of gt_cls / gt_onehot (or neither when C == 0)
+    const float* anchors;
+    int B, n, N, A, C;
+    float threshold;
+};
+
+// per-slot targets (model.fill_norm, model/__init__.py:98-103) from the best-IoU-matched GT
+__device__ __forceinline__ void slot_targets(const LossArgs& a, int b, int i, float& t_cy, float& t_cx, float& t_h, float& t_w, int& gi) {
+    gi = a.best_idx[(size_t)b * a.n + i];
+    const size_t o = ((size_t)b * a.N + gi) * 2;
+    const float y0 = a.gt_min[o], x0 = a.gt_min[o + 1], y1 = a.gt_max[o], x1 = a.gt_max[o + 1];
+    const float cy = (y0 + y1) / 2.f, cx = (x0 + x1) / 2.f;
+    t_cy = cy - floorf(cy); t_cx = cx - floorf(cx);
+    const int anc = i % a.A;
+    t_h = logf((y1 - y0) / a.anchors[2 * anc]);
+    t_w = logf((x1 - x0) / a.anchors[2 * anc + 1]);
+}
+
+// sums[0..5] = foreground, background, center, size, cls (sum over positives), number of positives   (fp64 atomics)
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const LossArgs a, double* sums) {
+    __shared__ float part[6][4];
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v[6] = {0, 0, 0, 0, 0, 0};
+    if (i < a.n) {
+        const size_t s = (size_t)b * a.n + i;
+        const float p_iou = a.iou[s];
+        const float bi = a.best_iou[s];
+        const bool pos = a.positive[s] != 0;
+        const bool neg = !pos && bi < a.threshold;                              // model/__init__.py:145
+        if (neg) v[1] = p_iou * p_iou;                                          // :152
+        if (pos) {
+            float t_cy, t_cx, t_h, t_w; int gi;
+            slot_targets(a, b, i, t_cy, t_cx, t_h, t_w, gi);
+            const float d0 = p_iou - bi; v[0] = d0 * d0;                        // :151
+            const float dcy = a.co[2 * s] - t_cy, dcx = a.co[2 * s + 1] - t_cx; v[2] = dcy * dcy + dcx * dcx;   // :154
+            const float dh = a.sn[2 * s] - t_h, dw = a.sn[2 * s + 1] - t_w; v[3] = dh * dh + dw * dw;           // :155
+            v[5] = 1.f;
+            if (a.C > 0) {
+                const float* lg = a.logits + s * a.C;
+                float mx = lg[0];
+                for (int c = 1; c < a.C; ++c) mx = fmaxf(mx, lg[c]);
+                float sum = 0.f;
+                for (int c = 0; c < a.C; ++c) sum += expf(lg[c] - mx);
+                if (a.gt_cls != nullptr) {                                      // :162 cross entropy (summed here, mean taken by the caller)
+                    const int k = (int)a.gt_cls[(size_t)b * a.N + gi];
+                    v[4] = -(lg[k] - mx - logf(sum));
+                } else if (a.gt_onehot != nullptr) {                            // :160 MSE on softmax
+                    const float* oh = a.gt_onehot + ((size_t)b * a.N + gi) * a.C;
+                    float acc = 0.f;
+                    for (int c = 0; c < a.C; ++c) { const float d = expf(lg[c] - mx) / sum - oh[c]; acc += d * d; }
+                    v[4] = acc;
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        float x = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if (lane == 0) part[k][wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const float x = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+        if (x != 0.f) atomicAdd(sums + threadIdx.x, (double)x);
+    }
+}
+
+// loss[k] = sums[k] / cnt (k < 4); cls: CE mean over positives then / cnt (model/__init__.py:162,164-166), MSE: sum / cnt
+__global__ void loss_finalize_kernel(const double* sums, double cnt, int ce, float* out) {
+    const int k = threadIdx.x;
+    if (k < 4) out[k] = (float)(sums[k] / cnt);
+    else if (k == 4) out[4] = ce ? (float)(sums[4] / sums[5] / cnt) : (float)(sums[4] / cnt);   // no positives -> nan, like F.cross_entropy on an empty batch
+}
+
+// gradient w.r.t. iou / center_offset / size_norm / logits; w[k] = upstream gradient of loss term k (train.py:348-349 hparams)
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const LossArgs a, const double* sums, double cnt, const float* __restrict__ w,
+                                                       float* d_iou, float* d_co, float* d_sn, float* d_logits) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const size_t s = (size_t)b * a.n + i;
+    const float inv = (float)(1.0 / cnt);
+    const float p_iou = a.iou[s];
+    const float bi = a.best_iou[s];
+    const bool pos = a.positive[s] != 0;
+    const bool neg = !pos && bi < a.threshold;
+    float g_iou = 0.f, g_cy = 0.f, g_cx = 0.f, g_h = 0.f, g_w = 0.f;
+    if (neg) g_iou = w[1] * 2.f * p_iou * inv;
+    int gi = 0;
+    if (pos) {
+        float t_cy, t_cx, t_h, t_w;
+        slot_targets(a, b, i, t_cy, t_cx, t_h, t_w, gi);
+        g_iou = w[0] * 2.f * (p_iou - bi) * inv;
+        g_cy = w[2] * 2.f * (a.co[2 * s] - t_cy) * inv;
+        g_cx = w[2] * 2.f * (a.co[2 * s + 1] - t_cx) * inv;
+        g_h = w[3] * 2.f * (a.sn[2 * s] - t_h) * inv;
+        g_w = w[3] * 2.f * (a.sn[2 * s + 1] - t_w) * inv;
+    }
+    d_iou[s] = g_iou;
+    d_co[2 * s] = g_cy; d_co[2 * s + 1] = g_cx;
+    d_sn[2 * s] = g_h; d_sn[2 * s + 1] = g_w;
+    if (a.C > 0 && d_logits != nullptr) {
+        float* dl = d_logits + s * a.C;
+        if (!pos || (a.gt_cls == nullptr && a.gt_onehot == nullptr)) {
+            for (int c = 0; c < a.C; ++c) dl[c] = 0.f;
+        } else {
+            const float* lg = a.logits + s * a.C;
+            float mx = lg[0];
+            for (int c = 1; c < a.C; ++c) mx = fmaxf(mx, lg[c]);
+            float sum = 0.f;
+            for (int c = 0; c < a.C; ++c) sum += expf(lg[c] - mx);
+            if (a.gt_cls != nullptr) {
+                const int k = (int)a.gt_cls[(size_t)b * a.N + gi];
+                const float f = w[4] * inv / (float)sums[5];
+                for (int c = 0; c < a.C; ++c) dl[c] = f * (expf(lg[c] - mx) / sum - (c == k ? 1.f : 0.f));
+            } else {
+                const float* oh = a.gt_onehot + ((size_t)b * a.N + gi) * a.C;
+                const float f = w[4] * 2.f * inv;
+                float dot = 0.f;
+                for (int c = 0; c < a.C; ++c) { const float sm = expf(lg[c] - mx) / sum; dot += f * (sm - oh[c]) * sm; }
+                for (int c = 0; c < a.C; ++c) { const float sm = expf(lg[c] - mx) / sum; dl[c] = sm * (f * (sm - oh[c]) - dot); }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" int y2_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps,
+                              float* scale, float* shift, float* mean, float* invstd, int C, y2_stream_t stream) {
+    if (!stats || !gamma || !beta || !scale || !shift || !mean || !invstd || C <= 0 || count <= 0) return Y2_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(y2_cdiv(C, 256)), dim3(256), 0, y2_s(stream), stats, count, gamma, beta, running_mean, running_var,
+                       momentum, eps, scale, shift, mean, invstd, C);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_bn_act_fwd(const float* z, const float* scale, const float* shift, float slope, float* y, float* y_pool,
+                             int B, int H, int W, int C, int ldz, int ldy, int coff, int ldp, int poff, int out_mode, y2_stream_t stream) {
+    if (!z || (!y && !y_pool) || B <= 0 || H <= 0 || W <= 0 || C <= 0) return Y2_EINVAL;
+    const bool pool = y_pool != nullptr;
+    if ((pool || out_mode == 1) && ((H & 1) || (W & 1))) return Y2_EINVAL;
+    ActArgs a;
+    a.z = z; a.scale = scale; a.shift = shift; a.y = y; a.y_pool = y_pool;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.ldz = ldz; a.ldy = ldy; a.coff = coff; a.ldp = ldp; a.poff = poff; a.out_mode = out_mode; a.slope = slope;
+    const bool vec = !(C & 3) && !(ldz & 3) && (!y || (!(ldy & 3) && !(coff & 3) && y2_aligned16(y))) && (!pool || (!(ldp & 3) && !(poff & 3) && y2_aligned16(y_pool))) && y2_aligned16(z);
+    const long long pix = (long long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    const long long total = pix * (vec ? C / 4 : C);
+    const int grid = stream_grid(total, 256);
+    hipStream_t s = y2_s(stream);
+    if (pool) { if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<true, 4>), dim3(grid), dim3(256), 0, s, a, total); else hipLaunchKernelGGL((bn_act_fwd_kernel<true, 1>), dim3(grid), dim3(256), 0, s, a, total); }
+    else { if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<false, 4>), dim3(grid), dim3(256), 0, s, a, total); else hipLaunchKernelGGL((bn_act_fwd_kernel<false, 1>), dim3(grid), dim3(256), 0, s, a, total); }
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_bn_act_bwd(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,
+                             float slope, const float* dy_full, int ldf, int foff, int fmode, const float* dy_pool, int ldp, int poff,
+                             double* sums, float* dz, int ldd, int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream) {
+    if (!z || (!dy_full && !dy_pool) || !sums || !dz || B <= 0 || H <= 0 || W <= 0 || C <= 0) return Y2_EINVAL;
+    if (has_bn && (!mean || !invstd || !gamma)) return Y2_EINVAL;
+    const bool pool = dy_pool != nullptr;
+    if ((pool || fmode == 1) && ((H & 1) || (W & 1))) return Y2_EINVAL;
+    if (C > 8192) return Y2_ENOSUP;
+    ActBwdArgs a;
+    a.z = z; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.gamma = gamma;
+    a.dy_full = dy_full; a.dy_pool = dy_pool; a.sums = sums; a.dz = dz;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.ldz = ldz; a.ldf = ldf; a.foff = foff; a.fmode = fmode; a.ldp = ldp; a.poff = poff; a.ldd = ldd;
+    a.slope = slope; a.n = (double)B * H * W; a.has_bn = has_bn;
+    const bool vec = !(C & 3) && !(ldz & 3) && !(ldd & 3) && y2_aligned16(z) && y2_aligned16(dz) &&
+                     (!dy_full || (!(ldf & 3) && !(foff & 3) && y2_aligned16(dy_full))) && (!pool || (!(ldp & 3) && !(poff & 3) && y2_aligned16(dy_pool)));
+    const int Cg = vec ? C / 4 : C;
+    const long long pix = (long long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    const long long total = pix * Cg;
+    // total threads must be a multiple of Cg: blocks of 256 threads, grid a multiple of Cg / gcd(Cg, 256)
+    int g = 256, r = Cg;
+    while (r) { const int t = g % r; g = r; r = t; }
+    const int unit = Cg / g;
+    long long want = (total + 256 * 8 - 1) / (256 * 8);
+    const long long cap = (long long)Y2_NUM_CU * 8;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    const int grid = (int)(((want + unit - 1) / unit) * unit);
+    const size_t lds = (size_t)2 * C * sizeof(float);
+    hipStream_t s = y2_s(stream);
+#define Y2_BWD(POOL, CV)                                                                                             \
+    do {                                                                                                             \
+        hipLaunchKernelGGL((bn_act_bwd_kernel<POOL, CV, false>), dim3(grid), dim3(256), lds, s, a, total);            \
+        hipLaunchKernelGGL((bn_act_bwd_kernel<POOL, CV, true>), dim3(grid), dim3(256), 0, s, a, total);               \
+    } while (0)
+    if (pool) { if (vec) Y2_BWD(true, 4); else Y2_BWD(true, 1); }
+    else { if (vec) Y2_BWD(false, 4); else Y2_BWD(false, 1); }
+#undef Y2_BWD
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_colsum(const float* x, long long M, int C, int ld, double* out, y2_stream_t stream) {
+    if (!x || !out || M <= 0 || C <= 0 || ld < C || C > 16384) return Y2_EINVAL;
+    // total threads multiple of C
+    int g = 256, r = C;
+    while (r) { const int t = g % r; g = r; r = t; }
+    const int unit = C / g;
+    long long want = (M * C + 256 * 16 - 1) / (256 * 16);
+    const long long cap = (long long)Y2_NUM_CU * 4;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    const int grid = (int)(((want + unit - 1) / unit) * unit);
+    hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), (size_t)C * sizeof(float), y2_s(stream), x, M, C, ld, out);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_f64_to_f32(const double* src, float* dst, int n, double mul, y2_stream_t stream) {
+    if (!src || !dst || n <= 0) return Y2_EINVAL;
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(y2_cdiv(n, 256)), dim3(256), 0, y2_s(stream), src, dst, n, mul);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_decode_bwd(const float* iou, const float* center_offset, const float* d_iou, const float* d_center_offset, const float* d_size_norm,
+                             const float* d_logits, float* d_feature, int boxes, int C, y2_stream_t stream) {
+    if (!iou || !center_offset || !d_feature || boxes <= 0 || C < 0) return Y2_EINVAL;
+    const long long total = (long long)boxes * (5 + C);
+    hipLaunchKernelGGL(decode_bwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), iou, center_offset, d_iou, d_center_offset, d_size_norm, d_logits,
+                       d_feature, boxes, C);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_region_loss_fwd(const float* iou, const float* center_offset, const float* size_norm, const float* logits,
+                                  const float* yx_min, const float* yx_max,
+                                  const float* gt_yx_min, const float* gt_yx_max, const int64_t* gt_cls, const float* gt_onehot,
+                                  const float* anchors, int B, int rows, int cols, int A, int C, int N, float threshold,
+                                  float* best_iou, int32_t* best_idx, uint8_t* positive, double* sums, float* loss_out, y2_stream_t stream) {
+    if (!iou || !center_offset || !size_norm || !yx_min || !yx_max || !gt_yx_min || !gt_yx_max || !anchors) return Y2_EINVAL;
+    if (!best_iou || !best_idx || !positive || !sums || !loss_out) return Y2_EINVAL;
+    if (B <= 0 || rows <= 0 || cols <= 0 || A <= 0 || C < 0 || N <= 0) return Y2_EINVAL;
+    if (C > 0 && !logits) return Y2_EINVAL;
+    const int n = rows * cols * A;
+    hipStream_t s = y2_s(stream);
+    hipError_t e = hipMemsetAsync(positive, 0, (size_t)B * n, s);
+    if (e != hipSuccess) return -(1000 + (int)e);
+    e = hipMemsetAsync(sums, 0, 6 * sizeof(double), s);
+    if (e != hipSuccess) return -(1000 + (int)e);
+    hipLaunchKernelGGL(loss_match_kernel, dim3(y2_cdiv(n, 256), B), dim3(256), 0, s, yx_min, yx_max, gt_yx_min, gt_yx_max, n, N, best_iou, best_idx);
+    hipLaunchKernelGGL(loss_positive_kernel, dim3(y2_cdiv((long long)B * N, 256)), dim3(256), 0, s, gt_yx_min, gt_yx_max, anchors, B, N, rows, cols, A, positive);
+    LossArgs a;
+    a.iou = iou; a.co = center_offset; a.sn = size_norm; a.logits = logits; a.best_iou = best_iou; a.best_idx = best_idx; a.positive = positive;
+    a.gt_min = gt_yx_min; a.gt_max = gt_yx_max; a.gt_cls = gt_cls; a.gt_onehot = gt_onehot; a.anchors = anchors;
+    a.B = B; a.n = n; a.N = N; a.A = A; a.C = C; a.threshold = threshold;
+    hipLaunchKernelGGL(loss_fwd_kernel, dim3(y2_cdiv(n, 256), B), dim3(256), 0, s, a, sums);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, sums, (double)B * n, gt_cls != nullptr ? 1 : 0, loss_out);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_region_loss_bwd(const float* iou, const float* center_offset, const float* size_norm, const float* logits,
+                                  const float* gt_yx_min, const float* gt_yx_max, const int64_t* gt_cls, const float* gt_onehot,
+                                  const float* anchors, int B, int rows, int cols, int A, int C, int N, float threshold,
+                                  const float* best_iou, const int32_t* best_idx, const uint8_t* positive, const double* sums, const float* weights,
+                                  float* d_iou, float* d_center_offset, float* d_size_norm, float* d_logits, y2_stream_t stream) {
+    if (!iou || !center_offset || !size_norm || !gt_yx_min || !gt_yx_max || !anchors || !best_iou || !best_idx || !positive || !sums || !weights) return Y2_EINVAL;
+    if (!d_iou || !d_center_offset || !d_size_norm) return Y2_EINVAL;
+    const int n = rows * cols * A;
+    LossArgs a;
+    a.iou = iou; a.co = center_offset; a.sn = size_norm; a.logits = logits; a.best_iou = best_iou; a.best_idx = best_idx; a.positive = positive;
+    a.gt_min = gt_yx_min; a.gt_max = gt_yx_max; a.gt_cls = gt_cls; a.gt_onehot = gt_onehot; a.anchors = anchors;
+    a.B = B; a.n = n; a.N = N; a.A = A; a.C = C; a.threshold = threshold;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(y2_cdiv(n, 256), B), dim3(256), 0, y2_s(stream), a, sums, (double)B * n, weights, d_iou, d_center_offset, d_size_norm, d_logits);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}

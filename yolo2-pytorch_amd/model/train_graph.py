@@ -1,0 +1,380 @@
+"""Training graph of the YOLOv2 hot path on MI355X: autograd.Functions whose forward/backward are chains of HIP kernels.
+
+The reference trains through torch autograd over nn.Conv2d / nn.BatchNorm2d / LeakyReLU / MaxPool2d
+(model/yolo2.py:49-130) and elementwise tensor expressions (model/__init__.py:117-167); `train.py:344-357` calls
+`_inference` -> `loss` -> `backward` -> `optimizer.step`.  Here the same Python surface is kept and three Functions
+carry the arithmetic:
+
+  DarknetTrainFn : x, parameters -> head image (NHWC).  forward = per block {raw conv (+ per-channel sum / sum^2 in the
+                   epilogue) -> y2_bn_finalize (batch statistics, running-stat update) -> y2_bn_act_fwd (affine +
+                   LeakyReLU + pool / reorg / concat addressing)}; backward = per block, in reverse, {y2_bn_act_bwd
+                   (pool routing + LeakyReLU + BN backward, d gamma / d beta) -> y2_conv_wgrad -> dgrad (= y2_conv_fwd on
+                   180-degree-rotated, in/out-swapped weights)}.
+  DecodeFn       : head image -> iou, center_offset, size_norm, yx_min, yx_max, logits (y2_decode / y2_decode_bwd).
+  RegionLossFn   : predictions + labels -> the five loss terms (y2_region_loss_fwd / _bwd).
+
+torch only allocates, keeps the autograd tape and (in train.py's wrapper) runs the RCCL all-reduce.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+import _hip
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.01
+LEAKY = 0.1
+
+
+def _new(dev, *shape, dtype=torch.float32):
+    return torch.empty(*shape, dtype=dtype, device=dev)
+
+
+def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=None, slope=1.0, stats=None, y_pool=None, ldp=0, coff=0, out_mode=0):
+    p = _hip.ConvParams()
+    p.x, p.w = x.data_ptr(), wp.data_ptr()
+    p.scale = scale.data_ptr() if scale is not None else None
+    p.shift = shift.data_ptr() if shift is not None else None
+    p.y = y.data_ptr() if y is not None else None
+    p.y_pool = y_pool.data_ptr() if y_pool is not None else None
+    p.stats = stats.data_ptr() if stats is not None else None
+    p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize = B, H, W, cin, ldx, cout, k
+    p.ldy, p.coff, p.ldp, p.poff, p.out_mode = ldy, coff, ldp, 0, out_mode
+    p.slope, p.tile = slope, 0
+    _hip.check(L.y2_conv_fwd(ctypes.byref(p), st), 'y2_conv_fwd')
+
+
+class _Block(object):
+    """One conv block of the forward pass: geometry + saved tensors for backward."""
+    __slots__ = ('mod', 'name', 'x', 'ldx', 'H', 'W', 'cin', 'cout', 'k', 'z', 'scale', 'shift', 'mean', 'invstd', 'pool',
+                 'out_full', 'out_pool', 'out_ld', 'out_off', 'out_mode', 'has_bn', 'slope', 'first')
+
+
+def darknet_forward(dnn, x):
+    """Training-mode forward of model.yolo2.Darknet; returns the NCHW view like the inference path."""
+    params = [p for p in dnn.parameters()]
+    out = DarknetTrainFn.apply(dnn, x, *params)
+    return out.permute(0, 3, 1, 2)
+
+
+class DarknetTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dnn, x, *params):
+        _hip.require_gpu(x)
+        L = _hip.lib()
+        st = _hip.stream()
+        x = _hip.f32c(x.detach())
+        B, cin0, H, W = x.shape
+        if H % 32 or W % 32:
+            raise ValueError('input size must be a multiple of 32 (got %dx%d)' % (H, W))
+        dev = x.device
+        b1, b2, b3 = dnn._blocks()
+        blocks = []
+
+        def run_block(name, mod, xin, ldx, h, w, pool, out_full=None, out_ld=0, out_off=0, out_mode=0, want_full=True, first=False):
+            """raw conv + stats -> finalize -> act.  Returns (_Block, full activation or None, pooled activation or None)."""
+            blk = _Block()
+            weight = mod.conv.weight.detach()
+            cout, cin, k, _ = weight.shape
+            blk.mod, blk.name, blk.x, blk.ldx, blk.H, blk.W, blk.cin, blk.cout, blk.k = mod, name, xin, ldx, h, w, cin, cout, k
+            blk.pool, blk.has_bn, blk.slope, blk.first = pool, mod.bn is not None, (LEAKY if mod.has_act else 1.0), first
+            z = _new(dev, B, h, w, cout)
+            stats = torch.zeros(2 * cout, dtype=torch.float64, device=dev) if blk.has_bn else None
+            if first:
+                _hip.check(L.y2_conv0_fwd(_hip.ptr(xin), _hip.ptr(_hip.f32c(weight)), None, None, _hip.ptr(z), None, _hip.ptr(stats),
+                                          B, h, w, cin, cout, cout, 0, 1.0, st), 'y2_conv0_fwd')
+            else:
+                wp = _new(dev, weight.numel())
+                _hip.check(L.y2_pack_weight(_hip.ptr(_hip.f32c(weight)), _hip.ptr(wp), cout, cin, k, 0, st), 'y2_pack_weight')
+                _conv(L, st, xin, wp, z, B, h, w, cin, ldx, cout, k, cout, stats=stats)
+            blk.z = z
+            if blk.has_bn:
+                bn = mod.bn
+                blk.scale, blk.shift, blk.mean, blk.invstd = (_new(dev, cout) for _ in range(4))
+                _hip.check(L.y2_bn_finalize(_hip.ptr(stats), float(B * h * w), _hip.ptr(bn.weight.detach()), _hip.ptr(bn.bias.detach()),
+                                            _hip.ptr(bn.running_mean), _hip.ptr(bn.running_var), BN_MOMENTUM, BN_EPS,
+                                            _hip.ptr(blk.scale), _hip.ptr(blk.shift), _hip.ptr(blk.mean), _hip.ptr(blk.invstd), cout, st), 'y2_bn_finalize')
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
+            else:
+                blk.scale, blk.mean, blk.invstd = None, None, None
+                blk.shift = _hip.f32c(mod.conv.bias.detach()) if mod.conv.bias is not None else None
+            y_full = y_pool = None
+            if out_full is not None:
+                y_full = out_full
+            elif want_full:
+                y_full, out_ld, out_off = _new(dev, B, h, w, cout), cout, 0
+            if pool:
+                y_pool = _new(dev, B, h // 2, w // 2, cout)
+            _hip.check(L.y2_bn_act_fwd(_hip.ptr(z), _hip.ptr(blk.scale), _hip.ptr(blk.shift), blk.slope, _hip.ptr(y_full), _hip.ptr(y_pool),
+                                       B, h, w, cout, cout, out_ld, out_off, cout, 0, out_mode, st), 'y2_bn_act_fwd')
+            blk.out_full, blk.out_pool, blk.out_ld, blk.out_off, blk.out_mode = y_full, y_pool, out_ld, out_off, out_mode
+            blocks.append(blk)
+            return blk, y_full, y_pool
+
+        # ---- layers1 (model/yolo2.py:76-96)
+        cur, ld, h, w = x, cin0, H, W
+        full_last = None
+        for i, (name, mod, pool) in enumerate(b1):
+            last = i == len(b1) - 1
+            pool = pool or last      # layers2 starts with the MaxPool that follows layers1[-1] (model/yolo2.py:97)
+            blk, yf, yp = run_block(name, mod, cur, ld, h, w, pool, want_full=(not pool) or last, first=(i == 0))
+            if last:
+                full_last, fh, fw = yf, h, w
+            if pool:
+                cur, h, w = yp, h // 2, w // 2
+            else:
+                cur = yf
+            ld = blk.cout
+        # ---- passthrough + reorg into the concat buffer (model/yolo2.py:107,126,129)
+        c_pt = dnn.passthrough.conv.weight.shape[0]
+        c_l2 = b2[-1][1].conv.weight.shape[0]
+        cat = _new(dev, B, h, w, 4 * c_pt + c_l2)
+        run_block('passthrough', dnn.passthrough, full_last, full_last.shape[-1], fh, fw, False, out_full=cat, out_ld=cat.shape[-1], out_off=0, out_mode=1)
+        # ---- layers2 (leading MaxPool already applied: `cur` is the pooled output of layers1[-1])
+        for i, (name, mod, pool) in enumerate(b2):
+            if i == len(b2) - 1:
+                blk, yf, yp = run_block(name, mod, cur, ld, h, w, False, out_full=cat, out_ld=cat.shape[-1], out_off=4 * c_pt)
+            else:
+                blk, yf, yp = run_block(name, mod, cur, ld, h, w, False)
+                cur, ld = yf, blk.cout
+        # ---- layers3
+        cur, ld = cat, cat.shape[-1]
+        for i, (name, mod, pool) in enumerate(b3):
+            blk, yf, yp = run_block(name, mod, cur, ld, h, w, False)
+            cur, ld = yf, blk.cout
+        ctx.dnn = dnn
+        ctx.blocks = blocks
+        ctx.geom = (B, cin0, H, W, c_pt, c_l2)
+        ctx.x = x
+        ctx.param_ids = [id(p) for p in params]
+        return cur
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _hip.lib()
+        st = _hip.stream()
+        dnn, blocks = ctx.dnn, ctx.blocks
+        B, cin0, H, W, c_pt, c_l2 = ctx.geom
+        dev = dout.device
+        dout = _hip.f32c(dout)
+        grads = {}
+        hook = getattr(dnn, 'grad_ready_hook', None)
+
+        def ready(param, g):
+            grads[id(param)] = g
+            if hook is not None:
+                hook(param, g)
+
+        # gradient sources per block index: (dy_full tensor, ldf, foff, fmode), dy_pool tensor
+        n = len(blocks)
+        src_full = [None] * n
+        src_pool = [None] * n
+        idx = {b.name: i for i, b in enumerate(blocks)}
+        head = n - 1
+        src_full[head] = (dout, blocks[head].cout, 0, 0)
+        # who consumes whose output
+        n1 = len(dnn._blocks()[0])
+        i_pass = idx['passthrough']
+        order = list(range(n - 1, -1, -1))
+        dcat = None
+        for i in order:
+            blk = blocks[i]
+            h, w, cout, cin, k = blk.H, blk.W, blk.cout, blk.cin, blk.k
+            sums = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
+            # the wgrad / dgrad DMA kernels want channel counts that are multiples of 4: an unaligned Cout (the 125 / 425
+            # channel head) is handled in a zero-padded channel space; unaligned Cin is an inference-only feature
+            cop = (cout + 3) // 4 * 4
+            if not blk.first and cin % 4:
+                raise RuntimeError('training needs conv input channel counts that are multiples of 4 (%s has %d); inference supports any width' % (blk.name, cin))
+            dz = _new(dev, B, h, w, cop) if cop == cout else torch.zeros(B, h, w, cop, dtype=torch.float32, device=dev)
+            sf, sp = src_full[i], src_pool[i]
+            _hip.check(L.y2_bn_act_bwd(_hip.ptr(blk.z), _hip.ptr(blk.scale), _hip.ptr(blk.shift), _hip.ptr(blk.mean), _hip.ptr(blk.invstd),
+                                       _hip.ptr(blk.mod.bn.weight.detach()) if blk.has_bn else None, blk.slope,
+                                       _hip.ptr(sf[0]) if sf else None, sf[1] if sf else 0, sf[2] if sf else 0, sf[3] if sf else 0,
+                                       _hip.ptr(sp), cout, 0, _hip.ptr(sums), _hip.ptr(dz), cop, B, h, w, cout, cout, int(blk.has_bn), st), 'y2_bn_act_bwd')
+            # parameter gradients of the affine part
+            if blk.has_bn:
+                gb = _new(dev, 2 * cout)
+                _hip.check(L.y2_f64_to_f32(_hip.ptr(sums), _hip.ptr(gb), 2 * cout, 1.0, st), 'y2_f64_to_f32')
+                ready(blk.mod.bn.bias, gb[:cout])
+                ready(blk.mod.bn.weight, gb[cout:])
+            elif blk.mod.conv.bias is not None:
+                gb = _new(dev, cout)
+                _hip.check(L.y2_f64_to_f32(_hip.ptr(sums), _hip.ptr(gb), cout, 1.0, st), 'y2_f64_to_f32')
+                ready(blk.mod.conv.bias, gb)
+            # weight gradient
+            weight = blk.mod.conv.weight
+            if blk.first:
+                x4 = torch.zeros(B, h, w, 4, dtype=torch.float32, device=dev)
+                x4[..., :cin] = ctx.x.permute(0, 2, 3, 1)          # layout conversion only (NCHW plugin input -> NHWC, 4th channel zero)
+                dwp = torch.zeros(cout * k * k * 4, dtype=torch.float32, device=dev)
+                _hip.check(L.y2_conv_wgrad(_hip.ptr(x4), _hip.ptr(dz), _hip.ptr(dwp), B, h, w, 4, 4, cout, cout, k, st), 'y2_conv_wgrad')
+                dw4 = _new(dev, cout, 4, k, k)
+                _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw4), cout, 4, k, st), 'y2_unpack_weight_grad')
+                ready(weight, dw4[:, :cin].contiguous())
+            else:
+                dwp = torch.zeros(cop * cin * k * k, dtype=torch.float32, device=dev)
+                _hip.check(L.y2_conv_wgrad(_hip.ptr(blk.x), _hip.ptr(dz), _hip.ptr(dwp), B, h, w, cin, blk.ldx, cop, cop, k, st), 'y2_conv_wgrad')
+                dw = _new(dev, cop, cin, k, k)
+                _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cop, cin, k, st), 'y2_unpack_weight_grad')
+                ready(weight, dw if cop == cout else dw[:cout].contiguous())
+                # data gradient -> the producer's gradient source
+                wsrc = _hip.f32c(weight.detach())
+                if cop != cout:
+                    wpad = torch.zeros(cop, cin, k, k, dtype=torch.float32, device=dev)
+                    wpad[:cout] = wsrc                                   # zero rows for the padded output channels
+                    wsrc = wpad
+                wd = _new(dev, wsrc.numel())
+                _hip.check(L.y2_pack_weight(_hip.ptr(wsrc), _hip.ptr(wd), cop, cin, k, 1, st), 'y2_pack_weight')
+                dx = _new(dev, B, h, w, cin)
+                _conv(L, st, dz, wd, dx, B, h, w, cop, cop, cin, k, cin)
+                # route dx
+                if blk.name == 'layers3.0':
+                    dcat = dx                                           # [B,h,w,4*c_pt + c_l2]
+                    src_full[i_pass] = (dcat, dcat.shape[-1], 0, 1)     # reorg'ed channels first
+                    src_full[idx[dnn._blocks()[1][-1][0]]] = (dcat, dcat.shape[-1], 4 * c_pt, 0)
+                elif blk.name == 'passthrough':
+                    j = n1 - 1
+                    src_full[j] = (dx, cin, 0, 0)
+                elif i == n1 + 1 and blk.name.startswith('layers2.'):   # first conv of layers2: its input is the pooled layers1[-1]
+                    src_pool[n1 - 1] = dx
+                else:
+                    prod = i - 1
+                    if blocks[prod].pool:
+                        src_pool[prod] = dx
+                    else:
+                        src_full[prod] = (dx, cin, 0, 0)
+            blk.z = None   # free as we go
+        out = [None, None]
+        for pid in ctx.param_ids:
+            out.append(grads.get(pid))
+        ctx.blocks = None
+        return tuple(out)
+
+
+# ------------------------------------------------------------------------------------------------ head
+class DecodeFn(torch.autograd.Function):
+    """model.Inference decode (model/__init__.py:122-135) with gradient to the head image."""
+
+    @staticmethod
+    def forward(ctx, feature_nhwc, anchors_dev, A):
+        L = _hip.lib()
+        f = _hip.f32c(feature_nhwc.detach())
+        B, rows, cols, ch = f.shape
+        E = ch // A
+        C = E - 5
+        cells = rows * cols
+        dev = f.device
+        iou = _new(dev, B, cells, A)
+        co, sn, mn, mx = (_new(dev, B, cells, A, 2) for _ in range(4))
+        _hip.check(L.y2_decode(_hip.ptr(f), _hip.ptr(anchors_dev), B, rows, cols, A, C, _hip.ptr(iou), _hip.ptr(co), _hip.ptr(sn), _hip.ptr(mn), _hip.ptr(mx),
+                               None, None, None, _hip.stream()), 'y2_decode')
+        logits = f.view(B, cells, A, E)[..., 5:].contiguous() if C > 0 else torch.empty(0, device=dev)
+        ctx.save_for_backward(iou, co)
+        ctx.shape = (B, rows, cols, A, C)
+        ctx.mark_non_differentiable(mn, mx)
+        return iou, co, sn, mn, mx, logits
+
+    @staticmethod
+    def backward(ctx, d_iou, d_co, d_sn, d_mn, d_mx, d_logits):
+        L = _hip.lib()
+        iou, co = ctx.saved_tensors
+        B, rows, cols, A, C = ctx.shape
+        dev = iou.device
+        df = _new(dev, B, rows, cols, A * (5 + C))
+        c = lambda t: _hip.f32c(t) if t is not None else None
+        d_iou, d_co, d_sn = c(d_iou), c(d_co), c(d_sn)
+        d_logits = c(d_logits) if (C > 0 and d_logits is not None) else None
+        _hip.check(L.y2_decode_bwd(_hip.ptr(iou), _hip.ptr(co), _hip.ptr(d_iou), _hip.ptr(d_co), _hip.ptr(d_sn), _hip.ptr(d_logits),
+                                   _hip.ptr(df), B * rows * cols * A, C, _hip.stream()), 'y2_decode_bwd')
+        return df, None, None
+
+
+def inference_forward(inference, feature):
+    """Differentiable model.Inference.forward (training): feature is the plugin's NCHW(-view) output with grad."""
+    import model
+    A = inference.anchors.size(0)
+    _feature = feature.permute(0, 2, 3, 1).contiguous()
+    anchors = model._device_anchors(inference.anchors, _feature.device)
+    iou, co, sn, mn, mx, logits = DecodeFn.apply(_feature, anchors, A)
+    return feature, iou, co, sn, mn, mx, (logits if logits.numel() else None)
+
+
+class RegionLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, iou, co, sn, logits, yx_min, yx_max, gt_min, gt_max, gt_cls, anchors_dev, rows, cols, threshold):
+        L = _hip.lib()
+        dev = iou.device
+        B, cells, A = iou.shape
+        n = cells * A
+        iou, co, sn, yx_min, yx_max = (_hip.f32c(t.detach()) for t in (iou, co, sn, yx_min, yx_max))
+        C = 0 if logits is None else logits.shape[-1]
+        lg = _hip.f32c(logits.detach()) if C else None
+        gt_min, gt_max = _hip.f32c(gt_min), _hip.f32c(gt_max)
+        N = gt_min.shape[1]
+        cls_i = cls_oh = None
+        if C:
+            if gt_cls.dim() > 2:
+                cls_oh = _hip.f32c(gt_cls)
+            else:
+                cls_i = gt_cls.to(torch.int64).contiguous()
+        best_iou = _new(dev, B, cells, A)
+        best_idx = torch.empty(B, cells, A, dtype=torch.int32, device=dev)
+        positive = torch.empty(B, cells, A, dtype=torch.uint8, device=dev)
+        sums = torch.empty(6, dtype=torch.float64, device=dev)
+        out = _new(dev, 5)
+        _hip.check(L.y2_region_loss_fwd(_hip.ptr(iou), _hip.ptr(co), _hip.ptr(sn), _hip.ptr(lg), _hip.ptr(yx_min), _hip.ptr(yx_max),
+                                        _hip.ptr(gt_min), _hip.ptr(gt_max), _hip.ptr(cls_i), _hip.ptr(cls_oh), _hip.ptr(anchors_dev),
+                                        B, rows, cols, A, C, N, float(threshold), _hip.ptr(best_iou), _hip.ptr(best_idx), _hip.ptr(positive),
+                                        _hip.ptr(sums), _hip.ptr(out), _hip.stream()), 'y2_region_loss_fwd')
+        ctx.saved = (iou, co, sn, lg, gt_min, gt_max, cls_i, cls_oh, anchors_dev, best_iou, best_idx, positive, sums)
+        ctx.geom = (B, rows, cols, A, C, N, float(threshold))
+        ctx.mark_non_differentiable(best_iou, best_idx, positive)
+        return out, best_iou, best_idx, positive
+
+    @staticmethod
+    def backward(ctx, d_out, *_):
+        L = _hip.lib()
+        iou, co, sn, lg, gt_min, gt_max, cls_i, cls_oh, anchors_dev, best_iou, best_idx, positive, sums = ctx.saved
+        B, rows, cols, A, C, N, thr = ctx.geom
+        dev = iou.device
+        w = _hip.f32c(d_out)
+        d_iou = torch.empty_like(iou)
+        d_co, d_sn = torch.empty_like(co), torch.empty_like(sn)
+        d_lg = torch.empty_like(lg) if C else None
+        _hip.check(L.y2_region_loss_bwd(_hip.ptr(iou), _hip.ptr(co), _hip.ptr(sn), _hip.ptr(lg), _hip.ptr(gt_min), _hip.ptr(gt_max),
+                                        _hip.ptr(cls_i), _hip.ptr(cls_oh), _hip.ptr(anchors_dev), B, rows, cols, A, C, N, thr,
+                                        _hip.ptr(best_iou), _hip.ptr(best_idx), _hip.ptr(positive), _hip.ptr(sums), _hip.ptr(w),
+                                        _hip.ptr(d_iou), _hip.ptr(d_co), _hip.ptr(d_sn), _hip.ptr(d_lg), _hip.stream()), 'y2_region_loss_bwd')
+        return (d_iou, d_co, d_sn, d_lg) + (None,) * 9
+
+
+def loss(anchors, data, pred, threshold):
+    """model.loss (model/__init__.py:138-167): returns (dict of 5 one-element tensors with grad, debug dict)."""
+    import model
+    iou = pred['iou']
+    _hip.require_gpu(iou)
+    rows, cols = pred['feature'].size()[-2:]
+    anchors_dev = model._device_anchors(anchors, iou.device)
+    logits = pred.get('logits')
+    dev = iou.device
+    gt_min, gt_max, gt_cls = (data[k].to(dev) for k in ('yx_min', 'yx_max', 'cls'))
+    out, best_iou, best_idx, positive = RegionLossFn.apply(iou, pred['center_offset'], pred['size_norm'], logits, pred['yx_min'], pred['yx_max'],
+                                                           gt_min, gt_max, gt_cls, anchors_dev, rows, cols, threshold)
+    result = dict(foreground=out[0:1], background=out[1:2], center=out[2:3], size=out[3:4])
+    if logits is not None:
+        result['cls'] = out[4:5]
+    positive_b = positive.bool()
+    negative = ~positive_b & (best_iou < threshold)
+    # debug dict of the reference (:167): matched data gathered per slot (plumbing for summaries, not on the hot path)
+    B = iou.shape[0]
+    flat = best_idx.view(B, -1).long()
+    _data = {}
+    for key, t in (('yx_min', gt_min), ('yx_max', gt_max), ('cls', gt_cls)):
+        if t.dim() == 2:
+            _data[key] = torch.gather(t, 1, flat).view(*best_idx.shape)
+        else:
+            _data[key] = torch.gather(t, 1, flat.unsqueeze(-1).expand(-1, -1, t.shape[-1])).view(*best_idx.shape, -1)
+    return result, dict(iou=best_iou, data=_data, positive=positive_b, negative=negative)
