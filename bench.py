@@ -86,6 +86,48 @@ def cpu_baseline(sd, anchors, size, sample):
             'sample': '%d synthetic %dx%d images in batches of 16, oracle conv stack (torch-CPU fp32, best of %d/%d/%d/%d threads) + decode + filter(fix=1) + NMS, %.1f s' % (sample, size, size, cores, cores // 2, cores // 4, cores // 8, dt)}
 
 
+def train_leg(args, dev, world, rank, barrier):
+    """BASELINE configs[2]: Darknet-19 VOC-20 training step at 416x416, per-GPU batch 64: forward (batch-stat BN) + region
+    loss + backward + SGD(lr 1e-3, momentum 0.9) (quick_start.sh:71).  N > 1: data parallel, gradients averaged with bucketed
+    RCCL all-reduce overlapped with backward (train.DataParallelRCCL), weak scaling."""
+    import train as y2train
+    from oracle import loss as oloss
+    from oracle import synth
+    inf, anchors, sd = build_model(args.classes, dev)
+    del sd
+    inf.train()
+    wrapped = y2train.ensure_model(inf)
+    opt = torch.optim.SGD(wrapped.parameters(), 1e-3, momentum=0.9)
+    B, S = args.train_batch, args.size
+    data = {k: v.to(dev) for k, v in synth.labels(B, S, args.classes, seed=2 + rank).items()}
+    data['tensor'] = synth.images(B, S, seed=11 + rank).to(dev)
+
+    def step():
+        return y2train.iterate(wrapped, opt, data, oloss.HPARAM, 0.6, anchors)
+
+    for _ in range(2):
+        r = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        r = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    flops = 87.78e9 * B * args.train_steps * world * (S / 416.0) ** 2      # SURVEY.md 8d: fwd + wgrad + dgrad (all but first conv)
+    out = {'metric': 'images/sec (416x416) train, Darknet-19 YOLOv2 VOC-20', 'value': round(B * args.train_steps * world / dt, 2), 'unit': 'images/sec',
+           'ms_per_step': round(dt / args.train_steps * 1e3, 3), 'steps': args.train_steps, 'per_gpu_batch': B, 'global_batch': B * world,
+           'parallelism': 'dp%d (RCCL all-reduce, bucketed, overlapped with backward)' % world if world > 1 else 'single GPU',
+           'optimizer': 'torch.optim.SGD(lr=1e-3, momentum=0.9)', 'loss_total': float(r['loss_total']),
+           'conv_tflops': round(flops / dt / 1e12 / world, 2), 'conv_frac_of_fp32_mfma_peak': round(flops / dt / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4)}
+    del wrapped, opt, inf
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -95,6 +137,9 @@ def main():
     ap.add_argument('--size', type=int, default=416)
     ap.add_argument('--classes', type=int, default=20)
     ap.add_argument('--mode', default='detect', choices=['detect', 'forward'])
+    ap.add_argument('--no-graph', action='store_true', help='launch the detect step eagerly instead of replaying a captured hipGraph')
+    ap.add_argument('--train-steps', type=int, default=6, help='extra leg: timed training steps (fwd + region loss + bwd + SGD), 0 = skip')
+    ap.add_argument('--train-batch', type=int, default=64, help='per-GPU batch of the training leg (BASELINE configs[2])')
     ap.add_argument('--cpu-sample', type=int, default=192, help='images for the CPU baseline (0 = skip)')
     args = ap.parse_args()
 
@@ -105,8 +150,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)   # nccl == RCCL on ROCm
+        import train as y2train
+        y2train.init_distributed()                      # backend "nccl" == RCCL on ROCm, one process per GPU
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     import detect
@@ -130,13 +175,29 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # roofline leg: eager steps with one HIP event pair around the conv chain (events cannot be queried inside a graph)
     dnn.profile = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(min(args.steps, 10)):
         step()
     barrier()
-    dt = time.perf_counter() - t0
     prof, dnn.profile = dnn.profile, None
+    graphed = None
+    if not args.no_graph and args.mode == 'detect':
+        try:
+            graphed = detect.GraphedDetector(dnn, anchors, x, fix=True, threshold_cls=0.005, overlap=0.45, limit=200)
+        except Exception as e:   # capture not possible -> eager launches
+            print('hipGraph capture failed (%s); eager launches' % e, file=sys.stderr)
+            graphed = None
+    run = (lambda: graphed.run()) if graphed is not None else step
+    for _ in range(2):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    host_dt = time.perf_counter() - t0
+    barrier()
+    dt = time.perf_counter() - t0
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -157,7 +218,11 @@ def main():
             fl0 += flops
             ms0 += d
     achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    n_prof = max(1, n_launch)   # profiled steps (one conv-chain event pair each)
 
+    train_out = None
+    if args.train_steps > 0:
+        train_out = train_leg(args, dev, world, rank, barrier)
     traffic = None
     try:   # HBM-side bytes per step of the same kernel family from the committed rocprofv3 PMC passes (separate runs)
         import glob
@@ -172,7 +237,7 @@ def main():
             'metric': 'images/sec (416x416) detect, Darknet-19 YOLOv2',
             'value': round(images / dt, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32', 'data': 'synthetic', 'launch': 'hipGraph replay' if graphed is not None else 'eager', 'host_ms_per_step': round(host_dt / args.steps * 1e3, 4),
             'config': {'workload': 'Darknet-19 YOLOv2 %dx%d batch-%d/GPU inference: conv stack + decode + filter + NMS (BASELINE configs[1])'
                                    % (args.size, args.size, args.batch) if args.mode == 'detect' else
                                    'Darknet-19 YOLOv2 %dx%d batch-%d/GPU conv stack only' % (args.size, args.size, args.batch),
@@ -181,10 +246,12 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'conv_fwd_dma_kernel family (fp32 MFMA implicit GEMM; 22 launches per step timed as one event pair, inter-launch gaps included)',
                          'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         'flops_per_step': fl / max(args.steps, 1), 'ms_per_step': round(ms / max(args.steps, 1), 4),
-                         'conv0_ms_per_step': round(ms0 / max(args.steps, 1), 4), 'traffic': traffic,
+                         'flops_per_step': fl / n_prof, 'ms_per_step': round(ms / n_prof, 4),
+                         'conv0_ms_per_step': round(ms0 / n_prof, 4), 'traffic': traffic,
                          'traffic_note': 'bytes per step (22 launches) from rocprofv3 PMC FETCH_SIZE(x2, gfx950 correction)+WRITE_SIZE, profiles/; L2 memory-side requests incl. Infinity-Cache hits'},
         }
+        if train_out is not None:
+            out['train'] = train_out
         if world == 1 and args.cpu_sample > 0:
             out['cpu_baseline'] = cpu_baseline(sd, anchors, args.size, args.cpu_sample)
         print(json.dumps(out))

@@ -205,6 +205,10 @@ int y2_region_loss_fwd(const float* iou, const float* center_offset, const float
                        const float* anchors, int B, int rows, int cols, int A, int C, int N, float threshold,
                        float* best_iou, int32_t* best_idx, uint8_t* positive, double* sums, float* loss_out, y2_stream_t stream);
 
+/* Data-parallel training: after sums[5] (number of positives) has been summed over ranks, recompute loss_out so that
+ * the mean-over-positives of the cls term uses the GLOBAL count (cnt stays the local B*cells*A). */
+int y2_region_loss_finalize(const double* sums, double cnt, int cross_entropy, float* loss_out, y2_stream_t stream);
+
 /* Gradients of sum_k weights[k]*loss[k] (train.py:348-349) w.r.t. iou, center_offset, size_norm, logits. */
 int y2_region_loss_bwd(const float* iou, const float* center_offset, const float* size_norm, const float* logits,
                        const float* gt_yx_min, const float* gt_yx_max, const int64_t* gt_cls, const float* gt_onehot,

@@ -1,0 +1,111 @@
+"""Data-parallel wrapper (train.ensure_model / DataParallelRCCL) on CPU with the gloo backend, world_size 2:
+averaged gradients must equal single-process gradients on the concatenated batch, for both the late path
+(post-accumulate hooks) and the early path (a module announcing gradients from inside its backward, like the
+Darknet training graph does layer by layer)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from conftest import APP, ROOT
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class EarlyLinear(nn.Module):
+    """A layer whose backward announces its parameter gradients through grad_ready_hook (the Darknet protocol)."""
+
+    def __init__(self, i, o):
+        nn.Module.__init__(self)
+        self.weight = nn.Parameter(torch.randn(o, i) * 0.3)
+        self.bias = nn.Parameter(torch.zeros(o))
+        self.grad_ready_hook = None
+
+    def forward(self, x):
+        mod = self
+
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w, b):
+                ctx.save_for_backward(x, w)
+                return x @ w.t() + b
+
+            @staticmethod
+            def backward(ctx, g):
+                x, w = ctx.saved_tensors
+                gw, gb = g.t() @ x, g.sum(0)
+                if mod.grad_ready_hook is not None:
+                    mod.grad_ready_hook(mod.bias, gb)
+                    mod.grad_ready_hook(mod.weight, gw)
+                return g @ w, gw, gb
+        return Fn.apply(x, self.weight, self.bias)
+
+
+def make_model():
+    torch.manual_seed(0)
+    return nn.Sequential(nn.Linear(6, 16), nn.Tanh(), EarlyLinear(16, 12), nn.Tanh(), nn.Linear(12, 3))
+
+
+def worker(rank, world, port, tmp):
+    for p in (ROOT, APP):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import train
+    assert train.init_distributed() == world
+    torch.manual_seed(100 + rank)          # different initial weights per rank: the wrapper must broadcast rank 0's
+    m = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), EarlyLinear(16, 12), nn.Tanh(), nn.Linear(12, 3))
+    ref = make_model()
+    if rank == 0:
+        m.load_state_dict(ref.state_dict())
+    dp = train.DataParallelRCCL(m, bucket_bytes=256)   # tiny buckets: several all-reduces per step
+    for a, b in zip(m.parameters(), ref.parameters()):
+        assert torch.equal(a, b)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 6, generator=g)
+    y = torch.randn(8, 3, generator=g)
+    shard = slice(rank * 4, rank * 4 + 4)
+    for step in range(2):                  # twice: state must reset between steps
+        for p in dp.parameters():
+            p.grad = None
+        ((dp(x[shard]) - y[shard]) ** 2).mean().backward()
+        for p in ref.parameters():
+            p.grad = None
+        ((ref(x) - y) ** 2).mean().backward()
+        for (n, a), b in zip(m.named_parameters(), ref.parameters()):
+            assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6), (n, step)
+    if rank == 0:
+        open(os.path.join(tmp, 'ok'), 'w').write('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_dp_wrapper_gloo_world2(tmp_path):
+    port = free_port()
+    mp.spawn(worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / 'ok').exists()
+
+
+def test_ensure_model_single_process_is_identity():
+    import train
+    m = nn.Linear(2, 2)
+    assert train.ensure_model(m) is m or not torch.cuda.is_available()
+
+
+def test_norm_data():
+    import train
+    d = dict(yx_min=torch.tensor([[[104.0, 208.0]]]), yx_max=torch.tensor([[[416.0, 416.0]]]), cls=torch.tensor([[3]]))
+    n = train.norm_data(d, 416, 416, 13, 13)
+    assert n['yx_min'].tolist() == [[[3.25, 6.5]]] and n['yx_max'].tolist() == [[[13.0, 13.0]]] and n['cls'] is d['cls']

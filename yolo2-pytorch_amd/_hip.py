@@ -53,6 +53,7 @@ SIGNATURES = {
     'y2_f64_to_f32': [c_void_p, c_void_p, c_int, ctypes.c_double, c_void_p],
     'y2_decode_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     'y2_region_loss_fwd': [c_void_p] * 11 + [c_int] * 6 + [c_float] + [c_void_p] * 5 + [c_void_p],
+    'y2_region_loss_finalize': [c_void_p, ctypes.c_double, c_int, c_void_p, c_void_p],
     'y2_region_loss_bwd': [c_void_p] * 9 + [c_int] * 6 + [c_float] + [c_void_p] * 5 + [c_void_p] * 4 + [c_void_p],
     'y2_nms': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
 }

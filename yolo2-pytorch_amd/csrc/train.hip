@@ -610,3 +610,11 @@ extern "C" int y2_region_loss_bwd(const float* iou, const float* center_offset, 
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
+
+// Re-run the finalisation after the number of positives (sums[5]) has been all-reduced across data-parallel ranks.
+extern "C" int y2_region_loss_finalize(const double* sums, double cnt, int cross_entropy, float* loss_out, y2_stream_t stream) {
+    if (!sums || !loss_out || cnt <= 0) return Y2_EINVAL;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, y2_s(stream), sums, cnt, cross_entropy, loss_out);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}

@@ -19,8 +19,11 @@ import ctypes
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 import _hip
+
+SYNC_POSITIVES = True   # data parallel: all-reduce the positive count so the cls mean is over the global batch
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.01
@@ -329,6 +332,10 @@ class RegionLossFn(torch.autograd.Function):
                                         _hip.ptr(gt_min), _hip.ptr(gt_max), _hip.ptr(cls_i), _hip.ptr(cls_oh), _hip.ptr(anchors_dev),
                                         B, rows, cols, A, C, N, float(threshold), _hip.ptr(best_iou), _hip.ptr(best_idx), _hip.ptr(positive),
                                         _hip.ptr(sums), _hip.ptr(out), _hip.stream()), 'y2_region_loss_fwd')
+        if SYNC_POSITIVES and cls_i is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # exact data-parallel parity of the cls term (mean over positives, model/__init__.py:162): global positive count
+            dist.all_reduce(sums[5:6], op=dist.ReduceOp.SUM)
+            _hip.check(L.y2_region_loss_finalize(_hip.ptr(sums), float(B * n), 1, _hip.ptr(out), _hip.stream()), 'y2_region_loss_finalize')
         ctx.saved = (iou, co, sn, lg, gt_min, gt_max, cls_i, cls_oh, anchors_dev, best_iou, best_idx, positive, sums)
         ctx.geom = (B, rows, cols, A, C, N, float(threshold))
         ctx.mark_non_differentiable(best_iou, best_idx, positive)

@@ -101,6 +101,7 @@ class Darknet(nn.Module):
         self.init()
         self._cache = None  # packed weights / folded BN for eval, keyed on parameter versions
         self._plan_cache = None
+        self.grad_ready_hook = None  # set by train.DataParallelRCCL: called as hook(param, grad) inside backward, layer by layer
         self.profile = None  # bench.py: list receiving (kernel, flops, start_event, end_event) per conv launch
 
     def init(self):
@@ -341,6 +342,7 @@ class Darknet(nn.Module):
         self.init()
         self._cache = None  # packed weights / folded BN for eval, keyed on parameter versions
         self._plan_cache = None
+        self.grad_ready_hook = None  # set by train.DataParallelRCCL: called as hook(param, grad) inside backward, layer by layer
         self.profile = None  # bench.py: list receiving (kernel, flops, start_event, end_event) per conv launch
 
     def init(self):

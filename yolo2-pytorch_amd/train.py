@@ -1,0 +1,180 @@
+"""`train` — the data-parallel wrapper and step helpers of the reference's train.py, MI355X-native.
+
+Reference: `ensure_model` (train.py:65-71) wraps the Inference module in single-process `nn.DataParallel`: every step
+it re-broadcasts 202.6 MB of parameters from GPU0, scatters the batch, gathers outputs to GPU0 and reduce-adds all
+gradients into GPU0.  Here: one process per GPU (launched by `python -m torch.distributed.run`), each rank owns a full
+replica and a per-GPU batch (`-b` per GPU, global batch = b x N exactly like train.py:309), gradients are averaged with
+bucketed RCCL all-reduces over xGMI that start INSIDE backward as soon as a bucket's layers have produced their weight
+gradients (the Darknet backward calls `grad_ready_hook` per layer), BatchNorm statistics stay per replica (as in
+nn.DataParallel) and rank 0's running statistics are the ones a checkpoint sees.  No parameter broadcast per step, no
+output gather.  The cls term's mean over positives uses the GLOBAL positive count (one scalar all-reduce) so that the
+averaged gradient equals the single-process gradient on the concatenated batch.
+
+Only the hot-path pieces of train.py are mirrored (`norm_data` :57-62, `ensure_model` :65-71, the body of
+`Train.iterate` :338-362 as `iterate`); the dataset / TensorBoard / checkpoint harness is out of scope.
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+import model
+import utils
+
+BUCKET_BYTES = 25 * 1024 * 1024
+
+
+def norm_data(data, height, width, rows, cols, keys='yx_min, yx_max'):
+    """train.py:57-62: ground-truth boxes from pixels to grid-cell units."""
+    _data = {key: data[key] for key in data}
+    t = _data[keys.split(', ')[0]]
+    scale = torch.tensor([rows / height, cols / width], dtype=torch.float32, device=t.device).view(1, 1, 2)
+    for key in keys.split(', '):
+        _data[key] = _data[key] * scale
+    return _data
+
+
+class DataParallelRCCL(nn.Module):
+    """Gradient-averaging data parallelism over torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" on CPU)."""
+
+    def __init__(self, module, process_group=None, bucket_bytes=BUCKET_BYTES):
+        nn.Module.__init__(self)
+        self.module = module
+        self.pg = process_group
+        self.world = dist.get_world_size(self.pg)
+        self.bucket_bytes = bucket_bytes
+        # identical replicas: rank 0's parameters and buffers win (the reference broadcasts GPU0's every step)
+        with torch.no_grad():
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t, 0, group=self.pg)
+        self._build_buckets()
+        self._pending = False
+        for p in self._params:
+            p.register_post_accumulate_grad_hook(self._late_hook)
+        # modules whose backward produces gradients layer by layer announce them early (overlap with compute)
+        for m in module.modules():
+            if hasattr(m, 'grad_ready_hook'):
+                m.grad_ready_hook = self._early_hook
+
+    # ---- bucketing: reverse registration order ~ the order in which backward produces gradients
+    def _build_buckets(self):
+        self._params = [p for p in self.module.parameters() if p.requires_grad]
+        self._where = {}
+        self._buckets = []
+        cur, size = [], 0
+        for p in reversed(self._params):
+            cur.append(p)
+            size += p.numel() * p.element_size()
+            if size >= self.bucket_bytes:
+                self._buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self._buckets.append(cur)
+        self._flat = []
+        for bi, bucket in enumerate(self._buckets):
+            off = 0
+            for p in bucket:
+                self._where[id(p)] = (bi, off)
+                off += p.numel()
+            self._flat.append(torch.zeros(off, dtype=bucket[0].dtype, device=bucket[0].device))
+        self._reset()
+
+    def _reset(self):
+        self._ready = [0] * len(self._buckets)
+        self._done = set()
+        self._works = [None] * len(self._buckets)
+
+    def _start(self):
+        if not self._pending:
+            self._pending = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+
+    def _fill(self, p, g):
+        bi, off = self._where[id(p)]
+        if self._flat[bi].device != g.device:
+            self._flat[bi] = self._flat[bi].to(g.device)
+        self._flat[bi][off:off + p.numel()].copy_(g.reshape(-1))
+        self._done.add(id(p))
+        self._ready[bi] += 1
+        if self._ready[bi] == len(self._buckets[bi]):
+            self._works[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _early_hook(self, p, g):
+        """Called from inside a module's backward with the finished gradient of parameter p."""
+        if id(p) not in self._where or id(p) in self._done:
+            return
+        self._start()
+        self._fill(p, g)
+
+    def _late_hook(self, p):
+        if id(p) in self._done:
+            return
+        self._start()
+        self._fill(p, p.grad)
+
+    def _finalize(self):
+        inv = 1.0 / self.world
+        for bi, bucket in enumerate(self._buckets):
+            if self._works[bi] is None:   # bucket with parameters that got no gradient this step
+                if self._ready[bi] == 0:
+                    continue
+                for p in bucket:
+                    if id(p) not in self._done:
+                        bo, off = self._where[id(p)]
+                        self._flat[bi][off:off + p.numel()].zero_()
+                self._works[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._works[bi].wait()
+            flat = self._flat[bi]
+            flat.mul_(inv)
+            for p in bucket:
+                bo, off = self._where[id(p)]
+                if p.grad is not None:
+                    p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+        self._pending = False
+        self._reset()
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
+def init_distributed():
+    """One process per GPU: reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set by torch.distributed.run."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if torch.cuda.is_available():
+            local = int(os.environ.get('LOCAL_RANK', '0'))
+            torch.cuda.set_device(local)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group('gloo')
+    return world
+
+
+def ensure_model(model_):
+    """train.py:65-71: move to the GPU and wrap for multi-GPU training (callable like the module, .parameters(), .train())."""
+    if torch.cuda.is_available():
+        model_.cuda()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        logging.info('%d GPUs are used' % dist.get_world_size())
+        model_ = DataParallelRCCL(model_)
+    return model_
+
+
+def iterate(inference, optimizer, data, loss_hparam, threshold, anchors, clip=None):
+    """Body of Train.iterate (train.py:338-362): forward, region loss, weighted sum, backward, optional clip, step."""
+    tensor = data['tensor']
+    pred = model._inference(inference, tensor)
+    height, width = tensor.size()[-2:]
+    rows, cols = pred['feature'].size()[-2:]
+    loss, debug = model.loss(anchors, norm_data(data, height, width, rows, cols), pred, threshold)
+    loss_total = sum(loss[key] * loss_hparam[key] for key in loss)
+    optimizer.zero_grad()
+    loss_total.backward()
+    if clip is not None:
+        nn.utils.clip_grad_norm_(inference.parameters(), clip)
+    optimizer.step()
+    return dict(pred=pred, loss=loss, loss_total=loss_total, debug=debug)
