@@ -34,6 +34,11 @@ extern "C" {
 #define Y2_EALIGN (-2)    /* pointer or stride not aligned as required */
 #define Y2_ENOSUP (-3)    /* combination not supported by this build */
 
+/* Training-mode BN statistics are accumulated with fp64 atomics into Y2_STATS_REPL replicated copies of the
+ * [sum | sum of squares] vector (copy = tile index mod Y2_STATS_REPL) to keep atomic contention off the critical
+ * path; y2_bn_finalize adds the copies.  A stats buffer therefore holds Y2_STATS_REPL * 2 * C doubles. */
+#define Y2_STATS_REPL 32
+
 typedef void* y2_stream_t; /* hipStream_t */
 
 /* Library/ABI version (bump when a signature changes) and the gfx target it was compiled for. */
@@ -70,8 +75,8 @@ typedef struct y2_conv_params {
     const float* shift;  /* [Cout] or NULL (= 0); conv bias goes here */
     float* y;            /* full-resolution output or NULL */
     float* y_pool;       /* 2x2/stride-2 max-pooled output or NULL (needs even H and W) */
-    double* stats;       /* NULL, or [2*Cout] doubles (pre-zeroed): sum and sum of squares of the RAW conv
-                            output per channel are atomically accumulated (training-mode BN statistics) */
+    double* stats;       /* NULL, or [Y2_STATS_REPL][2*Cout] doubles (pre-zeroed): sum and sum of squares of the RAW
+                            conv output per channel are atomically accumulated (training-mode BN statistics) */
     int32_t B, H, W;     /* input = output spatial size (stride 1, same padding) */
     int32_t Cin, ldx;
     int32_t Cout;
@@ -161,8 +166,12 @@ int y2_nms(const float* score, const float* yx_min, const float* yx_max, const i
 int y2_conv_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int ldx, int Cout, int ldz,
                   int ksize, y2_stream_t stream);
 
-/* Training-mode nn.BatchNorm2d(momentum 0.01, eps 1e-5) statistics (model/yolo2.py:58): stats = [sum z | sum z^2] per
- * channel (fp64, accumulated by y2_conv_fwd / y2_conv0_fwd), count = B*H*W.  Writes the affine (scale, shift) used for
+/* Weight gradient of the first layer (model/yolo2.py:78): x is the plugin's NCHW input [B,Cin<=3,H,W], dz NHWC with pixel
+ * stride ldz, Cout <= 64.  dw is the state_dict layout [Cout][Cin][3][3], pre-zeroed (partials are added atomically). */
+int y2_conv0_wgrad(const float* x_nchw, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, int ldz, y2_stream_t stream);
+
+/* Training-mode nn.BatchNorm2d(momentum 0.01, eps 1e-5) statistics (model/yolo2.py:58): stats = Y2_STATS_REPL copies of
+ * [sum z | sum z^2] per channel (fp64, accumulated by y2_conv_fwd / y2_conv0_fwd), count = B*H*W.  Writes the affine (scale, shift) used for
  * normalisation (biased variance), saves mean / invstd for backward and updates the running statistics in place
  * (unbiased variance) when running_mean != NULL. */
 int y2_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,

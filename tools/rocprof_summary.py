@@ -46,8 +46,26 @@ def pmc(paths):
             print('%-90s %-28s dispatches=%4d mean_per_dispatch=%.6g mean_us=%.1f' % (k[:90], c, n, sum(v for v, _ in vals) / n, sum(u for _, u in vals) / n))
 
 
+def listing(path, start_frac=0.0, count=400):
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    t = tables(cur)
+    kd = [x for x in t if x.startswith('rocpd_kernel_dispatch')][0]
+    ks = [x for x in t if x.startswith('rocpd_info_kernel_symbol')][0]
+    rows = list(cur.execute(f"select s.kernel_name, d.start, d.end, d.grid_size_x, d.grid_size_y, d.workgroup_size_x from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
+    i0 = int(len(rows) * start_frac)
+    prev_end = None
+    for name, st, en, gx, gy, wx in rows[i0:i0 + count]:
+        gap = (st - prev_end) / 1e3 if prev_end else 0.0
+        prev_end = en
+        short = name.replace('_ZN12_GLOBAL__N_1', '').replace('.kd', '')[:60]
+        print('%-62s wgs=%7d dur=%9.1fus gap=%7.1fus' % (short, gx // max(wx, 1) * max(gy, 1), (en - st) / 1e3, gap))
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'stats':
+    if sys.argv[1] == 'list':
+        listing(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.0, int(sys.argv[4]) if len(sys.argv) > 4 else 400)
+    elif sys.argv[1] == 'stats':
         stats(sys.argv[2])
     else:
         pmc(sys.argv[2:])

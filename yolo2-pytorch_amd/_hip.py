@@ -45,6 +45,7 @@ SIGNATURES = {
     'y2_iou_matrix': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     'y2_iou_pair': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p],
     'y2_conv_wgrad': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'y2_conv0_wgrad': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'y2_bn_finalize': [c_void_p, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     'y2_bn_act_fwd': [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'y2_bn_act_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
@@ -57,6 +58,8 @@ SIGNATURES = {
     'y2_region_loss_bwd': [c_void_p] * 9 + [c_int] * 6 + [c_float] + [c_void_p] * 5 + [c_void_p] * 4 + [c_void_p],
     'y2_nms': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
 }
+
+STATS_REPL = 32   # Y2_STATS_REPL (include/yolo2_hip.h)
 
 ERRORS = {-1: 'Y2_EINVAL (bad size / null pointer)', -2: 'Y2_EALIGN (unaligned pointer or stride)', -3: 'Y2_ENOSUP (unsupported combination)'}
 

@@ -145,8 +145,9 @@ __global__ __launch_bounds__(256) void conv0_kernel(const Conv0Args a) {
             float t1 = s1[j] + __shfl_xor(s1[j], 32);
             float t2 = s2[j] + __shfl_xor(s2[j], 32);
             if (half == 0 && n < a.Cout) {
-                atomicAdd(a.stats + n, (double)t1);
-                atomicAdd(a.stats + a.Cout + n, (double)t2);
+                double* st = a.stats + (size_t)(blockIdx.x % Y2_STATS_REPL) * 2 * a.Cout;   // replicated accumulators
+                atomicAdd(st + n, (double)t1);
+                atomicAdd(st + a.Cout + n, (double)t2);
             }
         }
     }

@@ -134,8 +134,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
             s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 32);
             if (half == 0 && nok) {
-                atomicAdd(a.stats + n, (double)s1);
-                atomicAdd(a.stats + a.Cout + n, (double)s2);
+                double* st = a.stats + (size_t)((m0 >> 6) % Y2_STATS_REPL) * 2 * a.Cout;   // replicated accumulators: see Y2_STATS_REPL
+                atomicAdd(st + n, (double)s1);
+                atomicAdd(st + a.Cout + n, (double)s2);
             }
         }
     }
@@ -500,6 +501,7 @@ int dispatch_dma(const ConvArgs& a, int tile, hipStream_t s) {
         case 2: return launch_dma<128, 64, 2, POOLORD>(a, s);
         case 3: return launch_dma<64, 64, 2, POOLORD>(a, s);
         case 5: return launch_dma<64, 128, 2, POOLORD>(a, s);
+        case 6: return launch_dma<128, 32, 4, POOLORD>(a, s);   // narrow outputs (Cout <= 32: dgrad into the first layers)
         default: return Y2_ENOSUP;
     }
 }
@@ -528,7 +530,7 @@ int dispatch_tile(const ConvArgs& a, int tile, hipStream_t s) {
 // every CU is saturated by its resident workgroups, so the makespan is quantised in whole tiles per CU.
 int choose_tile(long long M, int Cout) {
     struct Cand { int id, bm, bn; double eff; };
-    const Cand cands[] = {{5, 64, 128, 0.80}, {3, 64, 64, 0.78}, {2, 128, 64, 0.775}, {1, 128, 128, 0.74}};
+    const Cand cands[] = {{5, 64, 128, 0.80}, {3, 64, 64, 0.78}, {2, 128, 64, 0.775}, {1, 128, 128, 0.74}, {6, 128, 32, 0.60}};
     int best = 3;
     double best_cost = 1e300;
     for (const Cand& c : cands) {
@@ -582,7 +584,7 @@ extern "C" int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream) {
     // tile ids 1,2,3,5: LDS-DMA kernel when the operands allow it; 101.. force the register-staged kernel (also the
     // path for channel counts / strides that are not multiples of 4, e.g. pruned checkpoints)
     const unsigned long long xb = (unsigned long long)M * p->ldx * 4ull, wb = (unsigned long long)p->Cout * a.taps * p->Cin * 4ull;
-    const bool dma_ok = vec && xb < 0x7fffffffull && wb < 0x7fffffffull && (tile == 1 || tile == 2 || tile == 3 || tile == 5);
+    const bool dma_ok = vec && xb < 0x7fffffffull && wb < 0x7fffffffull && (tile == 1 || tile == 2 || tile == 3 || tile == 5 || tile == 6);
     if (dma_ok) {
         a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
         return pool ? dispatch_dma<true>(a, tile, s) : dispatch_dma<false>(a, tile, s);

@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int TI = 128, TJ = 128, KS = 32;   // tile rows (co), tile cols (tap,ci), pixels per slab
+constexpr int TJ = 128, KS = 32;   // tile cols (tap,ci), pixels per slab; tile rows TI (co) is a template parameter
 
 struct WgradArgs {
     const float* x;     // [B,H,W,Cin] pixel stride ldx
@@ -31,16 +31,23 @@ struct WgradArgs {
     unsigned x_bytes, dz_bytes;
 };
 
+template <int TI, int WAVES_I>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr unsigned OOB = 0x80000000u;
-    constexpr int STAGE = 2 * KS * 128;   // floats per stage: A [32][128] then B [32][128]
+    constexpr int WAVES_J = 4 / WAVES_I;
+    constexpr int WI = TI / WAVES_I, WJ = TJ / WAVES_J;
+    constexpr int IB = WI / 32, JB = WJ / 32;          // 32x32 MFMA blocks per wave
+    constexpr int CA = TI / 4;                          // 16-B chunks per A row
+    constexpr int RA = NT / CA;                         // A rows per DMA pass
+    constexpr int PA = KS / RA;                         // A passes per slab
+    constexpr int STAGE = KS * TI + KS * TJ;            // floats per stage: A [32][TI] then B [32][128]
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_J, wn = wave % WAVES_J;
     const int l31 = lane & 31, half = lane >> 5;
 
     int bid = blockIdx.x;
@@ -56,11 +63,13 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     const int nk = slab_hi - slab_lo;
     if (nk <= 0) return;
 
-    // ---- DMA assignment: lane -> 16-B chunk (t&31) of pixel row (t>>5) + 8*p, p = 0..3
+    // ---- DMA assignment.  B: lane -> 16-B chunk (t&31) of pixel row (t>>5) + 8*p, p = 0..3.  A: chunk t % CA of row t / CA + RA*p
     const int chunk = t & 31;
     const int prow = t >> 5;
-    // A (dz): column i0 + 4*chunk
-    const int ca = i0 + 4 * chunk;
+    const int chunk_a = t % CA;
+    const int prow_a = t / CA;
+    // A (dz): column i0 + 4*chunk_a
+    const int ca = i0 + 4 * chunk_a;
     const bool a_ok = ca < a.Cout;
     // B (x): column j = j0 + 4*chunk -> (tap, ci), fixed for the whole kernel
     const int jb = j0 + 4 * chunk;
@@ -83,14 +92,18 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz), 0, a.dz_bytes, 0x00020000);
 
     auto issue_slab = [&](int slab, int buf) {
-        float* sa = smem + buf * STAGE + wave * 256;          // wave covers 2 rows x 128 floats = 256 floats per pass
-        float* sb = sa + KS * 128;
+        float* sa = smem + buf * STAGE + wave * 256;          // every DMA instruction of a wave fills 256 contiguous floats
+        float* sb = smem + buf * STAGE + KS * TI + wave * 256;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int m = slab * KS + prow_a + RA * p;
+            const unsigned va = (m < a.M && a_ok) ? (unsigned)(((size_t)m * a.ldz + ca) * 4) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (lds_ptr_t)(sa + p * RA * TI), 16, (int)va, 0, 0, 0);
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int m = slab * KS + prow + 8 * p;
             const bool mok = m < a.M;
-            const unsigned va = (mok && a_ok) ? (unsigned)(((size_t)m * a.ldz + ca) * 4) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (lds_ptr_t)(sa + p * 8 * 128), 16, (int)va, 0, 0, 0);
             const bool in = (unsigned)(py[p] + dy) < (unsigned)a.H && (unsigned)(px[p] + dx) < (unsigned)a.W;
             const unsigned vb = (mok && b_ok && in) ? (unsigned)(((size_t)(m + dy * a.W + dx) * a.ldx + ci) * 4) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sb + p * 8 * 128), 16, (int)vb, 0, 0, 0);
@@ -104,30 +117,30 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[IB][JB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < IB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < JB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int fa = wm * 64 + l31 + half * 128;            // + (2s)*128 + 32*block
-    const int fb = KS * 128 + wn * 64 + l31 + half * 128;
+    const int fa = wm * WI + l31 + half * TI;              // + (2s)*TI + 32*block
+    const int fb = KS * TI + wn * WJ + l31 + half * 128;   // + (2s)*128 + 32*block
 
     auto compute_slab = [&](int buf) {
         const float* sbuf = smem + buf * STAGE;
 #pragma unroll
         for (int s = 0; s < KS / 2; ++s) {
-            float av[2], bv[2];
+            float av[IB], bv[JB];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = sbuf[fa + s * 256 + 32 * i];
+            for (int i = 0; i < IB; ++i) av[i] = sbuf[fa + s * 2 * TI + 32 * i];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bv[j] = sbuf[fb + s * 256 + 32 * j];
+            for (int j = 0; j < JB; ++j) bv[j] = sbuf[fb + s * 256 + 32 * j];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < IB; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < JB; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
     };
@@ -145,14 +158,14 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 
     // ---- epilogue: lane -> column j (l31), register r -> row co = (r&3) + 8*(r>>2) + 4*half
 #pragma unroll
-    for (int jbk = 0; jbk < 2; ++jbk) {
-        const int j = j0 + wn * 64 + jbk * 32 + l31;
+    for (int jbk = 0; jbk < JB; ++jbk) {
+        const int j = j0 + wn * WJ + jbk * 32 + l31;
         if (j >= ncols) continue;
 #pragma unroll
-        for (int ib = 0; ib < 2; ++ib) {
+        for (int ib = 0; ib < IB; ++ib) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = i0 + wm * 64 + ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int co = i0 + wm * WI + ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (co < a.Cout) {
                     float* dst = a.dw + (size_t)co * ncols + j;
                     if (a.splits > 1) atomicAdd(dst, acc[ib][jbk][r]);
@@ -180,6 +193,7 @@ extern "C" int y2_conv_wgrad(const float* x, const float* dz, float* dw, int B, 
     a.x = x; a.dz = dz; a.dw = dw;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.Cout = Cout; a.ldz = ldz; a.taps = ksize * ksize;
     a.M = (int)M;
+    const int TI = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
     a.tiles_i = y2_cdiv(Cout, TI);
     a.tiles_j = y2_cdiv(a.taps * Cin, TJ);
     const int tiles = a.tiles_i * a.tiles_j;
@@ -192,16 +206,112 @@ extern "C" int y2_conv_wgrad(const float* x, const float* dz, float* dw, int B, 
     a.slabs_per_split = y2_cdiv(slabs, splits);
     a.splits = y2_cdiv(slabs, a.slabs_per_split);
     a.x_bytes = (unsigned)xb; a.dz_bytes = (unsigned)zb;
-    const size_t lds = 2u * 2u * KS * 128 * sizeof(float);   // 64 KB
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return -(1000 + (int)e);
-        attr = true;
-    }
     const long long grid = (long long)tiles * a.splits;
     if (grid > 0x7fffffffLL) return Y2_EINVAL;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)grid), dim3(NT), lds, y2_s(stream), a);
+    hipStream_t s = y2_s(stream);
+    const size_t lds = 2u * (size_t)(KS * TI + KS * TJ) * sizeof(float);
+#define Y2_WGRAD_LAUNCH(TI_, WI_)                                                                                         \
+    do {                                                                                                                  \
+        static bool attr = false;                                                                                         \
+        if (!attr) {                                                                                                      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<TI_, WI_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return -(1000 + (int)e);                                                                 \
+            attr = true;                                                                                                  \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((conv_wgrad_kernel<TI_, WI_>), dim3((unsigned)grid), dim3(NT), lds, s, a);                      \
+    } while (0)
+    if (TI == 32) Y2_WGRAD_LAUNCH(32, 1);
+    else if (TI == 64) Y2_WGRAD_LAUNCH(64, 1);
+    else Y2_WGRAD_LAUNCH(128, 2);
+#undef Y2_WGRAD_LAUNCH
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ first layer
+// Weight gradient of 'layers1.0' (model/yolo2.py:78): x is the plugin's NCHW input (Cin <= 3), dz NHWC [B,H,W,Cout<=64].
+// dW[co][c][ky][kx] = sum_pixels dz[pix][co] * x[c][y+ky-1][x+kx-1]: a 32(64) x 27 output with an 11-million-long
+// reduction — one 32x32 MFMA block per 32 output channels, no LDS staging: lane (co = l&31, parity = l>>5) reads
+// dz[pix][co] (128 B contiguous per pixel), lane (tap j = l&31) gathers its shifted input pixel (L1/L2 resident);
+// each wave walks image rows, the 4 waves of a workgroup are reduced through LDS and added atomically to dW (which is
+// in the state_dict layout already: column j = (c*3 + ky)*3 + kx).
+namespace {
+
+struct W0Args {
+    const float* x; const float* dz; float* dw;
+    int B, H, W, Cin, Cout, ldz, rows_total;
+};
+
+template <int IB>
+__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const W0Args a) {
+    __shared__ float red[4][IB * 32 * 33];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int K = a.Cin * 9;
+    const bool jok = l31 < K;
+    const int c = jok ? l31 / 9 : 0;
+    const int ky = jok ? (l31 % 9) / 3 : 0, kx = jok ? l31 % 3 : 0;
+    f32x16 acc[IB];
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    for (int row = wid; row < a.rows_total; row += nw) {          // row = b*H + y
+        const int b = row / a.H, y = row - b * a.H;
+        const int yy = y + ky - 1;
+        const bool yok = jok && (unsigned)yy < (unsigned)a.H;
+        const float* xr = a.x + (((size_t)b * a.Cin + c) * a.H + (yok ? yy : 0)) * a.W;
+        const float* zr = a.dz + (size_t)row * a.W * a.ldz;
+        for (int x0 = 0; x0 < a.W; x0 += 16) {                   // 8 MFMA steps (16 pixels) per batch of loads
+            float av[IB][8], bv[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int px = x0 + 2 * s + half;
+                const bool pok = px < a.W;
+#pragma unroll
+                for (int i = 0; i < IB; ++i) {
+                    const int co = i * 32 + l31;
+                    av[i][s] = (pok && co < a.Cout) ? zr[(size_t)px * a.ldz + co] : 0.f;
+                }
+                const int xx = px + kx - 1;
+                bv[s] = (pok && yok && (unsigned)xx < (unsigned)a.W) ? xr[xx] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int i = 0; i < IB; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[s], acc[i], 0, 0, 0);
+        }
+    }
+    // ---- reduce the 4 waves through LDS, then one atomic per output element per workgroup
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[wave][co * 33 + l31] = acc[i][r];
+        }
+    __syncthreads();
+    for (int e = t; e < IB * 32 * 32; e += 256) {
+        const int co = e >> 5, j = e & 31;
+        if (co < a.Cout && j < K) {
+            const float v = red[0][co * 33 + j] + red[1][co * 33 + j] + red[2][co * 33 + j] + red[3][co * 33 + j];
+            atomicAdd(a.dw + (size_t)co * K + j, v);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int y2_conv0_wgrad(const float* x_nchw, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, int ldz, y2_stream_t stream) {
+    if (!x_nchw || !dz || !dw || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || ldz < Cout) return Y2_EINVAL;
+    if (Cin < 1 || Cin > 3 || Cout > 64) return Y2_ENOSUP;
+    W0Args a;
+    a.x = x_nchw; a.dz = dz; a.dw = dw; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldz = ldz; a.rows_total = B * H;
+    const int grid = a.rows_total < 4 * 4 * Y2_NUM_CU ? y2_cdiv(a.rows_total, 4) : 4 * Y2_NUM_CU;
+    if (Cout <= 32) hipLaunchKernelGGL((conv0_wgrad_kernel<1>), dim3(grid), dim3(256), 0, y2_s(stream), a);
+    else hipLaunchKernelGGL((conv0_wgrad_kernel<2>), dim3(grid), dim3(256), 0, y2_s(stream), a);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

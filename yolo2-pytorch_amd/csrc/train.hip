@@ -23,8 +23,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double n, c
                                    float* scale, float* shift, float* mean_out, float* invstd_out, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double mean = stats[c] / n;
-    double var = stats[C + c] / n - mean * mean;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < Y2_STATS_REPL; ++r) { s1 += stats[(size_t)r * 2 * C + c]; s2 += stats[(size_t)r * 2 * C + C + c]; }
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float s = gamma[c] * invstd;

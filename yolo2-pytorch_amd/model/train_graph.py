@@ -83,7 +83,7 @@ class DarknetTrainFn(torch.autograd.Function):
             blk.mod, blk.name, blk.x, blk.ldx, blk.H, blk.W, blk.cin, blk.cout, blk.k = mod, name, xin, ldx, h, w, cin, cout, k
             blk.pool, blk.has_bn, blk.slope, blk.first = pool, mod.bn is not None, (LEAKY if mod.has_act else 1.0), first
             z = _new(dev, B, h, w, cout)
-            stats = torch.zeros(2 * cout, dtype=torch.float64, device=dev) if blk.has_bn else None
+            stats = torch.zeros(_hip.STATS_REPL * 2 * cout, dtype=torch.float64, device=dev) if blk.has_bn else None
             if first:
                 _hip.check(L.y2_conv0_fwd(_hip.ptr(xin), _hip.ptr(_hip.f32c(weight)), None, None, _hip.ptr(z), None, _hip.ptr(stats),
                                           B, h, w, cin, cout, cout, 0, 1.0, st), 'y2_conv0_fwd')
@@ -209,14 +209,18 @@ class DarknetTrainFn(torch.autograd.Function):
                 ready(blk.mod.conv.bias, gb)
             # weight gradient
             weight = blk.mod.conv.weight
-            if blk.first:
+            if blk.first and cin <= 3 and cout <= 64:
+                dw0 = torch.zeros(cout, cin, k, k, dtype=torch.float32, device=dev)
+                _hip.check(L.y2_conv0_wgrad(_hip.ptr(ctx.x), _hip.ptr(dz), _hip.ptr(dw0), B, h, w, cin, cout, cop, st), 'y2_conv0_wgrad')
+                ready(weight, dw0)
+            elif blk.first:
                 x4 = torch.zeros(B, h, w, 4, dtype=torch.float32, device=dev)
                 x4[..., :cin] = ctx.x.permute(0, 2, 3, 1)          # layout conversion only (NCHW plugin input -> NHWC, 4th channel zero)
-                dwp = torch.zeros(cout * k * k * 4, dtype=torch.float32, device=dev)
-                _hip.check(L.y2_conv_wgrad(_hip.ptr(x4), _hip.ptr(dz), _hip.ptr(dwp), B, h, w, 4, 4, cout, cout, k, st), 'y2_conv_wgrad')
-                dw4 = _new(dev, cout, 4, k, k)
-                _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw4), cout, 4, k, st), 'y2_unpack_weight_grad')
-                ready(weight, dw4[:, :cin].contiguous())
+                dwp = torch.zeros(cop * k * k * 4, dtype=torch.float32, device=dev)
+                _hip.check(L.y2_conv_wgrad(_hip.ptr(x4), _hip.ptr(dz), _hip.ptr(dwp), B, h, w, 4, 4, cop, cop, k, st), 'y2_conv_wgrad')
+                dw4 = _new(dev, cop, 4, k, k)
+                _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw4), cop, 4, k, st), 'y2_unpack_weight_grad')
+                ready(weight, dw4[:cout, :cin].contiguous())
             else:
                 dwp = torch.zeros(cop * cin * k * k, dtype=torch.float32, device=dev)
                 _hip.check(L.y2_conv_wgrad(_hip.ptr(blk.x), _hip.ptr(dz), _hip.ptr(dwp), B, h, w, cin, blk.ldx, cop, cop, k, st), 'y2_conv_wgrad')

@@ -287,220 +287,6 @@ class Darknet(nn.Module):
         return out
 
     def forward(self, x):
-        raise RuntimeError('model.yolo2.Conv2d is a parameter container; the network runs through Darknet.forward (HIP)')
-
-
-class _Pool(nn.Module):
-    """Placeholder keeping the reference's nn.Sequential indices (MaxPool2d has no parameters)."""
-
-    def forward(self, x):
-        raise RuntimeError('pooling is fused into the producing convolution')
-
-
-class Darknet(nn.Module):
-    def __init__(self, config_channels, anchors, num_cls, stride=2, ratio=1):
-        nn.Module.__init__(self)
-        assert stride == 2
-        self.stride = stride
-        channels = int(32 * ratio)
-        layers = []
-        bn = config_channels.config.getboolean('batch_norm', 'enable')
-        # layers1 — identical construction order to model/yolo2.py:76-96 (ConfigChannels is stateful)
-        for _ in range(2):
-            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-            layers.append(_Pool())
-            channels *= 2
-        for _ in range(2):
-            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-            layers.append(Conv2d(config_channels.channels, config_channels(channels // 2, 'layers1.%d.conv.weight' % len(layers)), 1, bn=bn))
-            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-            layers.append(_Pool())
-            channels *= 2
-        for _ in range(2):
-            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-            layers.append(Conv2d(config_channels.channels, config_channels(channels // 2, 'layers1.%d.conv.weight' % len(layers)), 1, bn=bn))
-        layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-        self.layers1 = nn.Sequential(*layers)
-
-        layers = []
-        layers.append(_Pool())
-        channels *= 2
-        for _ in range(2):
-            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers2.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-            layers.append(Conv2d(config_channels.channels, config_channels(channels // 2, 'layers2.%d.conv.weight' % len(layers)), 1, bn=bn))
-        for _ in range(3):
-            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers2.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-        self.layers2 = nn.Sequential(*layers)
-
-        self.passthrough = Conv2d(self.layers1[-1].conv.weight.size(0), config_channels(int(64 * ratio), 'passthrough.conv.weight'), 1, bn=bn)
-
-        layers = []
-        layers.append(Conv2d(self.passthrough.conv.weight.size(0) * self.stride * self.stride + self.layers2[-1].conv.weight.size(0), config_channels(int(1024 * ratio), 'layers3.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-        layers.append(Conv2d(config_channels.channels, model.output_channels(len(anchors), num_cls), 1, bn=False, act=False))
-        self.layers3 = nn.Sequential(*layers)
-
-        self.init()
-        self._cache = None  # packed weights / folded BN for eval, keyed on parameter versions
-        self._plan_cache = None
-        self.grad_ready_hook = None  # set by train.DataParallelRCCL: called as hook(param, grad) inside backward, layer by layer
-        self.profile = None  # bench.py: list receiving (kernel, flops, start_event, end_event) per conv launch
-
-    def init(self):
-        """model/yolo2.py:117-123."""
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d):
-                nn.init.kaiming_normal_(m.weight)
-            elif isinstance(m, nn.BatchNorm2d):
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
-
-    def scope(self, name):
-        return '.'.join(name.split('.')[:-2])
-
-    def get_mapper(self, index):
-        if index == 94:
-            return lambda indices, channels: torch.cat([indices + i * channels for i in range(self.stride * self.stride)])
-
-    # ------------------------------------------------------------------ execution plan
-    def _blocks(self):
-        """[(name, Conv2d, pool_follows)] in execution order for the three sequential stages."""
-        def seq(prefix, s):
-            out = []
-            mods = list(s)
-            for i, m in enumerate(mods):
-                if isinstance(m, Conv2d):
-                    out.append(('%s.%d' % (prefix, i), m, i + 1 < len(mods) and isinstance(mods[i + 1], _Pool)))
-            return out
-        return seq('layers1', self.layers1), seq('layers2', self.layers2), seq('layers3', self.layers3)
-
-    def _versions(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
-
-    def _prepare_eval(self, device):
-        """Pack weights to [Cout][tap][Cin] and fold BN once per parameter version (y2_pack_weight / y2_bn_fold)."""
-        ver = (device, self._versions())
-        if self._cache is not None and self._cache[0] == ver:
-            return self._cache[1]
-        L = _hip.lib()
-        st = _hip.stream()
-        prep = {}
-        first = self.layers1[0]
-        for blk in [m for m in self.modules() if isinstance(m, Conv2d)]:
-            w = blk.conv.weight.detach()
-            _hip.require_gpu(w)
-            cout, cin, k, _ = w.shape
-            w = _hip.f32c(w)
-            if blk is first:
-                wp = w  # y2_conv0_fwd reads the state_dict layout directly
-            else:
-                wp = torch.empty(cout * cin * k * k, dtype=torch.float32, device=device)
-                _hip.check(L.y2_pack_weight(_hip.ptr(w), _hip.ptr(wp), cout, cin, k, 0, st), 'y2_pack_weight')
-            if blk.bn is not None:
-                scale = torch.empty(cout, dtype=torch.float32, device=device)
-                shift = torch.empty(cout, dtype=torch.float32, device=device)
-                bn = blk.bn
-                _hip.check(L.y2_bn_fold(_hip.ptr(_hip.f32c(bn.weight.detach())), _hip.ptr(_hip.f32c(bn.bias.detach())),
-                                        _hip.ptr(_hip.f32c(bn.running_mean)), _hip.ptr(_hip.f32c(bn.running_var)),
-                                        BN_EPS, _hip.ptr(scale), _hip.ptr(shift), cout, st), 'y2_bn_fold')
-            else:
-                scale = None
-                shift = _hip.f32c(blk.conv.bias.detach()) if blk.conv.bias is not None else None
-            prep[blk] = (wp, scale, shift)
-        self._cache = (ver, prep)
-        return prep
-
-    def _conv(self, L, st, prep, blk, x, B, H, W, ldx, y=None, y_pool=None, ldy=0, coff=0, ldp=0, poff=0, out_mode=0):
-        wp, scale, shift = prep[blk]
-        cout, cin = blk.conv.weight.shape[:2]
-        p = _hip.ConvParams()
-        p.x, p.w, p.scale, p.shift = x.data_ptr(), wp.data_ptr(), (scale.data_ptr() if scale is not None else None), (shift.data_ptr() if shift is not None else None)
-        p.y = y.data_ptr() if y is not None else None
-        p.y_pool = y_pool.data_ptr() if y_pool is not None else None
-        p.stats = None
-        p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize = B, H, W, cin, ldx, cout, blk.kernel_size
-        p.ldy, p.coff, p.ldp, p.poff, p.out_mode = ldy, coff, ldp, poff, out_mode
-        p.slope = LEAKY if blk.has_act else 1.0
-        p.tile = 0
-        if self.profile is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _hip.check(L.y2_conv_fwd(ctypes.byref(p), st), 'y2_conv_fwd')
-        if self.profile is not None:
-            e1.record()
-            self.profile.append(('conv_fwd_k%d' % blk.kernel_size, 2.0 * cin * cout * blk.kernel_size ** 2 * B * H * W, e0, e1))
-
-    def forward_nhwc(self, x):
-        """x [B,Cin,H,W] NCHW fp32 on the GPU -> head image [B, H/32, W/32, A*(5+C)] (NHWC, contiguous)."""
-        _hip.require_gpu(x)
-        L = _hip.lib()
-        x = _hip.f32c(x)
-        B, cin0, H, W = x.shape
-        if H % 32 or W % 32:
-            raise ValueError('input size must be a multiple of 32 (got %dx%d)' % (H, W))
-        dev = x.device
-        prep = self._prepare_eval(dev)
-        st = _hip.stream()
-        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        b1, b2, b3 = self._blocks()
-
-        # ---- layers1.0: NCHW in, NHWC (pooled) out
-        name, blk, pool = b1[0]
-        wp, scale, shift = prep[blk]
-        c = blk.conv.weight.shape[0]
-        assert pool
-        cur = new(B, H // 2, W // 2, c)
-        if self.profile is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _hip.check(L.y2_conv0_fwd(_hip.ptr(x), _hip.ptr(wp), _hip.ptr(scale), _hip.ptr(shift), None, _hip.ptr(cur), None,
-                                  B, H, W, cin0, c, 0, c, LEAKY if blk.has_act else 1.0, st), 'y2_conv0_fwd')
-        if self.profile is not None:
-            e1.record()
-            self.profile.append(('conv0', 2.0 * cin0 * c * 9 * B * H * W, e0, e1))
-        h, w, ld = H // 2, W // 2, c
-        # ---- rest of layers1
-        full_last = None
-        for i, (name, blk, pool) in enumerate(b1[1:], 1):
-            c = blk.conv.weight.shape[0]
-            last = i == len(b1) - 1
-            if last:
-                # output feeds both the passthrough (full res) and layers2's leading MaxPool (model/yolo2.py:97,126-128)
-                full_last = new(B, h, w, c)
-                pooled = new(B, h // 2, w // 2, c)
-                self._conv(L, st, prep, blk, cur, B, h, w, ld, y=full_last, y_pool=pooled, ldy=c, ldp=c)
-                cur = pooled
-                fh, fw = h, w
-                h, w, ld = h // 2, w // 2, c
-            elif pool:
-                out = new(B, h // 2, w // 2, c)
-                self._conv(L, st, prep, blk, cur, B, h, w, ld, y_pool=out, ldp=c)
-                cur, h, w, ld = out, h // 2, w // 2, c
-            else:
-                out = new(B, h, w, c)
-                self._conv(L, st, prep, blk, cur, B, h, w, ld, y=out, ldy=c)
-                cur, ld = out, c
-        # ---- concat buffer [B, h, w, 4*c_pt + c_l2]; passthrough writes reorg'ed channels FIRST (model/yolo2.py:129)
-        c_pt = self.passthrough.conv.weight.shape[0]
-        c_l2 = b2[-1][1].conv.weight.shape[0]
-        cat = new(B, h, w, 4 * c_pt + c_l2)
-        self._conv(L, st, prep, self.passthrough, full_last, B, fh, fw, full_last.shape[-1], y=cat, ldy=cat.shape[-1], coff=0, out_mode=1)
-        for i, (name, blk, pool) in enumerate(b2):
-            c = blk.conv.weight.shape[0]
-            if i == len(b2) - 1:
-                self._conv(L, st, prep, blk, cur, B, h, w, ld, y=cat, ldy=cat.shape[-1], coff=4 * c_pt)
-            else:
-                out = new(B, h, w, c)
-                self._conv(L, st, prep, blk, cur, B, h, w, ld, y=out, ldy=c)
-                cur, ld = out, c
-        cur, ld = cat, cat.shape[-1]
-        for name, blk, pool in b3:
-            c = blk.conv.weight.shape[0]
-            out = new(B, h, w, c)
-            self._conv(L, st, prep, blk, cur, B, h, w, ld, y=out, ldy=c)
-            cur, ld = out, c
-        return cur
-
-    def forward(self, x):
         if self.training and torch.is_grad_enabled():
             from model import train_graph  # training graph (autograd.Function over the HIP kernels)
             return train_graph.darknet_forward(self, x)
