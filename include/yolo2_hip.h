@@ -86,9 +86,15 @@ typedef struct y2_conv_params {
     int32_t out_mode;    /* 0: y[b,y,x,coff+n];  1: reorg(stride 2): y[b,y/2,x/2, coff + ((y&1)*2+(x&1))*Cout + n] */
     float slope;         /* LeakyReLU negative slope; 1.0f = no activation */
     int32_t tile;        /* 0 = auto; else force a tile config (see conv_fwd.hip; benchmarking only) */
+    float* workspace;    /* optional scratch (16-B aligned) for the split-K remainder scheme, or NULL */
+    int64_t workspace_bytes; /* its size; y2_conv_fwd_workspace_bytes() tells how much a problem can use */
 } y2_conv_params;
 
 int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream);
+
+/* Scratch bytes this problem can use (tiles that do not fill the last round of the 256 CUs are split along K into a
+ * caller-provided workspace and combined by a fix-up kernel); 0 = none; negative = argument error. */
+long long y2_conv_fwd_workspace_bytes(const y2_conv_params* p);
 
 /* The same for `count` convolutions enqueued back to back (one host call for a whole Darknet stage chain;
  * model/yolo2.py:125-130 runs them as separate nn.Module calls). Stops at the first error. */

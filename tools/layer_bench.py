@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--tiles', default='0,1,2,3,5')
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--only', default='')
+    ap.add_argument('--no-split', action='store_true')
     args = ap.parse_args()
     L = _hip.lib()
     dev = torch.device('cuda:0')
@@ -59,6 +60,8 @@ def main():
                 p.y, p.ldy = y.data_ptr(), cout
             p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize = B, H, W, cin, cin, cout, k
             p.slope, p.tile = 0.1, tile
+            if not args.no_split:
+                _hip.conv_workspace(p, dev)
             st = _hip.stream()
             rc = L.y2_conv_fwd(ctypes.byref(p), st)
             if rc != 0:

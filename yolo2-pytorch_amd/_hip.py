@@ -25,7 +25,8 @@ class ConvParams(ctypes.Structure):
                 ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32),
                 ('Cin', ctypes.c_int32), ('ldx', ctypes.c_int32), ('Cout', ctypes.c_int32), ('ksize', ctypes.c_int32),
                 ('ldy', ctypes.c_int32), ('coff', ctypes.c_int32), ('ldp', ctypes.c_int32), ('poff', ctypes.c_int32),
-                ('out_mode', ctypes.c_int32), ('slope', c_float), ('tile', ctypes.c_int32)]
+                ('out_mode', ctypes.c_int32), ('slope', c_float), ('tile', ctypes.c_int32),
+                ('workspace', c_void_p), ('workspace_bytes', ctypes.c_int64)]
 
 
 # name -> argtypes; restype is int for everything except y2_build_info
@@ -35,6 +36,7 @@ SIGNATURES = {
     'y2_unpack_weight_grad': [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'y2_bn_fold': [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p],
     'y2_conv_fwd': [ctypes.POINTER(ConvParams), c_void_p],
+    'y2_conv_fwd_workspace_bytes': [ctypes.POINTER(ConvParams)],
     'y2_conv_fwd_batch': [ctypes.POINTER(ConvParams), c_int, c_void_p],
     'y2_conv0_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
@@ -90,6 +92,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argtypes
             fn.restype = c_int
+        l.y2_conv_fwd_workspace_bytes.restype = ctypes.c_longlong
         l.y2_build_info.argtypes = []
         l.y2_build_info.restype = ctypes.c_char_p
         _lib = l
@@ -116,6 +119,77 @@ def require_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise RuntimeError('yolo2-hip: this operator runs only on an MI355X GPU tensor (got device %s); there is no CPU fallback' % t.device)
+
+
+_WS = {}
+
+
+def workspace(dev, nbytes):
+    """Per-device scratch for the conv split-K remainder scheme (grows on demand; consecutive convolutions on one stream
+    may share it: a layer's fix-up kernel has consumed it before the next layer's main kernel starts)."""
+    key = str(dev)
+    t = _WS.get(key)
+    if t is None or t.numel() * 4 < nbytes:
+        t = torch.empty(max(int(nbytes) // 4 + 4, 1024), dtype=torch.float32, device=dev)
+        _WS[key] = t
+    return t
+
+
+def conv_workspace(params, dev):
+    """Attach scratch to one ConvParams (query + cached allocation)."""
+    need = lib().y2_conv_fwd_workspace_bytes(ctypes.byref(params))
+    if need > 0:
+        ws = workspace(dev, need)
+        params.workspace, params.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    else:
+        params.workspace, params.workspace_bytes = None, 0
+    return need
+
+
+_TUNE = {}
+AUTOTUNE = os.environ.get('Y2_AUTOTUNE', '1') != '0'
+
+
+def autotune_conv(params, dev):
+    """Measure-don't-guess tile selection for one y2_conv_fwd problem: the first time a problem shape is seen, every
+    tile configuration is timed (HIP events, 3 launches each) and the fastest is cached for the process; later calls only
+    look the answer up.  The outputs written while timing are the real outputs (same arithmetic for every tile).
+    Never called while a hipGraph is being captured (plans are built during warm-up)."""
+    key = (params.B, params.H, params.W, params.Cin, params.ldx, params.Cout, params.ksize, bool(params.y), bool(params.y_pool),
+           bool(params.stats), params.out_mode, str(dev))
+    hit = _TUNE.get(key)
+    if hit is not None:
+        params.tile = hit
+        return hit
+    if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        params.tile = 0
+        return 0
+    L = lib()
+    st = stream()
+    cands = [5, 3, 2, 1] + ([6] if params.Cout <= 32 else [])
+    best, best_t = 0, float('inf')
+    stats_save = params.stats
+    params.stats = None          # timing launches must not accumulate statistics twice
+    for tile in cands:
+        params.tile = tile
+        conv_workspace(params, dev)
+        if L.y2_conv_fwd(ctypes.byref(params), st) != 0:
+            continue
+        t = float('inf')
+        for _ in range(2):          # best of two batches of 3 launches (DVFS / neighbour noise)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                L.y2_conv_fwd(ctypes.byref(params), st)
+            e1.record()
+            e1.synchronize()
+            t = min(t, e0.elapsed_time(e1))
+        if t < best_t:
+            best, best_t = tile, t
+    params.stats = stats_save
+    params.tile = best
+    _TUNE[key] = best
+    return best
 
 
 def f32c(t):

@@ -53,6 +53,10 @@ struct ConvArgs {
     float slope;
     int M, tiles_m, tiles_n, cchunks;   // cchunks = ceil(Cin / BK)
     unsigned x_bytes, w_bytes;          // buffer-descriptor ranges of x and w (DMA kernel)
+    // split-K of the remainder tiles (see launch_dma): blocks [0, full_tiles) compute whole tiles; the following blocks
+    // compute 1/ksplit of the K range of tile full_tiles + (block - full_tiles) / ksplit and park raw accumulators in `partial`
+    int full_tiles, ksplit;
+    float* partial;
 };
 
 // pixel index (b*H + y)*W + x and (y, x) of GEMM row m
@@ -163,9 +167,19 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvArgs a) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l31 = lane & 31, half = lane >> 5;
 
-    const int wg = y2_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = wg % a.tiles_n;
-    const int tile_m = wg / a.tiles_n;
+    // XCD-aware remap applied separately to the whole tiles and to the K-slices, so that both classes of work are spread
+    // evenly over the 8 XCDs (a joint remap would hand all the heavy whole tiles to the first XCDs)
+    const bool is_split = (int)blockIdx.x >= a.full_tiles;
+    int tile, part = 0;
+    if (!is_split) {
+        tile = y2_xcd_remap(blockIdx.x, min((int)gridDim.x, a.full_tiles));
+    } else {
+        const int r = y2_xcd_remap(blockIdx.x - a.full_tiles, gridDim.x - a.full_tiles);
+        tile = a.full_tiles + r / a.ksplit;
+        part = r % a.ksplit;
+    }
+    const int tile_n = tile % a.tiles_n;
+    const int tile_m = tile / a.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- staging assignment: thread t -> 16-B slot (t&7) of rows (t>>3) + 32*i
@@ -312,7 +326,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvArgs a) {
 //   * 2-deep ring: iteration s = {vmcnt(0); barrier; issue DMA of slab s+1; 16 ds_read_b128 + 64 MFMA on slab s}.
 // Requirements (host checks, else the register-staged kernel runs): Cin, ldx multiples of 4, 16-B aligned bases,
 // tensors < 2^31 bytes.
-template <int BM, int BN, int WAVES_M, bool POOLORD, bool CTAIL>
+template <int BM, int BN, int WAVES_M, bool POOLORD, bool CTAIL, int STAGES = 2>
 __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
     constexpr int BK = 32;
     constexpr int WAVES_N = 4 / WAVES_M;
@@ -331,9 +345,19 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l31 = lane & 31, half = lane >> 5;
 
-    const int wg = y2_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = wg % a.tiles_n;
-    const int tile_m = wg / a.tiles_n;
+    // XCD-aware remap applied separately to the whole tiles and to the K-slices, so that both classes of work are spread
+    // evenly over the 8 XCDs (a joint remap would hand all the heavy whole tiles to the first XCDs)
+    const bool is_split = (int)blockIdx.x >= a.full_tiles;
+    int tile, part = 0;
+    if (!is_split) {
+        tile = y2_xcd_remap(blockIdx.x, min((int)gridDim.x, a.full_tiles));
+    } else {
+        const int r = y2_xcd_remap(blockIdx.x - a.full_tiles, gridDim.x - a.full_tiles);
+        tile = a.full_tiles + r / a.ksplit;
+        part = r % a.ksplit;
+    }
+    const int tile_n = tile % a.tiles_n;
+    const int tile_m = tile / a.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- staging assignment: lane -> physical 16-B slot p = lane & 7 of row (t>>3) + 32*i; it fetches logical chunk p ^ swz(row)
@@ -430,22 +454,103 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
         }
     };
 
-    const int nk = a.taps * a.cchunks;
-    int tap = 0, c0 = 0;
-    issue_slab(0, 0, 0);
-    for (int ks = 0; ks < nk - 1; ++ks) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of slab ks has landed
-        __syncthreads();                                     // ... everybody's has, and nobody still reads the other buffer
-        c0 += BK;
-        if (c0 >= a.Cin) { c0 = 0; ++tap; }
-        issue_slab(tap, c0, (ks + 1) & 1);
-        compute_slab(ks & 1);
+    const int nk_all = a.taps * a.cchunks;
+    int ks0 = 0, ks1 = nk_all;
+    if (is_split) {
+        ks0 = (int)((long long)nk_all * part / a.ksplit);
+        ks1 = (int)((long long)nk_all * (part + 1) / a.ksplit);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    compute_slab((nk - 1) & 1);
+    const int nk = ks1 - ks0;
+    int tap = ks0 / a.cchunks, c0 = (ks0 % a.cchunks) * BK;
+    if (nk > 0) {
+        if (STAGES == 2) {
+            issue_slab(tap, c0, 0);
+            for (int ks = 0; ks < nk - 1; ++ks) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of slab ks has landed
+                __syncthreads();                                     // ... everybody's has, and nobody still reads the other buffer
+                c0 += BK;
+                if (c0 >= a.Cin) { c0 = 0; ++tap; }
+                issue_slab(tap, c0, (ks + 1) & 1);
+                compute_slab(ks & 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute_slab((nk - 1) & 1);
+        } else {
+            // 3-deep ring: the DMA of slab s+2 is issued before slab s is consumed, so one slab stays in flight ACROSS the
+            // barrier (counted vmcnt + raw s_barrier: __syncthreads() would drain the DMA queue, cdna guide "glds span").
+            issue_slab(tap, c0, 0);
+            if (nk > 1) {
+                c0 += BK;
+                if (c0 >= a.Cin) { c0 = 0; ++tap; }
+                issue_slab(tap, c0, 1);
+            }
+            int cur = 0, nxt = 2;
+            for (int ks = 0; ks < nk; ++ks) {
+                if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR + BR) : "memory");   // slab ks landed, ks+1 may be in flight
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();        // everyone's part of slab ks is in LDS; everyone finished reading slab ks-1
+                if (ks + 2 < nk) {
+                    c0 += BK;
+                    if (c0 >= a.Cin) { c0 = 0; ++tap; }
+                    issue_slab(tap, c0, nxt);         // overwrites the buffer of slab ks-1
+                }
+                compute_slab(cur);
+                cur = cur == 2 ? 0 : cur + 1;
+                nxt = nxt == 2 ? 0 : nxt + 1;
+            }
+        }
+    }
 
+    if (is_split) {
+        // raw accumulators -> partial[(tile - full_tiles) * ksplit + part][MB][NB][4][256 threads][4]: 16-B coalesced stores;
+        // conv_splitk_fixup_kernel (same thread geometry) adds the parts and runs the ordinary epilogue
+        float* dst = a.partial + ((size_t)(tile - a.full_tiles) * a.ksplit + part) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(dst + (((i * NB + j) * 4 + g) * NT + t) * 4) = v;
+                }
+        return;
+    }
     conv_epilogue<MB, NB, WM, WN, POOLORD>(a, acc, m0, n0, wm, wn, l31, half);
+}
+
+// Adds the K-parts of the split remainder tiles and applies the ordinary epilogue (one workgroup per split tile, same
+// thread -> accumulator mapping as conv_fwd_dma_kernel).
+template <int BM, int BN, int WAVES_M, bool POOLORD>
+__global__ __launch_bounds__(NT) void conv_splitk_fixup_kernel(const ConvArgs a) {
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MB = WM / 32, NB = WN / 32;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tile = a.full_tiles + blockIdx.x;
+    const int tile_n = tile % a.tiles_n;
+    const int tile_m = tile / a.tiles_n;
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                for (int p = 0; p < a.ksplit; ++p) {
+                    const float* src = a.partial + ((size_t)blockIdx.x * a.ksplit + p) * (BM * BN);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (((i * NB + j) * 4 + g) * NT + t) * 4);
+                    sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+                }
+                acc[i][j][4 * g] = sum[0]; acc[i][j][4 * g + 1] = sum[1]; acc[i][j][4 * g + 2] = sum[2]; acc[i][j][4 * g + 3] = sum[3];
+            }
+    conv_epilogue<MB, NB, WM, WN, POOLORD>(a, acc, tile_m * BM, tile_n * BN, wm, wn, l31, half);
 }
 
 template <int BM, int BN, int WAVES_M, int BK, bool POOLORD, bool VEC, int ABLATE = 0>
@@ -470,18 +575,53 @@ int launch(const ConvArgs& a0, hipStream_t stream) {
     return Y2_OK;
 }
 
+// Remainder split: T tiles on P CUs run floor(T/P) full rounds; the last T mod P tiles would occupy only part of the chip
+// for a whole tile time.  They are cut into s K-slices each (s chosen to minimise ceil(rem*s/P)/s) and a tiny fixup kernel
+// adds the slices.  Needs caller workspace; without it (or when nothing is gained) tiles run whole.
+inline void plan_split(long long tiles, int nk, long long tile_elems, size_t ws_bytes, int& full_tiles, int& ksplit) {
+    full_tiles = (int)tiles; ksplit = 1;
+    const int P = Y2_NUM_CU;
+    const long long rem = tiles % P;
+    if (rem == 0 || nk < 8) return;
+    double best = 1.0; int bs = 1;
+    for (int s = 2; s <= 16 && nk / s >= 4; ++s) {
+        const double t = (double)y2_cdiv(rem * s, P) / s * 1.02 + 0.01;   // small penalty for the extra prologue/epilogue + fixup
+        if (t < best - 1e-9) { best = t; bs = s; }
+    }
+    if (bs == 1) return;
+    const double before = (double)y2_cdiv(tiles, P), after = (double)(tiles / P) + best;
+    if (after > before * 0.97) return;                                      // < 3 % gain: not worth a second launch
+    if ((size_t)rem * bs * tile_elems * sizeof(float) > ws_bytes) return;
+    full_tiles = (int)(tiles - rem); ksplit = bs;
+}
+
 template <int BM, int BN, int WAVES_M, bool POOLORD>
-int launch_dma(const ConvArgs& a0, hipStream_t stream) {
+int launch_dma(const ConvArgs& a0, hipStream_t stream, float* ws, size_t ws_bytes, size_t* ws_need) {
     ConvArgs a = a0;
     a.tiles_m = y2_cdiv(a.M, BM);
     a.tiles_n = y2_cdiv(a.Cout, BN);
     a.cchunks = y2_cdiv(a.Cin, 32);
     const size_t lds = 2u * (BM + BN) * 32 * sizeof(float);
     const bool ctail = (a.Cin % 32) != 0;
-    const long long grid = (long long)a.tiles_m * a.tiles_n;
-    if (grid <= 0 || grid > 0x7fffffffLL) return Y2_EINVAL;
-    static bool attr_set[2] = {false, false};
-    if (ctail) {
+    const long long tiles = (long long)a.tiles_m * a.tiles_n;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return Y2_EINVAL;
+    if (ws_need != nullptr) {   // workspace query: the largest split this layer could use
+        int ft, ks;
+        plan_split(tiles, a.taps * a.cchunks, (long long)BM * BN, (size_t)-1, ft, ks);
+        *ws_need = (size_t)(tiles - ft) * ks * BM * BN * sizeof(float);
+        return Y2_OK;
+    }
+    plan_split(tiles, a.taps * a.cchunks, (long long)BM * BN, ws != nullptr ? ws_bytes : 0, a.full_tiles, a.ksplit);
+    a.partial = ws;
+    const long long grid = a.full_tiles + (tiles - a.full_tiles) * a.ksplit;
+    static bool attr_set[3] = {false, false, false};
+    static int stages3 = -1;
+    if (stages3 < 0) { const char* e = getenv("Y2_CONV_STAGES"); stages3 = (e != nullptr && atoi(e) == 3) ? 1 : 0; }
+    if (stages3 && !ctail) {
+        auto kern = conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, false, 3>;
+        if (!attr_set[2]) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return -(1000 + (int)e); attr_set[2] = true; }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds / 2 * 3, stream, a);
+    } else if (ctail) {
         auto kern = conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, true>;
         if (!attr_set[1]) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return -(1000 + (int)e); attr_set[1] = true; }
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
@@ -490,18 +630,20 @@ int launch_dma(const ConvArgs& a0, hipStream_t stream) {
         if (!attr_set[0]) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return -(1000 + (int)e); attr_set[0] = true; }
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
     }
+    if (a.ksplit > 1)
+        hipLaunchKernelGGL((conv_splitk_fixup_kernel<BM, BN, WAVES_M, POOLORD>), dim3((unsigned)(tiles - a.full_tiles)), dim3(NT), 0, stream, a);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
 
 template <bool POOLORD>
-int dispatch_dma(const ConvArgs& a, int tile, hipStream_t s) {
+int dispatch_dma(const ConvArgs& a, int tile, hipStream_t s, float* ws, size_t ws_bytes, size_t* ws_need) {
     switch (tile) {
-        case 1: return launch_dma<128, 128, 2, POOLORD>(a, s);
-        case 2: return launch_dma<128, 64, 2, POOLORD>(a, s);
-        case 3: return launch_dma<64, 64, 2, POOLORD>(a, s);
-        case 5: return launch_dma<64, 128, 2, POOLORD>(a, s);
-        case 6: return launch_dma<128, 32, 4, POOLORD>(a, s);   // narrow outputs (Cout <= 32: dgrad into the first layers)
+        case 1: return launch_dma<128, 128, 2, POOLORD>(a, s, ws, ws_bytes, ws_need);
+        case 2: return launch_dma<128, 64, 2, POOLORD>(a, s, ws, ws_bytes, ws_need);
+        case 3: return launch_dma<64, 64, 2, POOLORD>(a, s, ws, ws_bytes, ws_need);
+        case 5: return launch_dma<64, 128, 2, POOLORD>(a, s, ws, ws_bytes, ws_need);
+        case 6: return launch_dma<128, 32, 4, POOLORD>(a, s, ws, ws_bytes, ws_need);   // narrow outputs (Cout <= 32: dgrad into the first layers)
         default: return Y2_ENOSUP;
     }
 }
@@ -525,18 +667,29 @@ int dispatch_tile(const ConvArgs& a, int tile, hipStream_t s) {
     }
 }
 
-// Pick the tile that minimises (tiles per CU, rounded up) x (tile area) / (measured main-loop efficiency).
-// Efficiencies measured on MI355X with the LDS-DMA kernel at B=32..128 (tools/layer_bench.py, profiles/):
-// every CU is saturated by its resident workgroups, so the makespan is quantised in whole tiles per CU.
-int choose_tile(long long M, int Cout) {
+// Rounds of whole tiles per CU, including the split-K remainder scheme of launch_dma (nk = K slabs per tile).
+inline double effective_rounds(long long tiles, int nk) {
+    const int P = Y2_NUM_CU;
+    const long long rem = tiles % P;
+    double frac = rem ? 1.0 : 0.0;
+    if (rem && nk >= 8)
+        for (int s = 2; s <= 16 && nk / s >= 4; ++s) {
+            const double t = (double)y2_cdiv(rem * s, P) / s * 1.02 + 0.01;
+            if (t < frac) frac = t;
+        }
+    return (double)(tiles / P) + frac;
+}
+
+// Pick the tile that minimises (tile rounds per CU) x (tile area) / (measured main-loop efficiency).
+// Efficiencies measured on MI355X with the LDS-DMA kernel at B=32..128 (tools/layer_bench.py, profiles/).
+int choose_tile(long long M, int Cout, int nk) {
     struct Cand { int id, bm, bn; double eff; };
     const Cand cands[] = {{5, 64, 128, 0.80}, {3, 64, 64, 0.78}, {2, 128, 64, 0.775}, {1, 128, 128, 0.74}, {6, 128, 32, 0.60}};
     int best = 3;
     double best_cost = 1e300;
     for (const Cand& c : cands) {
         const long long tiles = (long long)y2_cdiv(M, c.bm) * y2_cdiv(Cout, c.bn);
-        const double rounds = (double)y2_cdiv(tiles, Y2_NUM_CU);
-        const double cost = rounds * c.bm * c.bn / c.eff;
+        const double cost = effective_rounds(tiles, nk) * c.bm * c.bn / c.eff;
         if (cost < best_cost) { best_cost = cost; best = c.id; }
     }
     return best;
@@ -544,7 +697,8 @@ int choose_tile(long long M, int Cout) {
 
 }  // namespace
 
-extern "C" int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream) {
+static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need) {
+    if (ws_need != nullptr) *ws_need = 0;
     if (p == nullptr || p->x == nullptr || p->w == nullptr) return Y2_EINVAL;
     if (p->y == nullptr && p->y_pool == nullptr && p->stats == nullptr) return Y2_EINVAL;
     if (p->B <= 0 || p->H <= 0 || p->W <= 0 || p->Cin <= 0 || p->Cout <= 0) return Y2_EINVAL;
@@ -569,6 +723,7 @@ extern "C" int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream) {
     a.cchunks = y2_cdiv(p->Cin, BK_DEFAULT);
     a.tiles_m = a.tiles_n = 0;
     a.x_bytes = a.w_bytes = 0;
+    a.full_tiles = 0x7fffffff; a.ksplit = 1; a.partial = nullptr;
     static const float* zeros = nullptr;
     if (zeros == nullptr) {
         void* zp = nullptr;
@@ -579,7 +734,7 @@ extern "C" int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream) {
     a.zeros = zeros;
 
     const bool vec = (p->Cin % 4 == 0) && (p->ldx % 4 == 0) && y2_aligned16(p->x) && y2_aligned16(p->w);
-    int tile = p->tile > 0 ? p->tile : choose_tile(M, p->Cout);
+    int tile = p->tile > 0 ? p->tile : choose_tile(M, p->Cout, a.taps * y2_cdiv(p->Cin, 32));
     hipStream_t s = y2_s(stream);
     // tile ids 1,2,3,5: LDS-DMA kernel when the operands allow it; 101.. force the register-staged kernel (also the
     // path for channel counts / strides that are not multiples of 4, e.g. pruned checkpoints)
@@ -587,11 +742,23 @@ extern "C" int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream) {
     const bool dma_ok = vec && xb < 0x7fffffffull && wb < 0x7fffffffull && (tile == 1 || tile == 2 || tile == 3 || tile == 5 || tile == 6);
     if (dma_ok) {
         a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
-        return pool ? dispatch_dma<true>(a, tile, s) : dispatch_dma<false>(a, tile, s);
+        float* ws = p->workspace;
+        const size_t wsb = (ws != nullptr && y2_aligned16(ws)) ? (size_t)p->workspace_bytes : 0;
+        return pool ? dispatch_dma<true>(a, tile, s, ws, wsb, ws_need) : dispatch_dma<false>(a, tile, s, ws, wsb, ws_need);
     }
+    if (ws_need != nullptr) return Y2_OK;
     if (tile > 100) tile -= 100;
     if (pool) return vec ? dispatch_tile<true, true>(a, tile, s) : dispatch_tile<true, false>(a, tile, s);
     return vec ? dispatch_tile<false, true>(a, tile, s) : dispatch_tile<false, false>(a, tile, s);
+}
+
+extern "C" int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream) { return conv_fwd_impl(p, stream, nullptr); }
+
+// Bytes of scratch y2_conv_fwd can use for this problem (0 = none needed); pass it via y2_conv_params.workspace.
+extern "C" long long y2_conv_fwd_workspace_bytes(const y2_conv_params* p) {
+    size_t need = 0;
+    const int rc = conv_fwd_impl(p, nullptr, &need);
+    return rc == Y2_OK ? (long long)need : (long long)rc;
 }
 
 // Coarse entry: a whole chain of convolutions (the Darknet stages) in one call — the host enqueues the launches

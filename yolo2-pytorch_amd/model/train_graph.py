@@ -45,6 +45,8 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
     p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize = B, H, W, cin, ldx, cout, k
     p.ldy, p.coff, p.ldp, p.poff, p.out_mode = ldy, coff, ldp, 0, out_mode
     p.slope, p.tile = slope, 0
+    _hip.autotune_conv(p, x.device)
+    _hip.conv_workspace(p, x.device)
     _hip.check(L.y2_conv_fwd(ctypes.byref(p), st), 'y2_conv_fwd')
 
 

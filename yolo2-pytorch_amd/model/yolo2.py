@@ -247,9 +247,15 @@ class Darknet(nn.Module):
                 flops += add(blk, cur, B, h, w, ld, y=out, ldy=c)
                 cur, ld = out, c
                 keep.append(out)
+        for p in plist:
+            _hip.autotune_conv(p, dev)      # per-layer tile choice by measurement (cached per problem shape)
+        need = max([_hip.lib().y2_conv_fwd_workspace_bytes(ctypes.byref(p)) for p in plist] + [0])
+        ws = _hip.workspace(dev, need) if need > 0 else None
+        for p in plist:
+            p.workspace, p.workspace_bytes = (ws.data_ptr(), ws.numel() * 4) if ws is not None else (None, 0)
         arr = (_hip.ConvParams * len(plist))(*plist)
         plan = dict(arr=arr, n=len(plist), first=first, head_index=head_index, head_shape=head_shape, flops=flops,
-                    flops0=2.0 * cin0 * blk0.conv.weight.shape[0] * 9 * B * H * W, keep=(keep, full_last, cat, prep))
+                    flops0=2.0 * cin0 * blk0.conv.weight.shape[0] * 9 * B * H * W, keep=(keep, full_last, cat, prep, ws))
         self._plan_cache = (key, plan)
         return plan
 
