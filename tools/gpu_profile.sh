@@ -3,7 +3,9 @@
 # --pmc only with --kernel-trace; never combined with other trace domains).
 cd "$(dirname "$0")/.." || exit 1
 R=$PWD; mkdir -p gpurun_out/prof; export TMPDIR=/tmp
-CMD="python $R/bench.py --steps ${STEPS:-5} --warmup 2 --cpu-sample 0"
+export Y2_TUNE_CACHE=/tmp/y2_tune.json
+CMD="python $R/bench.py --steps ${STEPS:-5} --warmup 2 --cpu-sample 0 --train-steps 0"
+$CMD > /dev/null 2>&1   # populate the tile-autotune cache so the profiled runs contain only steady-state launches
 cd /tmp
 rm -rf $R/gpurun_out/prof/*
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace -o trace -- $CMD > $R/gpurun_out/prof/trace.log 2>&1

@@ -148,6 +148,13 @@ def conv_workspace(params, dev):
 
 _TUNE = {}
 AUTOTUNE = os.environ.get('Y2_AUTOTUNE', '1') != '0'
+TUNE_CACHE = os.environ.get('Y2_TUNE_CACHE')      # optional JSON file persisting the measured tile choices across processes
+if TUNE_CACHE and os.path.exists(TUNE_CACHE):
+    try:
+        import json as _json
+        _TUNE.update({tuple(_json.loads(k)): v for k, v in _json.load(open(TUNE_CACHE)).items()})
+    except Exception:
+        pass
 
 
 def autotune_conv(params, dev):
@@ -189,6 +196,12 @@ def autotune_conv(params, dev):
     params.stats = stats_save
     params.tile = best
     _TUNE[key] = best
+    if TUNE_CACHE:
+        try:
+            import json as _json
+            _json.dump({_json.dumps(list(k)): v for k, v in _TUNE.items()}, open(TUNE_CACHE, 'w'))
+        except Exception:
+            pass
     return best
 
 
