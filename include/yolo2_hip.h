@@ -77,10 +77,10 @@ typedef struct y2_conv_params {
     float* y_pool;       /* 2x2/stride-2 max-pooled output or NULL (needs even H and W) */
     double* stats;       /* NULL, or [Y2_STATS_REPL][2*Cout] doubles (pre-zeroed): sum and sum of squares of the RAW
                             conv output per channel are atomically accumulated (training-mode BN statistics) */
-    int32_t B, H, W;     /* input = output spatial size (stride 1, same padding) */
+    int32_t B, H, W;     /* INPUT spatial size; output = (H + 2*pad - k)/stride + 1 (equal to the input for stride 1 / same padding) */
     int32_t Cin, ldx;
     int32_t Cout;
-    int32_t ksize;       /* 1 or 3 */
+    int32_t ksize;       /* 1..7 (1 and 3 with stride 1 / same padding take the specialised path) */
     int32_t ldy, coff;   /* y pixel stride and channel offset (concat write-through) */
     int32_t ldp, poff;   /* y_pool pixel stride and channel offset */
     int32_t out_mode;    /* 0: y[b,y,x,coff+n];  1: reorg(stride 2): y[b,y/2,x/2, coff + ((y&1)*2+(x&1))*Cout + n] */
@@ -88,6 +88,11 @@ typedef struct y2_conv_params {
     int32_t tile;        /* 0 = auto; else force a tile config (see conv_fwd.hip; benchmarking only) */
     float* workspace;    /* optional scratch (16-B aligned) for the split-K remainder scheme, or NULL */
     int64_t workspace_bytes; /* its size; y2_conv_fwd_workspace_bytes() tells how much a problem can use */
+    const float* residual; /* optional [B,Ho,Wo,Cout] (pixel stride ldr) added before the activation (model/resnet.py:59,101) */
+    int32_t ldr;
+    int32_t stride;      /* 0 or 1 = stride 1; 2 = the strided convs of model/resnet.py:31,71,111 */
+    int32_t pad_plus1;   /* 0 = "same" padding (k-1)/2; otherwise padding + 1 */
+    int32_t reserved;
 } y2_conv_params;
 
 int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream);

@@ -360,3 +360,52 @@ def test_detect_batch_end_to_end_vs_oracle(golden):
             if ref is not None:
                 for got, want in zip(res[b], ref[:5]):
                     np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------ general convolution (ResNet plugin: model/resnet.py)
+GEN_CASES = [
+    # B, Cin, Cout, H, W, k, stride, pad, residual, tile
+    (2, 4, 64, 32, 40, 7, 2, 3, False, 0),      # stem 7x7 s2 p3 on the zero-padded 4-channel NHWC input
+    (2, 64, 64, 19, 19, 3, 2, 1, False, 0),     # 3x3 s2 (Bottleneck.conv2 of a down-sampling block)
+    (2, 64, 128, 20, 20, 1, 2, 0, False, 3),    # 1x1 s2 down-sample branch
+    (2, 64, 256, 10, 10, 1, 1, 0, True, 0),     # 1x1 + residual + ReLU
+    (1, 16, 24, 9, 11, 3, 1, 1, True, 5),       # small Cin through the linear-K path
+    (2, 8, 40, 12, 12, 5, 1, 0, False, 2),      # 5x5 valid padding
+]
+
+
+@pytest.mark.parametrize('B,cin,cout,H,W,k,stride,pad,residual,tile', GEN_CASES)
+def test_conv_general_stride_kernel_residual(B, cin, cout, H, W, k, stride, pad, residual, tile):
+    import _hip
+    L = _hip.lib()
+    d = dev()
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    z = F.conv2d(x.double(), w.double(), stride=stride, padding=pad) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    Ho, Wo = z.shape[-2:]
+    res = torch.randn(B, cout, Ho, Wo, generator=g) if residual else None
+    if residual:
+        z = z + res.double()
+    ref = torch.relu(z)
+    xd = to_nhwc(x).to(d)
+    wd = w.to(d).contiguous()
+    wp = torch.empty(w.numel(), device=d)
+    _hip.check(L.y2_pack_weight(_hip.ptr(wd), _hip.ptr(wp), cout, cin, k, 0, _hip.stream()), 'pack')
+    y = torch.full((B, Ho, Wo, cout + 3), -7.0, device=d)
+    sc, sh = scale.to(d), shift.to(d)
+    rd = to_nhwc(res).to(d) if residual else None
+    p = _hip.ConvParams()
+    p.x, p.w, p.scale, p.shift, p.y = xd.data_ptr(), wp.data_ptr(), sc.data_ptr(), sh.data_ptr(), y.data_ptr()
+    p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize = B, H, W, cin, cin, cout, k
+    p.ldy, p.slope, p.tile = cout + 3, 0.0, tile
+    p.stride, p.pad_plus1 = stride, pad + 1
+    if residual:
+        p.residual, p.ldr = rd.data_ptr(), cout
+    _hip.conv_workspace(p, d)
+    _hip.check(L.y2_conv_fwd(ctypes.byref(p), _hip.stream()), 'conv')
+    torch.cuda.synchronize()
+    assert torch.all(y[..., cout:] == -7.0)
+    assert rel_err(y[..., :cout].permute(0, 3, 1, 2), ref) <= CONV_TOL

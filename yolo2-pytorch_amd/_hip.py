@@ -26,7 +26,8 @@ class ConvParams(ctypes.Structure):
                 ('Cin', ctypes.c_int32), ('ldx', ctypes.c_int32), ('Cout', ctypes.c_int32), ('ksize', ctypes.c_int32),
                 ('ldy', ctypes.c_int32), ('coff', ctypes.c_int32), ('ldp', ctypes.c_int32), ('poff', ctypes.c_int32),
                 ('out_mode', ctypes.c_int32), ('slope', c_float), ('tile', ctypes.c_int32),
-                ('workspace', c_void_p), ('workspace_bytes', ctypes.c_int64)]
+                ('workspace', c_void_p), ('workspace_bytes', ctypes.c_int64),
+                ('residual', c_void_p), ('ldr', ctypes.c_int32), ('stride', ctypes.c_int32), ('pad_plus1', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 # name -> argtypes; restype is int for everything except y2_build_info
@@ -163,7 +164,7 @@ def autotune_conv(params, dev):
     look the answer up.  The outputs written while timing are the real outputs (same arithmetic for every tile).
     Never called while a hipGraph is being captured (plans are built during warm-up)."""
     key = (params.B, params.H, params.W, params.Cin, params.ldx, params.Cout, params.ksize, bool(params.y), bool(params.y_pool),
-           bool(params.stats), params.out_mode, str(dev))
+           bool(params.stats), params.out_mode, params.stride, params.pad_plus1, bool(params.residual), str(dev))
     hit = _TUNE.get(key)
     if hit is not None:
         params.tile = hit

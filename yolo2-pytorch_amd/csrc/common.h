@@ -27,3 +27,24 @@ __device__ __forceinline__ int y2_xcd_remap(int bid, int nwg) {
     const int xcd = bid % Y2_NUM_XCD, i = bid / Y2_NUM_XCD;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
+
+// Exact unsigned division by a run-time constant without the ~30-instruction v_rcp sequence (Granlund-Montgomery,
+// "branch-free" form): q = (t + ((n - t) >> 1)) >> (l - 1),  t = umulhi(n, mul),  l = ceil(log2 d),
+// mul = floor(2^32 * (2^l - d) / d) + 1.  Valid for every 32-bit n; d == 1 is the identity.
+struct y2_fastdiv {
+    uint32_t mul, sh, d;
+};
+static inline y2_fastdiv y2_make_fastdiv(uint32_t d) {
+    y2_fastdiv f; f.d = d; f.mul = 0; f.sh = 0;
+    if (d <= 1) return f;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh = l - 1;
+    return f;
+}
+__device__ __forceinline__ uint32_t y2_div(uint32_t n, const y2_fastdiv& f) {
+    if (f.d <= 1) return n;
+    const uint32_t t = __umulhi(n, f.mul);
+    return (t + ((n - t) >> 1)) >> f.sh;
+}

@@ -57,22 +57,28 @@ struct ConvArgs {
     // compute 1/ksplit of the K range of tile full_tiles + (block - full_tiles) / ksplit and park raw accumulators in `partial`
     int full_tiles, ksplit;
     float* partial;
+    y2_fastdiv d_hw, d_w, d_w2;         // exact division by H*W, W, 2*W (row decode)
+    // general convolution (GEN kernels: any stride / kernel size / padding, K = k*k*Cin treated as one linear axis)
+    int stride, pad, KW, Ho, Wo, K;
+    const float* res;                   // optional residual added before the activation: res[m*ldr + n]
+    int ldr;
+    y2_fastdiv d_cin, d_kw, d_howo, d_wo;
 };
 
 // pixel index (b*H + y)*W + x and (y, x) of GEMM row m
 template <bool POOLORD>
 __device__ __forceinline__ void decode_row(const ConvArgs& a, int m, int& pix, int& y, int& x) {
     const int hw = a.H * a.W;
-    const int b = m / hw;
+    const int b = (int)y2_div((uint32_t)m, a.d_hw);
     const int idx = m - b * hw;
     if (POOLORD) {
         const int w2 = 2 * a.W;
-        const int p = idx / w2;
+        const int p = (int)y2_div((uint32_t)idx, a.d_w2);
         const int rem = idx - p * w2;
         y = 2 * p + ((rem >> 1) & 1);
         x = 2 * (rem >> 2) + (rem & 1);
     } else {
-        y = idx / a.W;
+        y = (int)y2_div((uint32_t)idx, a.d_w);
         x = idx - y * a.W;
     }
     pix = (b * a.H + y) * a.W + x;
@@ -102,19 +108,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                     const float z = acc[i][j][4 * g + e];
                     s1 += z;
                     s2 += z * z;
-                    const float u = z * sc + sh;
+                    float u = z * sc + sh;
+                    if (!POOLORD && a.res != nullptr && nok && mq + e < a.M) u += a.res[(size_t)(mq + e) * a.ldr + n];   // residual branch (model/resnet.py:59,101)
                     v[e] = u > 0.f ? u : u * a.slope;
                 }
                 if (!nok || mq >= a.M) continue;
                 if (do_full) {
-                    if (POOLORD || a.out_mode == 1) {
+                    if (POOLORD && a.out_mode == 0) {
+                        // the quad is one 2x2 window (M % 4 == 0): decode its top-left pixel once
+                        int pix, yy, xx;
+                        decode_row<true>(a, mq, pix, yy, xx);
+                        float* dst = a.y + (size_t)pix * a.ldy + a.coff + n;
+                        dst[0] = v[0];
+                        dst[a.ldy] = v[1];
+                        dst[(size_t)a.W * a.ldy] = v[2];
+                        dst[(size_t)(a.W + 1) * a.ldy] = v[3];
+                    } else if (POOLORD || a.out_mode == 1) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             if (mq + e >= a.M) break;
                             int pix, yy, xx;
                             decode_row<POOLORD>(a, mq + e, pix, yy, xx);
                             if (a.out_mode == 1) {
-                                const int b = pix / (a.H * a.W);
+                                const int b = (int)y2_div((uint32_t)pix, a.d_hw);
                                 const int opix = (b * (a.H >> 1) + (yy >> 1)) * (a.W >> 1) + (xx >> 1);
                                 a.y[(size_t)opix * a.ldy + a.coff + ((yy & 1) * 2 + (xx & 1)) * a.Cout + n] = v[e];
                             } else {
@@ -326,7 +342,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvArgs a) {
 //   * 2-deep ring: iteration s = {vmcnt(0); barrier; issue DMA of slab s+1; 16 ds_read_b128 + 64 MFMA on slab s}.
 // Requirements (host checks, else the register-staged kernel runs): Cin, ldx multiples of 4, 16-B aligned bases,
 // tensors < 2^31 bytes.
-template <int BM, int BN, int WAVES_M, bool POOLORD, bool CTAIL, int STAGES = 2>
+template <int BM, int BN, int WAVES_M, bool POOLORD, bool CTAIL, int STAGES = 2, bool GEN = false>
 __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
     constexpr int BK = 32;
     constexpr int WAVES_N = 4 / WAVES_M;
@@ -364,47 +380,86 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
     const int srow = t >> 3;                                   // 0..31 (rows 8*wave .. 8*wave+7)
     const int lchunk = (lane & 7) ^ ((srow >> 1) & 7);         // row + 32*i has the same swizzle
     unsigned a_base[AR];                                        // byte offset of (pixel row, tap (0,0) = up-left neighbour, chunk) or OOB
-    unsigned a_mask[AR];                                        // bit tap = 1 when that tap is inside the image
+    unsigned a_mask[AR];                                        // bit tap = 1 when that tap is inside the image (GEN: unused)
+    int a_yb[AR], a_xb[AR];                                     // GEN: input coordinates of tap (0,0) for this output pixel
     const int up_left = (a.taps == 9) ? (a.W + 1) : 0;
+    const int ktot = GEN ? a.K : a.taps * a.Cin;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + srow + 32 * i;
-        unsigned mask = 0;
-        int pix = 0;
-        if (m < a.M) {
-            int y, x;
-            decode_row<POOLORD>(a, m, pix, y, x);
-            if (a.taps == 9) {
-#pragma unroll
-                for (int tp = 0; tp < 9; ++tp) {
-                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
-                    if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) mask |= 1u << tp;
-                }
+        if (GEN) {
+            a_mask[i] = 0;
+            if (m < a.M) {
+                const int b = (int)y2_div((uint32_t)m, a.d_howo);
+                const int idx = m - b * (a.Ho * a.Wo);
+                const int yo = (int)y2_div((uint32_t)idx, a.d_wo);
+                const int xo = idx - yo * a.Wo;
+                a_yb[i] = yo * a.stride - a.pad;
+                a_xb[i] = xo * a.stride - a.pad;
+                a_base[i] = (unsigned)((long long)((b * a.H + a_yb[i]) * a.W + a_xb[i]) * a.ldx * 4);   // may wrap: only used when the tap is valid
             } else {
-                mask = 1u;
+                a_yb[i] = -(1 << 20); a_xb[i] = -(1 << 20); a_base[i] = 0;
             }
+        } else {
+            unsigned mask = 0;
+            int pix = 0;
+            if (m < a.M) {
+                int y, x;
+                decode_row<POOLORD>(a, m, pix, y, x);
+                if (a.taps == 9) {
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) {
+                        const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                        if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) mask |= 1u << tp;
+                    }
+                } else {
+                    mask = 1u;
+                }
+            }
+            a_mask[i] = mask;
+            a_yb[i] = 0; a_xb[i] = 0;
+            a_base[i] = (unsigned)(((long long)(pix - up_left) * a.ldx + 4 * lchunk) * 4);   // may wrap below 0: only used when the tap is valid
         }
-        a_mask[i] = mask;
-        a_base[i] = (unsigned)(((long long)(pix - up_left) * a.ldx + 4 * lchunk) * 4);   // may wrap below 0: only used when the tap is valid
     }
-    const int ktot = a.taps * a.Cin;
     unsigned b_base[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
         const int n = n0 + srow + 32 * i;
-        b_base[i] = n < a.Cout ? (unsigned)(((size_t)n * ktot + 4 * lchunk) * 4) : OOB;
+        b_base[i] = n < a.Cout ? (unsigned)(((size_t)n * ktot + (GEN ? 0 : 4 * lchunk)) * 4) : OOB;
     }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
 
-    auto issue_slab = [&](int tap, int c0, int buf) {
+    auto issue_slab = [&](int ks_abs, int tap, int c0, int buf) {
+        float* sa = smem + buf * STAGE + wave * (8 * BK);
+        float* sb = sa + BM * BK;
+        if (GEN) {
+            // K = (ky, kx, ci) linear: this lane's 16-B chunk is 4 consecutive channels of ONE tap (Cin % 4 == 0)
+            const int kq = ks_abs * BK + 4 * lchunk;
+            const bool kok = kq < a.K;
+            const int tp = (int)y2_div((uint32_t)kq, a.d_cin);
+            const int c = kq - tp * a.Cin;
+            const int ky = (int)y2_div((uint32_t)tp, a.d_kw);
+            const int kx = tp - ky * a.KW;
+            const unsigned toff = (unsigned)(((ky * a.W + kx) * a.ldx + c) * 4);
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bool ok = kok && (unsigned)(a_yb[i] + ky) < (unsigned)a.H && (unsigned)(a_xb[i] + kx) < (unsigned)a.W;
+                const unsigned voff = ok ? a_base[i] + toff : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 32 * BK), 16, (int)voff, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i) {
+                const unsigned voff = (kok && b_base[i] != OOB) ? b_base[i] + (unsigned)kq * 4u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sb + i * 32 * BK), 16, (int)voff, 0, 0, 0);
+            }
+            return;
+        }
         // A: voffset = a_base + ((ky*W + kx)*ldx + c0)*4   (ky, kx in 0..2 relative to the up-left neighbour)
         const int ky = (a.taps == 9) ? tap / 3 : 0, kx = (a.taps == 9) ? tap % 3 : 0;
         const unsigned toff = (unsigned)(((ky * a.W + kx) * a.ldx + c0) * 4);
         const unsigned tbit = 1u << tap;
         const bool cok = !CTAIL || (c0 + 4 * lchunk) < a.Cin;
-        float* sa = smem + buf * STAGE + wave * (8 * BK);
-        float* sb = sa + BM * BK;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const bool ok = (a_mask[i] & tbit) != 0 && cok;
@@ -454,23 +509,23 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
         }
     };
 
-    const int nk_all = a.taps * a.cchunks;
+    const int nk_all = GEN ? (a.K + BK - 1) / BK : a.taps * a.cchunks;
     int ks0 = 0, ks1 = nk_all;
     if (is_split) {
         ks0 = (int)((long long)nk_all * part / a.ksplit);
         ks1 = (int)((long long)nk_all * (part + 1) / a.ksplit);
     }
     const int nk = ks1 - ks0;
-    int tap = ks0 / a.cchunks, c0 = (ks0 % a.cchunks) * BK;
+    int tap = GEN ? 0 : ks0 / a.cchunks, c0 = GEN ? 0 : (ks0 % a.cchunks) * BK;
     if (nk > 0) {
         if (STAGES == 2) {
-            issue_slab(tap, c0, 0);
+            issue_slab(ks0, tap, c0, 0);
             for (int ks = 0; ks < nk - 1; ++ks) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of slab ks has landed
                 __syncthreads();                                     // ... everybody's has, and nobody still reads the other buffer
                 c0 += BK;
                 if (c0 >= a.Cin) { c0 = 0; ++tap; }
-                issue_slab(tap, c0, (ks + 1) & 1);
+                issue_slab(ks0 + ks + 1, tap, c0, (ks + 1) & 1);
                 compute_slab(ks & 1);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -479,11 +534,11 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
         } else {
             // 3-deep ring: the DMA of slab s+2 is issued before slab s is consumed, so one slab stays in flight ACROSS the
             // barrier (counted vmcnt + raw s_barrier: __syncthreads() would drain the DMA queue, cdna guide "glds span").
-            issue_slab(tap, c0, 0);
+            issue_slab(ks0, tap, c0, 0);
             if (nk > 1) {
                 c0 += BK;
                 if (c0 >= a.Cin) { c0 = 0; ++tap; }
-                issue_slab(tap, c0, 1);
+                issue_slab(ks0 + 1, tap, c0, 1);
             }
             int cur = 0, nxt = 2;
             for (int ks = 0; ks < nk; ++ks) {
@@ -493,7 +548,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
                 if (ks + 2 < nk) {
                     c0 += BK;
                     if (c0 >= a.Cin) { c0 = 0; ++tap; }
-                    issue_slab(tap, c0, nxt);         // overwrites the buffer of slab ks-1
+                    issue_slab(ks0 + ks + 2, tap, c0, nxt);         // overwrites the buffer of slab ks-1
                 }
                 compute_slab(cur);
                 cur = cur == 2 ? 0 : cur + 1;
@@ -595,55 +650,58 @@ inline void plan_split(long long tiles, int nk, long long tile_elems, size_t ws_
     full_tiles = (int)(tiles - rem); ksplit = bs;
 }
 
-template <int BM, int BN, int WAVES_M, bool POOLORD>
+template <int BM, int BN, int WAVES_M, bool POOLORD, bool GEN = false>
 int launch_dma(const ConvArgs& a0, hipStream_t stream, float* ws, size_t ws_bytes, size_t* ws_need) {
     ConvArgs a = a0;
     a.tiles_m = y2_cdiv(a.M, BM);
     a.tiles_n = y2_cdiv(a.Cout, BN);
     a.cchunks = y2_cdiv(a.Cin, 32);
     const size_t lds = 2u * (BM + BN) * 32 * sizeof(float);
-    const bool ctail = (a.Cin % 32) != 0;
+    const bool ctail = !GEN && (a.Cin % 32) != 0;
+    const int nk_all = GEN ? y2_cdiv(a.K, 32) : a.taps * a.cchunks;
     const long long tiles = (long long)a.tiles_m * a.tiles_n;
     if (tiles <= 0 || tiles > 0x7fffffffLL) return Y2_EINVAL;
     if (ws_need != nullptr) {   // workspace query: the largest split this layer could use
         int ft, ks;
-        plan_split(tiles, a.taps * a.cchunks, (long long)BM * BN, (size_t)-1, ft, ks);
+        plan_split(tiles, nk_all, (long long)BM * BN, (size_t)-1, ft, ks);
         *ws_need = (size_t)(tiles - ft) * ks * BM * BN * sizeof(float);
         return Y2_OK;
     }
-    plan_split(tiles, a.taps * a.cchunks, (long long)BM * BN, ws != nullptr ? ws_bytes : 0, a.full_tiles, a.ksplit);
+    plan_split(tiles, nk_all, (long long)BM * BN, ws != nullptr ? ws_bytes : 0, a.full_tiles, a.ksplit);
     a.partial = ws;
     const long long grid = a.full_tiles + (tiles - a.full_tiles) * a.ksplit;
-    static bool attr_set[3] = {false, false, false};
+    static bool attr_set[4] = {false, false, false, false};
     static int stages3 = -1;
     if (stages3 < 0) { const char* e = getenv("Y2_CONV_STAGES"); stages3 = (e != nullptr && atoi(e) == 3) ? 1 : 0; }
-    if (stages3 && !ctail) {
-        auto kern = conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, false, 3>;
-        if (!attr_set[2]) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return -(1000 + (int)e); attr_set[2] = true; }
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds / 2 * 3, stream, a);
-    } else if (ctail) {
-        auto kern = conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, true>;
-        if (!attr_set[1]) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return -(1000 + (int)e); attr_set[1] = true; }
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
-    } else {
-        auto kern = conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, false>;
-        if (!attr_set[0]) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return -(1000 + (int)e); attr_set[0] = true; }
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
-    }
+#define Y2_DMA_LAUNCH(KERN, SLOT, LDSB)                                                                                     \
+    do {                                                                                                                    \
+        auto kern = KERN;                                                                                                   \
+        if (!attr_set[SLOT]) {                                                                                              \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return -(1000 + (int)e);                                                                   \
+            attr_set[SLOT] = true;                                                                                          \
+        }                                                                                                                   \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), LDSB, stream, a);                                          \
+    } while (0)
+    if (GEN) Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, false, false, 2, true>), 3, lds);
+    else if (stages3 && !ctail) Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, false, 3>), 2, lds / 2 * 3);
+    else if (ctail) Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, true>), 1, lds);
+    else Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, false>), 0, lds);
+#undef Y2_DMA_LAUNCH
     if (a.ksplit > 1)
-        hipLaunchKernelGGL((conv_splitk_fixup_kernel<BM, BN, WAVES_M, POOLORD>), dim3((unsigned)(tiles - a.full_tiles)), dim3(NT), 0, stream, a);
+        hipLaunchKernelGGL((conv_splitk_fixup_kernel<BM, BN, WAVES_M, (POOLORD && !GEN)>), dim3((unsigned)(tiles - a.full_tiles)), dim3(NT), 0, stream, a);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
 
-template <bool POOLORD>
+template <bool POOLORD, bool GEN = false>
 int dispatch_dma(const ConvArgs& a, int tile, hipStream_t s, float* ws, size_t ws_bytes, size_t* ws_need) {
     switch (tile) {
-        case 1: return launch_dma<128, 128, 2, POOLORD>(a, s, ws, ws_bytes, ws_need);
-        case 2: return launch_dma<128, 64, 2, POOLORD>(a, s, ws, ws_bytes, ws_need);
-        case 3: return launch_dma<64, 64, 2, POOLORD>(a, s, ws, ws_bytes, ws_need);
-        case 5: return launch_dma<64, 128, 2, POOLORD>(a, s, ws, ws_bytes, ws_need);
-        case 6: return launch_dma<128, 32, 4, POOLORD>(a, s, ws, ws_bytes, ws_need);   // narrow outputs (Cout <= 32: dgrad into the first layers)
+        case 1: return launch_dma<128, 128, 2, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);
+        case 2: return launch_dma<128, 64, 2, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);
+        case 3: return launch_dma<64, 64, 2, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);
+        case 5: return launch_dma<64, 128, 2, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);
+        case 6: return launch_dma<128, 32, 4, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);   // narrow outputs (Cout <= 32: dgrad into the first layers)
         default: return Y2_ENOSUP;
     }
 }
@@ -702,15 +760,22 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
     if (p == nullptr || p->x == nullptr || p->w == nullptr) return Y2_EINVAL;
     if (p->y == nullptr && p->y_pool == nullptr && p->stats == nullptr) return Y2_EINVAL;
     if (p->B <= 0 || p->H <= 0 || p->W <= 0 || p->Cin <= 0 || p->Cout <= 0) return Y2_EINVAL;
-    if (p->ksize != 1 && p->ksize != 3) return Y2_ENOSUP;
+    if (p->ksize < 1 || p->ksize > 7) return Y2_ENOSUP;
     if (p->ldx < p->Cin) return Y2_EINVAL;
+    const int stride = p->stride > 0 ? p->stride : 1;
+    const int pad = p->pad_plus1 > 0 ? p->pad_plus1 - 1 : (p->ksize - 1) / 2;
+    const int Ho = (p->H + 2 * pad - p->ksize) / stride + 1, Wo = (p->W + 2 * pad - p->ksize) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return Y2_EINVAL;
+    const bool standard = stride == 1 && pad == (p->ksize - 1) / 2 && (p->ksize == 1 || p->ksize == 3);
     if (p->y != nullptr && p->out_mode == 0 && p->ldy < p->coff + p->Cout) return Y2_EINVAL;
     if (p->y != nullptr && p->out_mode == 1 && (p->ldy < p->coff + 4 * p->Cout || (p->H & 1) || (p->W & 1))) return Y2_EINVAL;
     if (p->out_mode != 0 && p->out_mode != 1) return Y2_EINVAL;
     const bool pool = p->y_pool != nullptr;
     if (pool && ((p->H & 1) || (p->W & 1) || p->ldp < p->poff + p->Cout)) return Y2_EINVAL;
-    const long long M = (long long)p->B * p->H * p->W;
-    if (M > 0x7fffffffLL / 2) return Y2_EINVAL;
+    if (p->residual != nullptr && (pool || p->out_mode != 0 || p->ldr < p->Cout)) return Y2_ENOSUP;
+    const long long Min = (long long)p->B * p->H * p->W;
+    const long long M = (long long)p->B * Ho * Wo;
+    if (M > 0x7fffffffLL / 2 || Min > 0x7fffffffLL / 2) return Y2_EINVAL;
 
     ConvArgs a;
     a.x = p->x; a.w = p->w; a.scale = p->scale; a.shift = p->shift;
@@ -724,8 +789,13 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
     a.tiles_m = a.tiles_n = 0;
     a.x_bytes = a.w_bytes = 0;
     a.full_tiles = 0x7fffffff; a.ksplit = 1; a.partial = nullptr;
+    a.d_hw = y2_make_fastdiv((uint32_t)(p->H * p->W)); a.d_w = y2_make_fastdiv((uint32_t)p->W); a.d_w2 = y2_make_fastdiv((uint32_t)(2 * p->W));
+    a.stride = stride; a.pad = pad; a.KW = p->ksize; a.Ho = Ho; a.Wo = Wo; a.K = a.taps * p->Cin;
+    a.res = p->residual; a.ldr = p->ldr;
+    a.d_cin = y2_make_fastdiv((uint32_t)p->Cin); a.d_kw = y2_make_fastdiv((uint32_t)p->ksize);
+    a.d_howo = y2_make_fastdiv((uint32_t)(Ho * Wo)); a.d_wo = y2_make_fastdiv((uint32_t)Wo);
     static const float* zeros = nullptr;
-    if (zeros == nullptr) {
+    if (zeros == nullptr && ws_need == nullptr) {
         void* zp = nullptr;
         hipError_t e = hipGetSymbolAddress(&zp, HIP_SYMBOL(y2_zero16_storage));
         if (e != hipSuccess) return -(1000 + (int)e);
@@ -734,19 +804,29 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
     a.zeros = zeros;
 
     const bool vec = (p->Cin % 4 == 0) && (p->ldx % 4 == 0) && y2_aligned16(p->x) && y2_aligned16(p->w);
-    int tile = p->tile > 0 ? p->tile : choose_tile(M, p->Cout, a.taps * y2_cdiv(p->Cin, 32));
+    const int nk = standard ? a.taps * y2_cdiv(p->Cin, 32) : y2_cdiv(a.K, 32);
+    int tile = p->tile > 0 ? p->tile : choose_tile(M, p->Cout, nk);
     hipStream_t s = y2_s(stream);
-    // tile ids 1,2,3,5: LDS-DMA kernel when the operands allow it; 101.. force the register-staged kernel (also the
-    // path for channel counts / strides that are not multiples of 4, e.g. pruned checkpoints)
-    const unsigned long long xb = (unsigned long long)M * p->ldx * 4ull, wb = (unsigned long long)p->Cout * a.taps * p->Cin * 4ull;
-    const bool dma_ok = vec && xb < 0x7fffffffull && wb < 0x7fffffffull && (tile == 1 || tile == 2 || tile == 3 || tile == 5 || tile == 6);
+    // tile ids 1,2,3,5,6: LDS-DMA kernel when the operands allow it; 101.. force the register-staged kernel (also the
+    // path for channel counts / strides that are not multiples of 4, e.g. pruned checkpoints).  Strided / 7x7 / padded
+    // variants and small Cin (K handled as one linear axis) use the GEN instantiation of the DMA kernel.
+    const unsigned long long xb = (unsigned long long)Min * p->ldx * 4ull, wb = (unsigned long long)p->Cout * a.taps * p->Cin * 4ull;
+    const bool dma_tile = (tile == 1 || tile == 2 || tile == 3 || tile == 5 || tile == 6);
+    const bool dma_ok = vec && xb < 0x7fffffffull && wb < 0x7fffffffull && dma_tile;
+    const bool gen = !standard || (dma_ok && p->Cin < 32 && !pool && p->out_mode == 0);
+    float* ws = p->workspace;
+    const size_t wsb = (ws != nullptr && y2_aligned16(ws)) ? (size_t)p->workspace_bytes : 0;
+    if (gen) {
+        if (!dma_ok || pool || p->out_mode != 0) return Y2_ENOSUP;
+        a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+        return dispatch_dma<false, true>(a, tile, s, ws, wsb, ws_need);
+    }
     if (dma_ok) {
         a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
-        float* ws = p->workspace;
-        const size_t wsb = (ws != nullptr && y2_aligned16(ws)) ? (size_t)p->workspace_bytes : 0;
         return pool ? dispatch_dma<true>(a, tile, s, ws, wsb, ws_need) : dispatch_dma<false>(a, tile, s, ws, wsb, ws_need);
     }
     if (ws_need != nullptr) return Y2_OK;
+    if (p->residual != nullptr) return Y2_ENOSUP;
     if (tile > 100) tile -= 100;
     if (pool) return vec ? dispatch_tile<true, true>(a, tile, s) : dispatch_tile<true, false>(a, tile, s);
     return vec ? dispatch_tile<false, true>(a, tile, s) : dispatch_tile<false, false>(a, tile, s);
