@@ -116,6 +116,13 @@ int y2_conv0_fwd(const float* x_nchw, const float* w, const float* scale, const 
 /* nn.MaxPool2d(kernel_size=2) (model/yolo2.py:79,86,97) on NHWC; H, W even (16-B vector path when C, ldx, ldy are multiples of 4). */
 int y2_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, y2_stream_t stream);
 
+/* General nn.MaxPool2d(ksize, stride, pad) on NHWC (model/resnet.py:114: 3, 2, 1); out = (H + 2*pad - k)/stride + 1. */
+int y2_maxpool_fwd(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, int ksize, int stride, int pad, y2_stream_t stream);
+
+/* Plugin input boundary for backbones whose stem runs through y2_conv_fwd (model/resnet.py:111): NCHW [B,C,H,W] ->
+ * NHWC with pixel stride ld >= C, padding channels zero-filled. */
+int y2_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int ld, y2_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Detection head decode: model.Inference.forward after self.dnn(x) (model/__init__.py:120-135),
  * softmax of the class logits (detect.py:152, eval.py:270) and the visibility filter

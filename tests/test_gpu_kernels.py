@@ -409,3 +409,45 @@ def test_conv_general_stride_kernel_residual(B, cin, cout, H, W, k, stride, pad,
     torch.cuda.synchronize()
     assert torch.all(y[..., cout:] == -7.0)
     assert rel_err(y[..., :cout].permute(0, 3, 1, 2), ref) <= CONV_TOL
+
+
+# ------------------------------------------------------------------ ResNet plugin (BASELINE config 5: model-plugin swap)
+def make_resnet(arch, sd, num_cls):
+    import model
+    import model.resnet
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1'}, 'model': {'pretrained': '0'}})
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    net = getattr(model.resnet, arch)(model.ConfigChannels(cfg, sd), anchors, num_cls)
+    net.load_state_dict(sd, strict=False)
+    return model.Inference(cfg, net, anchors).to(dev()).eval()
+
+
+@pytest.mark.parametrize('arch,width,S,C,B', [('resnet50', 8, 96, 80, 2), ('resnet18', 8, 64, 20, 2), ('resnet50', 64, 64, 80, 1)])
+def test_resnet_matches_reference_fixture(golden, arch, width, S, C, B):
+    from oracle import resnet as ores
+    g = golden('resnet')
+    sd = ores.init_state_dict(arch, 5, C, seed=0, width=width, head_scale=0.25)
+    inf = make_resnet(arch, sd, C)
+    with torch.no_grad():
+        f = inf.dnn(synth.images(B, S, seed=1).to(dev()))
+    assert tuple(f.shape) == g['%s_w%d_feature' % (arch, width)].shape
+    assert rel_err(f, torch.from_numpy(g['%s_w%d_fp64' % (arch, width)])) <= CONV_TOL
+    assert rel_err(f, torch.from_numpy(g['%s_w%d_feature' % (arch, width)])) <= 2 * CONV_TOL
+
+
+def test_resnet50_608_coco_full_pipeline():
+    """Config-5 shape: ResNet-50, 608x608, COCO-80 head -> decode -> filter -> NMS, against the fp32 oracle."""
+    import detect
+    import model
+    from oracle import resnet as ores
+    sd = ores.init_state_dict('resnet50', 5, 80, seed=0, head_scale=0.25)
+    inf = make_resnet('resnet50', sd, 80)
+    x = synth.images(1, 608, seed=1)
+    with torch.no_grad():
+        pred = model._inference(inf, x.to(dev()))
+        f32 = ores.forward(x, sd, 'resnet50')
+    assert tuple(pred['feature'].shape) == (1, 425, 19, 19)
+    assert rel_err(pred['feature'], f32) <= 4 * CONV_TOL
+    d = detect.detect_batch(pred['feature'].permute(0, 2, 3, 1).contiguous(), torch.from_numpy(synth.ANCHORS_VOC), fix=True)
+    assert int(d['keep_count'][0]) > 0

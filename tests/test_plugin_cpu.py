@@ -68,3 +68,17 @@ def test_forward_refuses_cpu_tensor():
     dnn = model.yolo2.Darknet(model.ConfigChannels(config(), sd), anchors, 20).eval()
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         dnn(torch.zeros(1, 3, 32, 32))
+
+
+@pytest.mark.parametrize('arch,width', [('resnet50', 64), ('resnet18', 64), ('resnet50', 8)])
+def test_resnet_state_dict_matches_reference_layout(arch, width):
+    import model.resnet
+    from oracle import resnet as ores
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    ref = ores.init_state_dict(arch, 5, 80, width=width)   # keys/shapes pinned against the reference by oracle/make_golden_resnet.py
+    net = getattr(model.resnet, arch)(model.ConfigChannels(config(), ref if width != 64 else None), anchors, 80)
+    ours = {k: tuple(v.shape) for k, v in net.state_dict().items() if not k.endswith('num_batches_tracked')}
+    assert list(ours.keys()) == list(ref.keys())
+    for k, v in ref.items():
+        assert ours[k] == tuple(v.shape), k
+    assert utils.parse_attr('model.resnet.' + arch) is getattr(model.resnet, arch)

@@ -70,6 +70,54 @@ __global__ void maxpool2_scalar_kernel(const float* __restrict__ x, float* __res
     }
 }
 
+// general max-pool on NHWC (nn.MaxPool2d(kernel_size=3, stride=2, padding=1), model/resnet.py:114): padded taps are skipped (-inf)
+template <int CV>
+__global__ void maxpool_gen_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int Ho, int Wo, int C, int ldx, int ldy,
+                                   int k, int stride, int pad, long long total) {
+    const int Cg = C / CV;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cg) * CV;
+        const long long p = i / Cg;
+        const int xo = (int)(p % Wo);
+        const long long r = p / Wo;
+        const int yo = (int)(r % Ho);
+        const long long b = r / Ho;
+        float m[CV];
+#pragma unroll
+        for (int e = 0; e < CV; ++e) m[e] = -INFINITY;
+        for (int ky = 0; ky < k; ++ky) {
+            const int yy = yo * stride - pad + ky;
+            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int xx = xo * stride - pad + kx;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const float* s = x + ((b * H + yy) * W + xx) * ldx + c;
+                if (CV == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(s);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+                } else {
+                    m[0] = fmaxf(m[0], s[0]);
+                }
+            }
+        }
+        if (CV == 4) { f32x4 o = {m[0], m[1], m[2], m[3]}; *reinterpret_cast<f32x4*>(y + p * ldy + c) = o; }
+        else y[p * ldy + c] = m[0];
+    }
+}
+
+// plugin input boundary for backbones whose first layer goes through the generic conv kernel: NCHW [B,C,H,W] -> NHWC with
+// pixel stride ld >= C, padding channels zero-filled
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW, int ld, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ld);
+        const long long p = i / ld;            // b*HW + pixel
+        const long long b = p / HW;
+        const long long pix = p - b * HW;
+        y[i] = c < C ? x[(b * C + c) * HW + pix] : 0.f;
+    }
+}
+
 inline int stream_grid(long long total, int block) {
     long long g = (total + block - 1) / block;
     const long long cap = (long long)Y2_NUM_CU * 8;
@@ -116,6 +164,26 @@ extern "C" int y2_maxpool2_fwd(const float* x, float* y, int B, int H, int W, in
     }
     const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(maxpool2_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, y, H / 2, W / 2, C / 4, ldx, ldy, total);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_maxpool_fwd(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, int ksize, int stride, int pad, y2_stream_t stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || ldx < C || ldy < C) return Y2_EINVAL;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return Y2_EINVAL;
+    const bool vec = !(C & 3) && !(ldx & 3) && !(ldy & 3) && y2_aligned16(x) && y2_aligned16(y);
+    const long long total = (long long)B * Ho * Wo * (vec ? C / 4 : C);
+    if (vec) hipLaunchKernelGGL((maxpool_gen_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, y, H, W, Ho, Wo, C, ldx, ldy, ksize, stride, pad, total);
+    else hipLaunchKernelGGL((maxpool_gen_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, y, H, W, Ho, Wo, C, ldx, ldy, ksize, stride, pad, total);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int ld, y2_stream_t stream) {
+    if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ld < C) return Y2_EINVAL;
+    const long long total = (long long)B * H * W * ld;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, y, C, H * W, ld, total);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

@@ -1,0 +1,278 @@
+"""`model.resnet` — the ResNet backbone plugins (resnet18 ... resnet152) of the reference, MI355X-native.
+
+Drop-in for model/resnet.py:29-224: same constructors `resnetNN(config_channels, anchors, num_cls)`, same
+`state_dict()` keys/shapes (`conv1.weight`, `bn1.*`, `layerL.B.conv{1,2,3}.weight`, `layerL.B.bn{1,2,3}.*`,
+`layerL.B.downsample.{0,1}.*`, `conv.{weight,bias}`), same `forward(x[B,3,H,W]) -> [B, A*(5+C), H/32, W/32]`;
+`[model] dnn = model.resnet.resnet50` in an unmodified ini selects it (BASELINE config 5 exercises the plugin swap).
+
+Execution (inference): the NCHW input is converted once to zero-padded 4-channel NHWC (y2_nchw_to_nhwc); every
+convolution — 7x7/s2 stem, 3x3/s2, 1x1/s2 down-sample, 1x1, 3x3 — is one y2_conv_fwd launch of the general fp32-MFMA
+LDS-DMA kernel with BatchNorm folded into the epilogue, ReLU as LeakyReLU(slope 0), and the residual addition of
+BasicBlock / Bottleneck (model/resnet.py:59,101) fused into the epilogue of the block's last convolution; the stem
+max-pool is y2_maxpool_fwd.  The whole chain is one y2_conv_fwd_batch call per stage list, built once per input shape.
+nn.Conv2d / nn.BatchNorm2d objects are parameter containers only.  Training of this plugin (strided dgrad) is not
+implemented yet: forward in training mode with grad enabled raises.
+"""
+import ctypes
+import logging
+
+import torch
+import torch.nn as nn
+
+import model
+import _hip
+
+BN_EPS = 1e-5
+
+
+class _Block(nn.Module):
+    def forward(self, x):
+        raise RuntimeError('model.resnet blocks are parameter containers; the network runs through ResNet.forward (HIP)')
+
+    def _downsample(self, channels_in, channels_out, stride):
+        if stride > 1 or channels_in != channels_out:
+            return nn.Sequential(nn.Conv2d(channels_in, channels_out, kernel_size=1, stride=stride, bias=False), nn.BatchNorm2d(channels_out))
+        return None
+
+
+class BasicBlock(_Block):
+    """model/resnet.py:29-62."""
+
+    def __init__(self, config_channels, prefix, channels, stride=1):
+        nn.Module.__init__(self)
+        channels_in = config_channels.channels
+        self.stride = stride
+        self.conv1 = nn.Conv2d(config_channels.channels, config_channels(channels, '%s.conv1.weight' % prefix), 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(config_channels.channels)
+        self.conv2 = nn.Conv2d(config_channels.channels, config_channels(channels, '%s.conv2.weight' % prefix), 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(config_channels.channels)
+        self.downsample = self._downsample(channels_in, config_channels.channels, stride)
+
+    def convs(self):
+        return [(self.conv1, self.bn1, self.stride, 1), (self.conv2, self.bn2, 1, 1)]
+
+
+class Bottleneck(_Block):
+    """model/resnet.py:65-104."""
+
+    def __init__(self, config_channels, prefix, channels, stride=1):
+        nn.Module.__init__(self)
+        channels_in = config_channels.channels
+        self.stride = stride
+        self.conv1 = nn.Conv2d(config_channels.channels, config_channels(channels, '%s.conv1.weight' % prefix), kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(config_channels.channels)
+        self.conv2 = nn.Conv2d(config_channels.channels, config_channels(channels, '%s.conv2.weight' % prefix), kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(config_channels.channels)
+        self.conv3 = nn.Conv2d(config_channels.channels, config_channels(channels * 4, '%s.conv3.weight' % prefix), kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(config_channels.channels)
+        self.downsample = self._downsample(channels_in, config_channels.channels, stride)
+
+    def convs(self):
+        return [(self.conv1, self.bn1, 1, 0), (self.conv2, self.bn2, self.stride, 1), (self.conv3, self.bn3, 1, 0)]
+
+
+class ResNet(nn.Module):
+    """model/resnet.py:107-159."""
+
+    def __init__(self, config_channels, anchors, num_cls, block, layers):
+        nn.Module.__init__(self)
+        self.conv1 = nn.Conv2d(config_channels.channels, config_channels(64, 'conv1.weight'), kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(config_channels.channels)
+        self.layer1 = self._make_layer(config_channels, 'layer1', block, 64, layers[0])
+        self.layer2 = self._make_layer(config_channels, 'layer2', block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(config_channels, 'layer3', block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(config_channels, 'layer4', block, 512, layers[3], stride=2)
+        self.conv = nn.Conv2d(config_channels.channels, model.output_channels(len(anchors), num_cls), 1)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+        self._cache = None
+        self._plan_cache = None
+        self.profile = None
+
+    def _make_layer(self, config_channels, prefix, block, channels, blocks, stride=1):
+        layers = [block(config_channels, '%s.%d' % (prefix, 0), channels, stride)]
+        for i in range(1, blocks):
+            layers.append(block(config_channels, '%s.%d' % (prefix, i), channels))
+        return nn.Sequential(*layers)
+
+    def scope(self, name):
+        comp = name.split('.')[:-1]
+        import re
+        try:
+            comp[-1] = re.search(r'[(conv)|(bn)](\d+)', comp[-1]).group(1)
+        except AttributeError:
+            if len(comp) > 1:
+                if comp[-2] == 'downsample':
+                    comp = comp[:-1]
+                else:
+                    assert False, name
+            else:
+                assert comp[-1] == 'conv', name
+        return '.'.join(comp)
+
+    # ------------------------------------------------------------------ preparation: packed weights + folded BN
+    def _versions(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def _prepare(self, dev):
+        ver = (dev, self._versions())
+        if self._cache is not None and self._cache[0] == ver:
+            return self._cache[1]
+        L = _hip.lib()
+        st = _hip.stream()
+        prep = {}
+
+        def fold(conv, bn):
+            w = _hip.f32c(conv.weight.detach())
+            _hip.require_gpu(w)
+            cout, cin, k, _ = w.shape
+            if cin % 4:                                   # the stem: zero-pad the input channels to the 4-channel NHWC image
+                wpad = torch.zeros(cout, (cin + 3) // 4 * 4, k, k, dtype=torch.float32, device=dev)
+                wpad[:, :cin] = w
+                w, cin = wpad, wpad.shape[1]
+            wp = torch.empty(w.numel(), dtype=torch.float32, device=dev)
+            _hip.check(L.y2_pack_weight(_hip.ptr(w), _hip.ptr(wp), cout, cin, k, 0, st), 'y2_pack_weight')
+            if bn is not None:
+                scale, shift = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+                _hip.check(L.y2_bn_fold(_hip.ptr(_hip.f32c(bn.weight.detach())), _hip.ptr(_hip.f32c(bn.bias.detach())), _hip.ptr(_hip.f32c(bn.running_mean)),
+                                        _hip.ptr(_hip.f32c(bn.running_var)), BN_EPS, _hip.ptr(scale), _hip.ptr(shift), cout, st), 'y2_bn_fold')
+            else:
+                scale, shift = None, (_hip.f32c(conv.bias.detach()) if conv.bias is not None else None)
+            prep[conv] = (wp, scale, shift, cin, cout, k)
+        fold(self.conv1, self.bn1)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                for conv, bn, _, _ in blk.convs():
+                    fold(conv, bn)
+                if blk.downsample is not None:
+                    fold(blk.downsample[0], blk.downsample[1])
+        fold(self.conv, None)
+        self._cache = (ver, prep)
+        return prep
+
+    def _plan(self, prep, dev, B, cin0, H, W):
+        key = (id(prep), dev, B, cin0, H, W)
+        if self._plan_cache is not None and self._plan_cache[0] == key:
+            return self._plan_cache[1]
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        keep, flops = [], [0.0]
+
+        def conv_params(conv, x, h, w, ldx, y, stride, pad, slope, residual=None):
+            wp, scale, shift, cin, cout, k = prep[conv]
+            p = _hip.ConvParams()
+            p.x, p.w = x.data_ptr(), wp.data_ptr()
+            p.scale = scale.data_ptr() if scale is not None else None
+            p.shift = shift.data_ptr() if shift is not None else None
+            p.y, p.ldy = y.data_ptr(), cout
+            p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize = B, h, w, cin, ldx, cout, k
+            p.stride, p.pad_plus1, p.slope, p.tile = stride, pad + 1, slope, 0
+            if residual is not None:
+                p.residual, p.ldr = residual.data_ptr(), cout
+            ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+            flops[0] += 2.0 * conv.weight.shape[1] * cout * k * k * B * ho * wo
+            return p
+
+        cpad = (cin0 + 3) // 4 * 4
+        x4 = new(B, H, W, cpad)
+        c1 = self.conv1.weight.shape[0]
+        h1, w1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        stem = new(B, h1, w1, c1)
+        p_stem = conv_params(self.conv1, x4, H, W, cpad, stem, 2, 3, 0.0)
+        h, w = (h1 + 2 - 3) // 2 + 1, (w1 + 2 - 3) // 2 + 1
+        pooled = new(B, h, w, c1)
+        plist = []
+        cur, ld = pooled, c1
+        keep += [x4, stem, pooled]
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                s = blk.stride
+                ho, wo = (h - 1) // s + 1, (w - 1) // s + 1
+                cout_blk = blk.convs()[-1][0].weight.shape[0]
+                residual = cur
+                if blk.downsample is not None:
+                    residual = new(B, ho, wo, cout_blk)
+                    plist.append(conv_params(blk.downsample[0], cur, h, w, ld, residual, s, 0, 1.0))   # BN folded, no activation
+                    keep.append(residual)
+                t, th, tw, tld = cur, h, w, ld
+                convs = blk.convs()
+                for i, (conv, bn, cs, cp) in enumerate(convs):
+                    co = conv.weight.shape[0]
+                    oh, ow = (th + 2 * cp - conv.kernel_size[0]) // cs + 1, (tw + 2 * cp - conv.kernel_size[0]) // cs + 1
+                    out = new(B, oh, ow, co)
+                    last = i == len(convs) - 1
+                    plist.append(conv_params(conv, t, th, tw, tld, out, cs, cp, 0.0, residual=residual if last else None))   # ReLU = slope 0
+                    keep.append(out)
+                    t, th, tw, tld = out, oh, ow, co
+                cur, h, w, ld = t, th, tw, tld
+        head_index = len(plist)
+        plist.append(conv_params(self.conv, cur, h, w, ld, cur, 1, 0, 1.0))
+        head_shape = (B, h, w, self.conv.weight.shape[0])
+        for p in [p_stem] + plist:
+            _hip.autotune_conv(p, dev) if p is not plist[head_index] else None
+        need = max([_hip.lib().y2_conv_fwd_workspace_bytes(ctypes.byref(p)) for p in [p_stem] + plist[:head_index]] + [0])
+        ws = _hip.workspace(dev, need) if need > 0 else None
+        for p in [p_stem] + plist:
+            p.workspace, p.workspace_bytes = (ws.data_ptr(), ws.numel() * 4) if ws is not None else (None, 0)
+        arr = (_hip.ConvParams * len(plist))(*plist)
+        plan = dict(x4=x4, cpad=cpad, stem=p_stem, stem_out=stem, stem_hw=(h1, w1, c1), pooled=pooled, arr=arr, n=len(plist), head_index=head_index,
+                    head_shape=head_shape, flops=flops[0], keep=(keep, prep, ws))
+        self._plan_cache = (key, plan)
+        return plan
+
+    def forward_nhwc(self, x):
+        _hip.require_gpu(x)
+        L = _hip.lib()
+        x = _hip.f32c(x)
+        B, cin0, H, W = x.shape
+        if H % 32 or W % 32:
+            raise ValueError('input size must be a multiple of 32 (got %dx%d)' % (H, W))
+        dev = x.device
+        prep = self._prepare(dev)
+        plan = self._plan(prep, dev, B, cin0, H, W)
+        st = _hip.stream()
+        out = torch.empty(plan['head_shape'], dtype=torch.float32, device=dev)
+        plan['arr'][plan['head_index']].y = out.data_ptr()
+        prof = self.profile
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _hip.check(L.y2_nchw_to_nhwc(_hip.ptr(x), _hip.ptr(plan['x4']), B, cin0, H, W, plan['cpad'], st), 'y2_nchw_to_nhwc')
+        _hip.check(L.y2_conv_fwd(ctypes.byref(plan['stem']), st), 'y2_conv_fwd')
+        h1, w1, c1 = plan['stem_hw']
+        _hip.check(L.y2_maxpool_fwd(_hip.ptr(plan['stem_out']), _hip.ptr(plan['pooled']), B, h1, w1, c1, c1, c1, 3, 2, 1, st), 'y2_maxpool_fwd')
+        _hip.check(L.y2_conv_fwd_batch(plan['arr'], plan['n'], st), 'y2_conv_fwd_batch')
+        if prof is not None:
+            e1.record()
+            prof.append(('conv_fwd', plan['flops'], e0, e1))
+        return out
+
+    def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError('model.resnet: the HIP training graph (strided dgrad / wgrad) is not implemented yet; use eval() / no_grad()')
+        with torch.no_grad():
+            out = self.forward_nhwc(x)
+        return out.permute(0, 3, 1, 2)
+
+
+def _make(block, layers):
+    def ctor(config_channels, anchors, num_cls, **kwargs):
+        net = ResNet(config_channels, anchors, num_cls, block, layers, **kwargs)
+        try:
+            pretrained = config_channels.config.getboolean('model', 'pretrained')
+        except Exception:
+            pretrained = False
+        if pretrained:   # model/resnet.py:164-171 downloads torchvision weights: there is no network here
+            logging.warning('model.resnet: [model] pretrained=1 ignored (no network / torchvision model zoo in this environment)')
+        return net
+    return ctor
+
+
+resnet18 = _make(BasicBlock, [2, 2, 2, 2])
+resnet34 = _make(BasicBlock, [3, 4, 6, 3])
+resnet50 = _make(Bottleneck, [3, 4, 6, 3])
+resnet101 = _make(Bottleneck, [3, 4, 23, 3])
+resnet152 = _make(Bottleneck, [3, 8, 36, 3])
