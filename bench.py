@@ -33,7 +33,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3
 
 
-def build_model(num_cls, dev):
+def build_model(num_cls, dev, arch='darknet'):
     import configparser
 
     import model
@@ -44,6 +44,14 @@ def build_model(num_cls, dev):
     cfg.read_dict({'batch_norm': {'enable': '1'}})
     anchors = torch.from_numpy(synth.ANCHORS_VOC)
     # SURVEY.md 8d weights: seed 0, kaiming conv, randomised BN buffers; head scaled so exp(size_norm) stays finite
+    if arch != 'darknet':
+        import model.resnet
+        from oracle import resnet as ores
+        cfg.read_dict({'model': {'pretrained': '0'}})
+        sd = ores.init_state_dict(arch, 5, num_cls, seed=0, head_scale=0.25)
+        dnn = getattr(model.resnet, arch)(model.ConfigChannels(cfg, sd), anchors, num_cls)
+        dnn.load_state_dict(sd, strict=False)
+        return model.Inference(cfg, dnn, anchors).to(dev).eval(), anchors, sd
     sd = odark.init_state_dict(5, num_cls, seed=0, head_scale=1 / 40.0)
     dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, num_cls)
     dnn.load_state_dict(sd, strict=False)
@@ -137,6 +145,7 @@ def main():
     ap.add_argument('--size', type=int, default=416)
     ap.add_argument('--classes', type=int, default=20)
     ap.add_argument('--mode', default='detect', choices=['detect', 'forward'])
+    ap.add_argument('--model', default='darknet', help="darknet (default, BASELINE configs[1]) or a model.resnet plugin name, e.g. resnet50 (configs[4] forward: --size 608 --classes 80)")
     ap.add_argument('--no-graph', action='store_true', help='launch the detect step eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--train-steps', type=int, default=6, help='extra leg: timed training steps (fwd + region loss + bwd + SGD), 0 = skip')
     ap.add_argument('--train-batch', type=int, default=64, help='per-GPU batch of the training leg (BASELINE configs[2])')
@@ -156,8 +165,11 @@ def main():
 
     import detect
     from oracle import synth
-    inf, anchors, sd = build_model(args.classes, dev)
+    inf, anchors, sd = build_model(args.classes, dev, args.model)
     dnn = inf.dnn
+    if args.model != 'darknet':
+        args.train_steps = 0
+        args.cpu_sample = 0
     x = synth.images(args.batch, args.size, seed=1 + rank).to(dev)   # resident in HBM before timing
 
     def step():
@@ -238,7 +250,7 @@ def main():
             'value': round(images / dt, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic', 'launch': 'hipGraph replay' if graphed is not None else 'eager', 'host_ms_per_step': round(host_dt / args.steps * 1e3, 4),
-            'config': {'workload': 'Darknet-19 YOLOv2 %dx%d batch-%d/GPU inference: conv stack + decode + filter + NMS (BASELINE configs[1])'
+            'config': {'model': args.model, 'workload': 'Darknet-19 YOLOv2 %dx%d batch-%d/GPU inference: conv stack + decode + filter + NMS (BASELINE configs[1])'
                                    % (args.size, args.size, args.batch) if args.mode == 'detect' else
                                    'Darknet-19 YOLOv2 %dx%d batch-%d/GPU conv stack only' % (args.size, args.size, args.batch),
                        'classes': args.classes, 'global_batch': args.batch * world, 'parallelism': 'replicas x%d (no collective)' % world,

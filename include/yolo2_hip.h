@@ -116,8 +116,10 @@ int y2_conv0_fwd(const float* x_nchw, const float* w, const float* scale, const 
 /* nn.MaxPool2d(kernel_size=2) (model/yolo2.py:79,86,97) on NHWC; H, W even (16-B vector path when C, ldx, ldy are multiples of 4). */
 int y2_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, y2_stream_t stream);
 
-/* General nn.MaxPool2d(ksize, stride, pad) on NHWC (model/resnet.py:114: 3, 2, 1); out = (H + 2*pad - k)/stride + 1. */
-int y2_maxpool_fwd(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, int ksize, int stride, int pad, y2_stream_t stream);
+/* General max-pool on NHWC with `pad` rows/cols of -inf before and `pad_end` after each spatial axis:
+ * nn.MaxPool2d(3, 2, 1) of model/resnet.py:114 is (3, 2, 1, 1); ConstantPad2d((0,1,0,1), float32.min) + MaxPool2d(2, stride=1)
+ * of model/yolo2.py:151-152 (Tiny) is (2, 1, 0, 1).  out = (H + pad + pad_end - k)/stride + 1. */
+int y2_maxpool_fwd(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, int ksize, int stride, int pad, int pad_end, y2_stream_t stream);
 
 /* Plugin input boundary for backbones whose stem runs through y2_conv_fwd (model/resnet.py:111): NCHW [B,C,H,W] ->
  * NHWC with pixel stride ld >= C, padding channels zero-filled. */

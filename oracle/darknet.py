@@ -142,3 +142,41 @@ def forward(x, sd, training=False, stats=None, taps=None):
     if taps is not None:
         taps[HEAD] = x
     return x
+
+
+# ------------------------------------------------------------------ tiny-yolo (model/yolo2.py:140-173)
+TINY = [('layers.0', 16), 'M', ('layers.2', 32), 'M', ('layers.4', 64), 'M', ('layers.6', 128), 'M', ('layers.8', 256), 'M',
+        ('layers.10', 512), 'P', ('layers.13', 1024), ('layers.14', 1024)]
+TINY_HEAD = 'layers.15'
+
+
+def init_tiny_state_dict(num_anchors=5, num_cls=20, seed=0, div=1, head_scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    sd = collections.OrderedDict()
+    cin = 3
+    for item in TINY:
+        if isinstance(item, str):
+            continue
+        prefix, cout = item[0], max(4, item[1] // div)
+        sd[prefix + '.conv.weight'] = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (cin * 9))
+        sd[prefix + '.bn.weight'] = torch.rand(cout, generator=g) + 0.5
+        sd[prefix + '.bn.bias'] = torch.randn(cout, generator=g) * 0.1
+        sd[prefix + '.bn.running_mean'] = torch.randn(cout, generator=g) * 0.1
+        sd[prefix + '.bn.running_var'] = torch.rand(cout, generator=g) + 0.5
+        cin = cout
+    nout = output_channels(num_anchors, num_cls)
+    sd[TINY_HEAD + '.conv.weight'] = torch.randn(nout, cin, 1, 1, generator=g) * math.sqrt(2.0 / cin) * head_scale
+    sd[TINY_HEAD + '.conv.bias'] = torch.randn(nout, generator=g) * 0.1 * head_scale
+    return collections.OrderedDict((k, v.to(dtype)) for k, v in sd.items())
+
+
+def tiny_forward(x, sd):
+    """model/yolo2.py:169-170 (eval): conv blocks, MaxPool2d(2), and ConstantPad2d((0,1,0,1), float32.min) + MaxPool2d(2, stride=1) (:151-152)."""
+    for item in TINY:
+        if item == 'M':
+            x = F.max_pool2d(x, 2)
+        elif item == 'P':
+            x = F.max_pool2d(F.pad(x, (0, 1, 0, 1), value=float(torch.finfo(torch.float32).min)), 2, stride=1)
+        else:
+            x = conv_block(x, sd, item[0], 3)
+    return F.conv2d(x, sd[TINY_HEAD + '.conv.weight'], sd[TINY_HEAD + '.conv.bias'])

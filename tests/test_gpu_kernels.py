@@ -451,3 +451,41 @@ def test_resnet50_608_coco_full_pipeline():
     assert rel_err(pred['feature'], f32) <= 4 * CONV_TOL
     d = detect.detect_batch(pred['feature'].permute(0, 2, 3, 1).contiguous(), torch.from_numpy(synth.ANCHORS_VOC), fix=True)
     assert int(d['keep_count'][0]) > 0
+
+
+# ------------------------------------------------------------------ tiny-yolo plugin and the eval matcher
+@pytest.mark.parametrize('div,S,B', [(8, 96, 2), (1, 64, 1)])
+def test_tiny_matches_reference_fixture(golden, div, S, B):
+    import model
+    import model.yolo2
+    g = golden('tiny')
+    sd = odark.init_tiny_state_dict(5, 20, seed=0, div=div, head_scale=0.25)
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1'}})
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    net = model.yolo2.Tiny(model.ConfigChannels(cfg, sd), anchors, 20)
+    res = net.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    net = net.to(dev()).eval()
+    with torch.no_grad():
+        f = net(synth.images(B, S, seed=1).to(dev()))
+    assert rel_err(f, torch.from_numpy(g['tiny_div%d_fp64' % div])) <= CONV_TOL
+
+
+def test_eval_matching_like_reference():
+    import importlib
+    ev = importlib.import_module('eval')
+    rng = np.random.RandomState(3)
+    c, s = rng.uniform(2, 11, (40, 2)).astype(np.float32), rng.uniform(1, 4, (40, 2)).astype(np.float32)
+    gt_min, gt_max = c[:7] - s[:7] / 2, c[:7] + s[:7] / 2
+    jit = rng.uniform(-0.4, 0.4, (40, 2)).astype(np.float32)
+    pc = np.concatenate([c[:7] + jit[:7], c[:7] + 2 * jit[7:14], c[14:]])
+    p_min, p_max = pc - s[:len(pc)] / 2, pc + s[:len(pc)] / 2
+    d = dev()
+    tp = ev.matching(torch.from_numpy(gt_min).to(d), torch.from_numpy(gt_max).to(d), torch.from_numpy(p_min).to(d), torch.from_numpy(p_max).to(d), 0.5)
+    m = oiou.iou_matrix(p_min, p_max, gt_min, gt_max)     # eval.py:67-75 restated on the oracle IoU
+    iou, index = m.max(-1), m.argmax(-1)
+    want = ev._matching(iou > 0.5, index)
+    np.testing.assert_array_equal(tp, want)
+    assert tp.sum() >= 5
+    assert ev.matching(torch.zeros(0, 2, device=d), torch.zeros(0, 2, device=d), torch.from_numpy(p_min).to(d), torch.from_numpy(p_max).to(d), 0.5).sum() == 0

@@ -42,7 +42,7 @@ SIGNATURES = {
     'y2_conv0_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     'y2_maxpool2_fwd': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    'y2_maxpool_fwd': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'y2_maxpool_fwd': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'y2_nchw_to_nhwc': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'y2_decode': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -168,9 +168,9 @@ extern "C" int y2_maxpool2_fwd(const float* x, float* y, int B, int H, int W, in
     return Y2_OK;
 }
 
-extern "C" int y2_maxpool_fwd(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, int ksize, int stride, int pad, y2_stream_t stream) {
-    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || ldx < C || ldy < C) return Y2_EINVAL;
-    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+extern "C" int y2_maxpool_fwd(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, int ksize, int stride, int pad, int pad_end, y2_stream_t stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || pad_end < 0 || ldx < C || ldy < C) return Y2_EINVAL;
+    const int Ho = (H + pad + pad_end - ksize) / stride + 1, Wo = (W + pad + pad_end - ksize) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return Y2_EINVAL;
     const bool vec = !(C & 3) && !(ldx & 3) && !(ldy & 3) && y2_aligned16(x) && y2_aligned16(y);
     const long long total = (long long)B * Ho * Wo * (vec ? C / 4 : C);

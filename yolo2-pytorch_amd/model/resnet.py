@@ -243,7 +243,7 @@ class ResNet(nn.Module):
         _hip.check(L.y2_nchw_to_nhwc(_hip.ptr(x), _hip.ptr(plan['x4']), B, cin0, H, W, plan['cpad'], st), 'y2_nchw_to_nhwc')
         _hip.check(L.y2_conv_fwd(ctypes.byref(plan['stem']), st), 'y2_conv_fwd')
         h1, w1, c1 = plan['stem_hw']
-        _hip.check(L.y2_maxpool_fwd(_hip.ptr(plan['stem_out']), _hip.ptr(plan['pooled']), B, h1, w1, c1, c1, c1, 3, 2, 1, st), 'y2_maxpool_fwd')
+        _hip.check(L.y2_maxpool_fwd(_hip.ptr(plan['stem_out']), _hip.ptr(plan['pooled']), B, h1, w1, c1, c1, c1, 3, 2, 1, 1, st), 'y2_maxpool_fwd')
         _hip.check(L.y2_conv_fwd_batch(plan['arr'], plan['n'], st), 'y2_conv_fwd_batch')
         if prof is not None:
             e1.record()

@@ -132,6 +132,9 @@ class Darknet(nn.Module):
             return out
         return seq('layers1', self.layers1), seq('layers2', self.layers2), seq('layers3', self.layers3)
 
+    def _first_block(self):
+        return self.layers1[0]
+
     def _versions(self):
         return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
@@ -143,7 +146,7 @@ class Darknet(nn.Module):
         L = _hip.lib()
         st = _hip.stream()
         prep = {}
-        first = self.layers1[0]
+        first = self._first_block()
         for blk in [m for m in self.modules() if isinstance(m, Conv2d)]:
             w = blk.conv.weight.detach()
             _hip.require_gpu(w)
@@ -300,4 +303,104 @@ class Darknet(nn.Module):
             out = self.forward_nhwc(x)
         # NCHW view of the NHWC head image: same values/shape as the reference's output; model.Inference's
         # permute(0,2,3,1).contiguous() (model/__init__.py:122) is then free.
+        return out.permute(0, 3, 1, 2)
+
+
+class _PadPool(nn.Module):
+    """Placeholder for ConstantPad2d((0,1,0,1), float32.min) + MaxPool2d(2, stride=1) (model/yolo2.py:151-152): two entries
+    in the reference's nn.Sequential, so two placeholders keep the state_dict indices."""
+
+    def forward(self, x):
+        raise RuntimeError('executed by y2_maxpool_fwd inside Tiny.forward_nhwc')
+
+
+class Tiny(Darknet):
+    """tiny-yolo (model/yolo2.py:140-173): 9 convolutions, state_dict keys `layers.{0,2,4,6,8,10,13,14}.{conv,bn}.*`,
+    `layers.15.conv.{weight,bias}`; xavier_normal init.  Inference through the same kernels as Darknet (conv0 + LDS-DMA
+    convolutions with fused pools); the stride-1 padded pool after layers.10 is one y2_maxpool_fwd launch."""
+
+    def __init__(self, config_channels, anchors, num_cls, channels=16):
+        nn.Module.__init__(self)
+        layers = []
+        bn = config_channels.config.getboolean('batch_norm', 'enable')
+        for _ in range(5):
+            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
+            layers.append(_Pool())
+            channels *= 2
+        layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
+        layers.append(_PadPool())
+        layers.append(_PadPool())
+        channels *= 2
+        for _ in range(2):
+            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
+        layers.append(Conv2d(config_channels.channels, model.output_channels(len(anchors), num_cls), 1, bn=False, act=False))
+        self.layers = nn.Sequential(*layers)
+        self.init()
+        self._cache = None
+        self._plan_cache = None
+        self.grad_ready_hook = None
+        self.profile = None
+
+    def init(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _first_block(self):
+        return self.layers[0]
+
+    def forward_nhwc(self, x):
+        _hip.require_gpu(x)
+        L = _hip.lib()
+        x = _hip.f32c(x)
+        B, cin0, H, W = x.shape
+        if H % 32 or W % 32:
+            raise ValueError('input size must be a multiple of 32 (got %dx%d)' % (H, W))
+        dev = x.device
+        prep = self._prepare_eval(dev)
+        st = _hip.stream()
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        mods = list(self.layers)
+        blk0 = mods[0]
+        wp, scale, shift = prep[blk0]
+        c = blk0.conv.weight.shape[0]
+        cur = new(B, H // 2, W // 2, c)
+        _hip.check(L.y2_conv0_fwd(_hip.ptr(x), _hip.ptr(wp), _hip.ptr(scale), _hip.ptr(shift), None, _hip.ptr(cur), None,
+                                  B, H, W, cin0, c, 0, c, LEAKY if blk0.has_act else 1.0, st), 'y2_conv0_fwd')
+        h, w, ld = H // 2, W // 2, c
+        i = 2
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, Conv2d):
+                c = m.conv.weight.shape[0]
+                pool = i + 1 < len(mods) and isinstance(mods[i + 1], _Pool)
+                if pool:
+                    out = new(B, h // 2, w // 2, c)
+                    p, _ = self._conv_params(prep, m, cur, B, h, w, ld, y_pool=out, ldp=c)
+                else:
+                    out = new(B, h, w, c)
+                    p, _ = self._conv_params(prep, m, cur, B, h, w, ld, y=out, ldy=c)
+                _hip.autotune_conv(p, dev)
+                _hip.conv_workspace(p, dev)
+                _hip.check(L.y2_conv_fwd(ctypes.byref(p), st), 'y2_conv_fwd')
+                cur, ld = out, c
+                if pool:
+                    h, w = h // 2, w // 2
+                    i += 1
+            elif isinstance(m, _PadPool):
+                out = new(B, h, w, ld)
+                _hip.check(L.y2_maxpool_fwd(_hip.ptr(cur), _hip.ptr(out), B, h, w, ld, ld, ld, 2, 1, 0, 1, st), 'y2_maxpool_fwd')
+                cur = out
+                i += 1          # the pad + pool pair
+            i += 1
+        return cur
+
+    def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError('model.yolo2.Tiny: only the inference path runs on the HIP kernels so far')
+        with torch.no_grad():
+            out = self.forward_nhwc(x)
         return out.permute(0, 3, 1, 2)
