@@ -101,7 +101,7 @@ def train_leg(args, dev, world, rank, barrier):
     import train as y2train
     from oracle import loss as oloss
     from oracle import synth
-    inf, anchors, sd = build_model(args.classes, dev)
+    inf, anchors, sd = build_model(args.classes, dev, args.model)
     del sd
     inf.train()
     wrapped = y2train.ensure_model(inf)
@@ -125,8 +125,9 @@ def train_leg(args, dev, world, rank, barrier):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
-    flops = 87.78e9 * B * args.train_steps * world * (S / 416.0) ** 2      # fwd + wgrad + dgrad (all but first conv)
-    out = {'metric': 'images/sec (416x416) train, Darknet-19 YOLOv2 VOC-20', 'value': round(B * args.train_steps * world / dt, 2), 'unit': 'images/sec',
+    per_img = 87.78e9 * (S / 416.0) ** 2 if args.model == 'darknet' else 3 * 60.85e9 * (S / 608.0) ** 2   # fwd + wgrad + dgrad
+    flops = per_img * B * args.train_steps * world
+    out = {'metric': 'images/sec (%dx%d) train, %s YOLOv2 %d classes' % (S, S, 'Darknet-19' if args.model == 'darknet' else args.model, args.classes), 'value': round(B * args.train_steps * world / dt, 2), 'unit': 'images/sec',
            'ms_per_step': round(dt / args.train_steps * 1e3, 3), 'steps': args.train_steps, 'per_gpu_batch': B, 'global_batch': B * world,
            'parallelism': 'dp%d (RCCL all-reduce, bucketed, overlapped with backward)' % world if world > 1 else 'single GPU',
            'optimizer': 'torch.optim.SGD(lr=1e-3, momentum=0.9)', 'loss_total': float(r['loss_total']),
@@ -168,7 +169,6 @@ def main():
     inf, anchors, sd = build_model(args.classes, dev, args.model)
     dnn = inf.dnn
     if args.model != 'darknet':
-        args.train_steps = 0
         args.cpu_sample = 0
     x = synth.images(args.batch, args.size, seed=1 + rank).to(dev)   # resident in HBM before timing
 

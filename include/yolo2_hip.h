@@ -92,6 +92,9 @@ typedef struct y2_conv_params {
     int32_t ldr;
     int32_t stride;      /* 0 or 1 = stride 1; 2 = the strided convs of model/resnet.py:31,71,111 */
     int32_t pad_plus1;   /* 0 = "same" padding (k-1)/2; otherwise padding + 1 */
+    int32_t transposed;  /* != 0: data gradient of a conv with this (ksize, stride, pad): x = dz [B,H,W,Cin=Cout_fwd], w = y2_pack_weight
+                            mode 1 of the forward weight, result [B,out_h,out_w,Cout=Cin_fwd] (fractionally strided convolution) */
+    int32_t out_h, out_w; /* transposed only: spatial size of the forward conv's input */
     int32_t reserved;
 } y2_conv_params;
 
@@ -186,6 +189,11 @@ int y2_nms(const float* score, const float* yx_min, const float* yx_max, const i
 int y2_conv_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int ldx, int Cout, int ldz,
                   int ksize, y2_stream_t stream);
 
+/* The same for any kernel size <= 7, stride and padding (model/resnet.py:31,71,79,111): x [B,Hi,Wi,Cin] is the conv INPUT, dz the
+ * gradient of its output [B,(Hi+2p-k)/s+1,(Wi+2p-k)/s+1,Cout]. */
+int y2_conv_wgrad_ex(const float* x, const float* dz, float* dw, int B, int Hi, int Wi, int Cin, int ldx, int Cout, int ldz,
+                     int ksize, int stride, int pad, y2_stream_t stream);
+
 /* Weight gradient of the first layer (model/yolo2.py:78): x is the plugin's NCHW input [B,Cin<=3,H,W], dz NHWC with pixel
  * stride ldz, Cout <= 64.  dw is the state_dict layout [Cout][Cin][3][3], pre-zeroed (partials are added atomically). */
 int y2_conv0_wgrad(const float* x_nchw, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, int ldz, y2_stream_t stream);
@@ -211,6 +219,21 @@ int y2_bn_act_fwd(const float* z, const float* scale, const float* shift, float 
 int y2_bn_act_bwd(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,
                   float slope, const float* dy_full, int ldf, int foff, int fmode, const float* dy_pool, int ldp, int poff,
                   double* sums, float* dz, int ldd, int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream);
+
+/* Extended forms for residual networks (model/resnet.py:29-104): `residual` (pixel stride ldr) is added before the
+ * activation in the forward; the backward takes an optional second full-resolution gradient source dy_full2 (fan-out),
+ * uses the residual to rebuild the activation mask and can emit dres = gradient w.r.t. the residual input. */
+int y2_bn_act_fwd_ex(const float* z, const float* scale, const float* shift, float slope, const float* residual, int ldr, float* y, float* y_pool,
+                     int B, int H, int W, int C, int ldz, int ldy, int coff, int ldp, int poff, int out_mode, y2_stream_t stream);
+int y2_bn_act_bwd_ex(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,
+                     float slope, const float* dy_full, int ldf, int foff, int fmode, const float* dy_pool, int ldp, int poff,
+                     const float* dy_full2, int ld2, const float* residual, int ldr, float* dres, int lddr,
+                     double* sums, float* dz, int ldd, int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream);
+
+/* Backward of y2_maxpool_fwd (overlapping windows allowed): dx[B,H,W,C] from dy (+ optional dy2) [B,Ho,Wo,C]; the gradient of a
+ * window goes to its first maximum (ATen semantics). */
+int y2_maxpool_bwd(const float* x, const float* dy, const float* dy2, float* dx, int B, int H, int W, int C, int ldx, int ldy, int lddx,
+                   int ksize, int stride, int pad, int pad_end, y2_stream_t stream);
 
 /* out[c] += sum_m x[m*ld + c] (fp64; conv-bias gradient of the head, model/yolo2.py:112).  out pre-zeroed. */
 int y2_colsum(const float* x, long long M, int C, int ld, double* out, y2_stream_t stream);

@@ -67,25 +67,31 @@ def init_state_dict(arch='resnet50', num_anchors=5, num_cls=80, seed=0, width=64
     return collections.OrderedDict((k, v.to(dtype)) for k, v in sd.items())
 
 
-def _bn(x, sd, prefix):
+def _bn(x, sd, prefix, training=False, stats=None):
+    if training:
+        rm, rv = sd[prefix + '.running_mean'].clone(), sd[prefix + '.running_var'].clone()
+        y = F.batch_norm(x, rm, rv, sd[prefix + '.weight'], sd[prefix + '.bias'], True, 0.1, BN_EPS)
+        if stats is not None:
+            stats[prefix] = (rm, rv)
+        return y
     return F.batch_norm(x, sd[prefix + '.running_mean'], sd[prefix + '.running_var'], sd[prefix + '.weight'], sd[prefix + '.bias'], False, 0.1, BN_EPS)
 
 
-def forward(x, sd, arch='resnet50'):
+def forward(x, sd, arch='resnet50', training=False, stats=None):
     """model/resnet.py:149-158 (eval mode)."""
     width = sd['conv1.weight'].shape[0]
-    x = F.relu(_bn(F.conv2d(x, sd['conv1.weight'], stride=2, padding=3), sd, 'bn1'))
+    x = F.relu(_bn(F.conv2d(x, sd['conv1.weight'], stride=2, padding=3), sd, 'bn1', training, stats))
     x = F.max_pool2d(x, 3, 2, 1)
     for prefix, kind, ch, stride in block_specs(arch, width):
         residual = x
         if kind == 'bottleneck':
-            out = F.relu(_bn(F.conv2d(x, sd[prefix + '.conv1.weight']), sd, prefix + '.bn1'))
-            out = F.relu(_bn(F.conv2d(out, sd[prefix + '.conv2.weight'], stride=stride, padding=1), sd, prefix + '.bn2'))
-            out = _bn(F.conv2d(out, sd[prefix + '.conv3.weight']), sd, prefix + '.bn3')
+            out = F.relu(_bn(F.conv2d(x, sd[prefix + '.conv1.weight']), sd, prefix + '.bn1', training, stats))
+            out = F.relu(_bn(F.conv2d(out, sd[prefix + '.conv2.weight'], stride=stride, padding=1), sd, prefix + '.bn2', training, stats))
+            out = _bn(F.conv2d(out, sd[prefix + '.conv3.weight']), sd, prefix + '.bn3', training, stats)
         else:
-            out = F.relu(_bn(F.conv2d(x, sd[prefix + '.conv1.weight'], stride=stride, padding=1), sd, prefix + '.bn1'))
-            out = _bn(F.conv2d(out, sd[prefix + '.conv2.weight'], padding=1), sd, prefix + '.bn2')
+            out = F.relu(_bn(F.conv2d(x, sd[prefix + '.conv1.weight'], stride=stride, padding=1), sd, prefix + '.bn1', training, stats))
+            out = _bn(F.conv2d(out, sd[prefix + '.conv2.weight'], padding=1), sd, prefix + '.bn2', training, stats)
         if prefix + '.downsample.0.weight' in sd:
-            residual = _bn(F.conv2d(x, sd[prefix + '.downsample.0.weight'], stride=stride), sd, prefix + '.downsample.1')
+            residual = _bn(F.conv2d(x, sd[prefix + '.downsample.0.weight'], stride=stride), sd, prefix + '.downsample.1', training, stats)
         x = F.relu(out + residual)
     return F.conv2d(x, sd['conv.weight'], sd['conv.bias'])

@@ -252,3 +252,96 @@ def test_darknet_training_step_matches_oracle_autograd(bn):
         np.testing.assert_allclose(bufs[prefix + '.bn.running_mean'].cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(bufs[prefix + '.bn.running_var'].cpu().numpy(), rv.numpy(), rtol=1e-4)
     print('worst relative gradient error', worst)
+
+
+# ------------------------------------------------------------------ ResNet training path (BASELINE config 5)
+@pytest.mark.parametrize('B,cin,cout,H,W,k,stride,pad', [(2, 16, 32, 19, 19, 3, 2, 1), (2, 32, 64, 20, 20, 1, 2, 0), (1, 4, 64, 32, 40, 7, 2, 3), (2, 64, 64, 10, 10, 3, 2, 1), (2, 8, 16, 9, 9, 3, 1, 1)])
+def test_strided_wgrad_and_transposed_dgrad(B, cin, cout, H, W, k, stride, pad):
+    import _hip
+    L = _hip.lib()
+    g = torch.Generator().manual_seed(cin + cout + H + k)
+    x = torch.randn(B, cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(cout, cin, k, k, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    y = F.conv2d(x, w, stride=stride, padding=pad)
+    dz = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dz)
+    Ho, Wo = y.shape[-2:]
+    d = dev()
+    xd, dzd = nhwc(x.detach().float()).to(d), nhwc(dz.float()).to(d)
+    dwp = torch.zeros(w.numel(), device=d)
+    _hip.check(L.y2_conv_wgrad_ex(_hip.ptr(xd), _hip.ptr(dzd), _hip.ptr(dwp), B, H, W, cin, cin, cout, cout, k, stride, pad, _hip.stream()), 'wgrad_ex')
+    dw = torch.empty(cout, cin, k, k, device=d)
+    _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cout, cin, k, _hip.stream()), 'unpack')
+    assert rel(dw, w.grad) <= TOL
+    wd = torch.empty(w.numel(), device=d)
+    wdev = w.detach().float().to(d).contiguous()
+    _hip.check(L.y2_pack_weight(_hip.ptr(wdev), _hip.ptr(wd), cout, cin, k, 1, _hip.stream()), 'pack1')
+    dx = torch.empty(B, H, W, cin, device=d)
+    p = _hip.ConvParams()
+    p.x, p.w, p.y = dzd.data_ptr(), wd.data_ptr(), dx.data_ptr()
+    p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize, p.ldy, p.slope = B, Ho, Wo, cout, cout, cin, k, cin, 1.0
+    if stride == 1:
+        p.stride, p.pad_plus1 = 1, k - 1 - pad + 1
+    else:
+        p.stride, p.pad_plus1, p.transposed, p.out_h, p.out_w = stride, pad + 1, 1, H, W
+    _hip.conv_workspace(p, d)
+    _hip.check(L.y2_conv_fwd(ctypes.byref(p), _hip.stream()), 'dgrad')
+    assert rel(dx.permute(0, 3, 1, 2), x.grad) <= TOL
+
+
+def test_maxpool3x3s2_forward_backward():
+    import _hip
+    L = _hip.lib()
+    d = dev()
+    for (B, C, H, W) in ((2, 8, 12, 14), (1, 6, 9, 9)):
+        x = torch.randn(B, C, H, W, dtype=torch.float64, requires_grad=True)
+        y = F.max_pool2d(x, 3, 2, 1)
+        dy = torch.randn(y.shape, dtype=torch.float64)
+        dy2 = torch.randn(y.shape, dtype=torch.float64)
+        y.backward(dy + dy2)
+        xd = nhwc(x.detach().float()).to(d)
+        Ho, Wo = y.shape[-2:]
+        yo = torch.empty(B, Ho, Wo, C, device=d)
+        _hip.check(L.y2_maxpool_fwd(_hip.ptr(xd), _hip.ptr(yo), B, H, W, C, C, C, 3, 2, 1, 1, _hip.stream()), 'pool')
+        assert torch.equal(yo.cpu().permute(0, 3, 1, 2), y.detach().float())
+        dx = torch.empty(B, H, W, C, device=d)
+        a, b = nhwc(dy.float()).to(d), nhwc(dy2.float()).to(d)
+        _hip.check(L.y2_maxpool_bwd(_hip.ptr(xd), _hip.ptr(a), _hip.ptr(b), _hip.ptr(dx), B, H, W, C, C, C, C, 3, 2, 1, 1, _hip.stream()), 'pool_bwd')
+        np.testing.assert_allclose(dx.cpu().permute(0, 3, 1, 2).numpy(), x.grad.float().numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('arch', ['resnet18', 'resnet50'])
+def test_resnet_training_step_matches_oracle_autograd(arch):
+    import model
+    import model.resnet
+    from oracle import resnet as ores
+    C = 20
+    sd = ores.init_state_dict(arch, 5, C, seed=0, width=8, head_scale=0.25)
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1'}, 'model': {'pretrained': '0'}})
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    net = getattr(model.resnet, arch)(model.ConfigChannels(cfg, sd), anchors, C)
+    net.load_state_dict(sd, strict=False)
+    inf = model.Inference(cfg, net, anchors).to(dev()).train()
+    S, B = 96, 3
+    x = synth.images(B, S, seed=1)
+    data = synth.norm_data(synth.labels(B, S, C, seed=2), S, S, S // 32, S // 32)
+    pred = model._inference(inf, x.to(dev()))
+    loss, _ = model.loss(anchors, data, pred, 0.6)
+    sum(loss[k] * oloss.HPARAM[k] for k in loss).backward()
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    stats = {}
+    f = ores.forward(x.double(), sd64, arch, training=True, stats=stats)
+    lo, _ = oloss.loss(anchors.double(), {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}, ohead.decode(f, anchors.double()), 0.6)
+    oloss.total(lo).backward()
+    for k in lo:
+        np.testing.assert_allclose(loss[k].item(), lo[k].item(), rtol=5e-4)   # fp32 vs fp64 through up to 53 batch-stat BN layers on 27 samples per channel
+    ours = dict(net.named_parameters())
+    for k, v in sd64.items():
+        if v.requires_grad:
+            assert ours[k].grad is not None, k
+            assert rel(ours[k].grad, v.grad) <= 2e-3, (k, rel(ours[k].grad, v.grad))
+    bufs = dict(net.named_buffers())
+    for prefix, (rm, rv) in stats.items():
+        np.testing.assert_allclose(bufs[prefix + '.running_mean'].cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(bufs[prefix + '.running_var'].cpu().numpy(), rv.numpy(), rtol=1e-4)

@@ -27,7 +27,8 @@ class ConvParams(ctypes.Structure):
                 ('ldy', ctypes.c_int32), ('coff', ctypes.c_int32), ('ldp', ctypes.c_int32), ('poff', ctypes.c_int32),
                 ('out_mode', ctypes.c_int32), ('slope', c_float), ('tile', ctypes.c_int32),
                 ('workspace', c_void_p), ('workspace_bytes', ctypes.c_int64),
-                ('residual', c_void_p), ('ldr', ctypes.c_int32), ('stride', ctypes.c_int32), ('pad_plus1', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('residual', c_void_p), ('ldr', ctypes.c_int32), ('stride', ctypes.c_int32), ('pad_plus1', ctypes.c_int32),
+                ('transposed', ctypes.c_int32), ('out_h', ctypes.c_int32), ('out_w', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 # name -> argtypes; restype is int for everything except y2_build_info
@@ -50,11 +51,17 @@ SIGNATURES = {
     'y2_iou_matrix': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     'y2_iou_pair': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p],
     'y2_conv_wgrad': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'y2_conv_wgrad_ex': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'y2_conv0_wgrad': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'y2_bn_finalize': [c_void_p, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     'y2_bn_act_fwd': [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'y2_bn_act_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
                       c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'y2_bn_act_fwd_ex': [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'y2_bn_act_bwd_ex': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
+                         c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                         c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'y2_maxpool_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'y2_colsum': [c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p, c_void_p],
     'y2_f64_to_f32': [c_void_p, c_void_p, c_int, ctypes.c_double, c_void_p],
     'y2_decode_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
@@ -166,7 +173,7 @@ def autotune_conv(params, dev):
     look the answer up.  The outputs written while timing are the real outputs (same arithmetic for every tile).
     Never called while a hipGraph is being captured (plans are built during warm-up)."""
     key = (params.B, params.H, params.W, params.Cin, params.ldx, params.Cout, params.ksize, bool(params.y), bool(params.y_pool),
-           bool(params.stats), params.out_mode, params.stride, params.pad_plus1, bool(params.residual), str(dev))
+           bool(params.stats), params.out_mode, params.stride, params.pad_plus1, bool(params.residual), params.transposed, params.out_h, params.out_w, str(dev))
     hit = _TUNE.get(key)
     if hit is not None:
         params.tile = hit

@@ -60,6 +60,8 @@ struct ConvArgs {
     y2_fastdiv d_hw, d_w, d_w2;         // exact division by H*W, W, 2*W (row decode)
     // general convolution (GEN kernels: any stride / kernel size / padding, K = k*k*Cin treated as one linear axis)
     int stride, pad, KW, Ho, Wo, K;
+    int tstride;                        // > 1: transposed (fractionally strided) convolution = data gradient of a strided conv
+    y2_fastdiv d_ts;
     const float* res;                   // optional residual added before the activation: res[m*ldr + n]
     int ldr;
     y2_fastdiv d_cin, d_kw, d_howo, d_wo;
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
                 a_yb[i] = yo * a.stride - a.pad;
                 a_xb[i] = xo * a.stride - a.pad;
                 a_base[i] = (unsigned)((long long)((b * a.H + a_yb[i]) * a.W + a_xb[i]) * a.ldx * 4);   // may wrap: only used when the tap is valid
+                a_mask[i] = (unsigned)(b * a.H * a.W);     // transposed mode: pixel index of the image's first input pixel
             } else {
                 a_yb[i] = -(1 << 20); a_xb[i] = -(1 << 20); a_base[i] = 0;
             }
@@ -442,11 +445,24 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
             const int ky = (int)y2_div((uint32_t)tp, a.d_kw);
             const int kx = tp - ky * a.KW;
             const unsigned toff = (unsigned)(((ky * a.W + kx) * a.ldx + c) * 4);
+            if (a.tstride > 1) {
+                // transposed convolution (data gradient of a stride-s conv): the input (dz) is read at (yu/s, xu/s) where
+                // (yu, xu) = output pixel - pad + tap lies on the stride grid; other taps contribute nothing
 #pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                const bool ok = kok && (unsigned)(a_yb[i] + ky) < (unsigned)a.H && (unsigned)(a_xb[i] + kx) < (unsigned)a.W;
-                const unsigned voff = ok ? a_base[i] + toff : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 32 * BK), 16, (int)voff, 0, 0, 0);
+                for (int i = 0; i < AR; ++i) {
+                    const int yu = a_yb[i] + ky, xu = a_xb[i] + kx;
+                    const unsigned yq = y2_div((unsigned)yu, a.d_ts), xq = y2_div((unsigned)xu, a.d_ts);
+                    const bool ok = kok && yu >= 0 && xu >= 0 && (int)yq * a.tstride == yu && (int)xq * a.tstride == xu && yq < (unsigned)a.H && xq < (unsigned)a.W;
+                    const unsigned voff = ok ? (unsigned)(((size_t)(a_mask[i] + yq * a.W + xq) * a.ldx + c) * 4) : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 32 * BK), 16, (int)voff, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < AR; ++i) {
+                    const bool ok = kok && (unsigned)(a_yb[i] + ky) < (unsigned)a.H && (unsigned)(a_xb[i] + kx) < (unsigned)a.W;
+                    const unsigned voff = ok ? a_base[i] + toff : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 32 * BK), 16, (int)voff, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int i = 0; i < BR; ++i) {
@@ -764,9 +780,14 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
     if (p->ldx < p->Cin) return Y2_EINVAL;
     const int stride = p->stride > 0 ? p->stride : 1;
     const int pad = p->pad_plus1 > 0 ? p->pad_plus1 - 1 : (p->ksize - 1) / 2;
-    const int Ho = (p->H + 2 * pad - p->ksize) / stride + 1, Wo = (p->W + 2 * pad - p->ksize) / stride + 1;
+    const bool transposed = p->transposed != 0;
+    int Ho = (p->H + 2 * pad - p->ksize) / stride + 1, Wo = (p->W + 2 * pad - p->ksize) / stride + 1;
+    if (transposed) {   // x is the gradient of a stride-s conv output; the result has the explicit size out_h x out_w of that conv's input
+        Ho = p->out_h; Wo = p->out_w;
+        if (Ho <= 0 || Wo <= 0 || (Ho + 2 * pad - p->ksize) / stride + 1 != p->H || (Wo + 2 * pad - p->ksize) / stride + 1 != p->W) return Y2_EINVAL;
+    }
     if (Ho <= 0 || Wo <= 0) return Y2_EINVAL;
-    const bool standard = stride == 1 && pad == (p->ksize - 1) / 2 && (p->ksize == 1 || p->ksize == 3);
+    const bool standard = !transposed && stride == 1 && pad == (p->ksize - 1) / 2 && (p->ksize == 1 || p->ksize == 3);
     if (p->y != nullptr && p->out_mode == 0 && p->ldy < p->coff + p->Cout) return Y2_EINVAL;
     if (p->y != nullptr && p->out_mode == 1 && (p->ldy < p->coff + 4 * p->Cout || (p->H & 1) || (p->W & 1))) return Y2_EINVAL;
     if (p->out_mode != 0 && p->out_mode != 1) return Y2_EINVAL;
@@ -791,6 +812,11 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
     a.full_tiles = 0x7fffffff; a.ksplit = 1; a.partial = nullptr;
     a.d_hw = y2_make_fastdiv((uint32_t)(p->H * p->W)); a.d_w = y2_make_fastdiv((uint32_t)p->W); a.d_w2 = y2_make_fastdiv((uint32_t)(2 * p->W));
     a.stride = stride; a.pad = pad; a.KW = p->ksize; a.Ho = Ho; a.Wo = Wo; a.K = a.taps * p->Cin;
+    a.tstride = 1; a.d_ts = y2_make_fastdiv(1);
+    if (transposed) {   // correlation of the s-dilated input with the (already 180-degree-rotated, y2_pack_weight mode 1) filter, padding k-1-pad
+        a.tstride = stride; a.d_ts = y2_make_fastdiv((uint32_t)stride);
+        a.stride = 1; a.pad = p->ksize - 1 - pad;
+    }
     a.res = p->residual; a.ldr = p->ldr;
     a.d_cin = y2_make_fastdiv((uint32_t)p->Cin); a.d_kw = y2_make_fastdiv((uint32_t)p->ksize);
     a.d_howo = y2_make_fastdiv((uint32_t)(Ho * Wo)); a.d_wo = y2_make_fastdiv((uint32_t)Wo);

@@ -26,7 +26,8 @@ struct WgradArgs {
     const float* x;     // [B,H,W,Cin] pixel stride ldx
     const float* dz;    // [B,H,W,Cout] pixel stride ldz
     float* dw;          // [Cout][taps*Cin], pre-zeroed
-    int B, H, W, Cin, ldx, Cout, ldz, taps;
+    int B, H, W, Cin, ldx, Cout, ldz, taps;   // H, W: spatial size of dz (the conv OUTPUT)
+    int Hi, Wi, stride, pad, KW;              // conv input size, stride, padding, kernel width
     int M, tiles_i, tiles_j, splits, slabs_per_split;
     unsigned x_bytes, dz_bytes;
 };
@@ -76,15 +77,16 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     const bool b_ok = jb < ncols;
     const int tap = b_ok ? jb / a.Cin : 0;
     const int ci = b_ok ? jb - tap * a.Cin : 0;
-    const int dy = (a.taps == 9) ? tap / 3 - 1 : 0;
-    const int dx = (a.taps == 9) ? tap % 3 - 1 : 0;
-    // (y, x) of this thread's 4 staged pixels in the first slab; advanced by 32 pixels per slab
-    int py[4], px[4];
+    const int dy = tap / a.KW - a.pad;         // input row = yo*stride + dy
+    const int dx = tap % a.KW - a.pad;
+    // (image, y, x) of this thread's 4 staged OUTPUT pixels in the first slab; advanced by 32 pixels per slab
+    int pb[4], py[4], px[4];
     const int q32 = KS / a.W, r32 = KS % a.W;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int m = slab_lo * KS + prow + 8 * p;
-        const int idx = m % (a.H * a.W);
+        pb[p] = m / (a.H * a.W);
+        const int idx = m - pb[p] * (a.H * a.W);
         py[p] = idx / a.W;
         px[p] = idx - py[p] * a.W;
     }
@@ -104,8 +106,9 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         for (int p = 0; p < 4; ++p) {
             const int m = slab * KS + prow + 8 * p;
             const bool mok = m < a.M;
-            const bool in = (unsigned)(py[p] + dy) < (unsigned)a.H && (unsigned)(px[p] + dx) < (unsigned)a.W;
-            const unsigned vb = (mok && b_ok && in) ? (unsigned)(((size_t)(m + dy * a.W + dx) * a.ldx + ci) * 4) : OOB;
+            const int yi = py[p] * a.stride + dy, xi = px[p] * a.stride + dx;
+            const bool in = (unsigned)yi < (unsigned)a.Hi && (unsigned)xi < (unsigned)a.Wi;
+            const unsigned vb = (mok && b_ok && in) ? (unsigned)(((size_t)((pb[p] * a.Hi + yi) * a.Wi + xi) * a.ldx + ci) * 4) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sb + p * 8 * 128), 16, (int)vb, 0, 0, 0);
         }
         // advance the pixel coordinates to the next slab (+32 pixels, row-major, wraps at image boundaries)
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         for (int p = 0; p < 4; ++p) {
             px[p] += r32; py[p] += q32;
             if (px[p] >= a.W) { px[p] -= a.W; py[p] += 1; }
-            if (py[p] >= a.H) py[p] %= a.H;
+            while (py[p] >= a.H) { py[p] -= a.H; pb[p] += 1; }
         }
     };
 
@@ -180,18 +183,21 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 
 // dW[Cout][k*k][Cin] (packed layout, y2_unpack_weight_grad converts to the state_dict layout) += / = wgrad.
 // dw must be zero-filled by the caller when the kernel decides to split (it always may): zero it unconditionally.
-extern "C" int y2_conv_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int ldx, int Cout, int ldz,
-                             int ksize, y2_stream_t stream) {
-    if (!x || !dz || !dw || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return Y2_EINVAL;
-    if (ksize != 1 && ksize != 3) return Y2_ENOSUP;
+extern "C" int y2_conv_wgrad_ex(const float* x, const float* dz, float* dw, int B, int Hi, int Wi, int Cin, int ldx, int Cout, int ldz,
+                                int ksize, int stride, int pad, y2_stream_t stream) {
+    if (!x || !dz || !dw || B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0) return Y2_EINVAL;
+    if (ksize < 1 || ksize > 7 || stride < 1 || pad < 0) return Y2_ENOSUP;
     if (ldx < Cin || ldz < Cout) return Y2_EINVAL;
     if ((Cin & 3) || (ldx & 3) || (Cout & 3) || (ldz & 3) || !y2_aligned16(x) || !y2_aligned16(dz)) return Y2_EALIGN;
+    const int H = (Hi + 2 * pad - ksize) / stride + 1, W = (Wi + 2 * pad - ksize) / stride + 1;   // dz spatial size
+    if (H <= 0 || W <= 0) return Y2_EINVAL;
     const long long M = (long long)B * H * W;
-    const unsigned long long xb = (unsigned long long)M * ldx * 4ull, zb = (unsigned long long)M * ldz * 4ull;
+    const unsigned long long xb = (unsigned long long)B * Hi * Wi * ldx * 4ull, zb = (unsigned long long)M * ldz * 4ull;
     if (M > 0x3fffffffLL || xb >= 0x7fffffffull || zb >= 0x7fffffffull) return Y2_ENOSUP;
     WgradArgs a;
     a.x = x; a.dz = dz; a.dw = dw;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.Cout = Cout; a.ldz = ldz; a.taps = ksize * ksize;
+    a.Hi = Hi; a.Wi = Wi; a.stride = stride; a.pad = pad; a.KW = ksize;
     a.M = (int)M;
     const int TI = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
     a.tiles_i = y2_cdiv(Cout, TI);
@@ -314,4 +320,10 @@ extern "C" int y2_conv0_wgrad(const float* x_nchw, const float* dz, float* dw, i
     else hipLaunchKernelGGL((conv0_wgrad_kernel<2>), dim3(grid), dim3(256), 0, y2_s(stream), a);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
+}
+
+extern "C" int y2_conv_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int ldx, int Cout, int ldz,
+                             int ksize, y2_stream_t stream) {
+    if (ksize != 1 && ksize != 3) return Y2_ENOSUP;
+    return y2_conv_wgrad_ex(x, dz, dw, B, H, W, Cin, ldx, Cout, ldz, ksize, 1, (ksize - 1) / 2, stream);
 }

@@ -47,6 +47,7 @@ struct ActArgs {
     float* y; float* y_pool;
     int B, H, W, C, ldz, ldy, coff, ldp, poff, out_mode;
     float slope;
+    const float* res; int ldr;     // optional residual added before the activation (model/resnet.py:59,101)
 };
 
 __device__ __forceinline__ float act1(float z, float sc, float sh, float slope) {
@@ -77,10 +78,13 @@ __global__ void bn_act_fwd_kernel(const ActArgs a, long long total) {
             float v[CV];
             if (CV == 4) {
                 const f32x4 zz = *reinterpret_cast<const f32x4*>(a.z + pix * a.ldz + c);
+                f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+                if (a.res != nullptr) rr = *reinterpret_cast<const f32x4*>(a.res + pix * a.ldr + c);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act1(zz[e], sc[e], sh[e], a.slope);
+                for (int e = 0; e < 4; ++e) { const float u = zz[e] * sc[e] + sh[e] + rr[e]; v[e] = u > 0.f ? u : u * a.slope; }
             } else {
-                v[0] = act1(a.z[pix * a.ldz + c], sc[0], sh[0], a.slope);
+                const float u = a.z[pix * a.ldz + c] * sc[0] + sh[0] + (a.res != nullptr ? a.res[pix * a.ldr + c] : 0.f);
+                v[0] = u > 0.f ? u : u * a.slope;
             }
             if (a.y != nullptr) {
                 long long o;
@@ -111,6 +115,9 @@ __global__ void bn_act_fwd_kernel(const ActArgs a, long long total) {
 struct ActBwdArgs {
     const float* z; const float* scale; const float* shift; const float* mean; const float* invstd; const float* gamma;
     const float* dy_full; const float* dy_pool;
+    const float* dy_full2; int ld2;     // optional second full-resolution gradient source (fan-out of a residual network)
+    const float* res; int ldr;          // residual that was added before the activation (decides the ReLU mask)
+    float* dres; int lddr;              // optional output: gradient w.r.t. that residual (= gradient of the pre-activation sum)
     double* sums;      // [2C]: sum g, sum g*zhat
     float* dz;         // [B,H,W,C] stride ldd
     int B, H, W, C, ldz, ldf, foff, fmode, ldp, poff, ldd;
@@ -166,6 +173,13 @@ __global__ void bn_act_bwd_kernel(const ActBwdArgs a, long long total) {
             } else zv[q][0] = a.z[pixs[q] * a.ldz + c];
 #pragma unroll
             for (int e = 0; e < CV; ++e) yv[q][e] = zv[q][e] * sc[e] + sh[e];   // u (pre-activation)
+            if (a.res != nullptr) {
+                if (CV == 4) {
+                    const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + pixs[q] * a.ldr + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) yv[q][e] += rr[e];
+                } else yv[q][0] += a.res[pixs[q] * a.ldr + c];
+            }
         }
         // pooled gradient -> first maximal activated value in scan order
         float dp[CV];
@@ -203,10 +217,18 @@ __global__ void bn_act_bwd_kernel(const ActBwdArgs a, long long total) {
                     for (int e = 0; e < 4; ++e) g[e] += d[e]; }
                 else g[0] += a.dy_full[o];
             }
-            float outv[CV];
+            if (a.dy_full2 != nullptr) {
+                const long long o = pixs[q] * a.ld2 + c;
+                if (CV == 4) { const f32x4 d = *reinterpret_cast<const f32x4*>(a.dy_full2 + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] += d[e]; }
+                else g[0] += a.dy_full2[o];
+            }
+            float outv[CV], gev[CV];
 #pragma unroll
             for (int e = 0; e < CV; ++e) {
                 const float ge = g[e] * (yv[q][e] > 0.f ? 1.f : a.slope);      // through LeakyReLU
+                gev[e] = ge;
                 const float zh = (zv[q][e] - mu[e]) * is[e];
                 if (!APPLY) { s1[e] += ge; s2[e] += ge * zh; }
                 else outv[e] = gs[e] * (ge - ma[e] - zh * mb[e]);
@@ -215,6 +237,11 @@ __global__ void bn_act_bwd_kernel(const ActBwdArgs a, long long total) {
                 const long long o = pixs[q] * a.ldd + c;
                 if (CV == 4) { f32x4 w = {outv[0], outv[1], outv[2], outv[3]}; *reinterpret_cast<f32x4*>(a.dz + o) = w; }
                 else a.dz[o] = outv[0];
+                if (a.dres != nullptr) {
+                    const long long r = pixs[q] * a.lddr + c;
+                    if (CV == 4) { f32x4 w = {gev[0], gev[1], gev[2], gev[3]}; *reinterpret_cast<f32x4*>(a.dres + r) = w; }
+                    else a.dres[r] = gev[0];
+                }
             }
         }
     }
@@ -226,6 +253,44 @@ __global__ void bn_act_bwd_kernel(const ActBwdArgs a, long long total) {
             const float v = red[i];
             if (v != 0.f) atomicAdd(a.sums + i, (double)v);
         }
+    }
+}
+
+// nn.MaxPool2d(k, stride, padding) backward on NHWC, gather form: an input element receives the gradient of every window whose
+// FIRST maximum (scan order, strict >, like ATen) it is; windows overlap when k > stride (model/resnet.py:114).
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ dy2, float* __restrict__ dx,
+                                   int H, int W, int Ho, int Wo, int C, int ldx, int ldy, int lddx, int k, int stride, int pad, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long p = i / C;
+        const int xx = (int)(p % W);
+        const long long r = p / W;
+        const int yy = (int)(r % H);
+        const long long b = r / H;
+        float g = 0.f;
+        const int oy_hi = min(Ho - 1, (yy + pad) / stride), ox_hi = min(Wo - 1, (xx + pad) / stride);
+        int oy_lo = (yy + pad - k + stride) / stride; if (yy + pad - k + 1 < 0) oy_lo = 0; if (oy_lo < 0) oy_lo = 0;
+        int ox_lo = (xx + pad - k + stride) / stride; if (xx + pad - k + 1 < 0) ox_lo = 0; if (ox_lo < 0) ox_lo = 0;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                float best = 0.f; int by = -1, bx = -1;
+                for (int ky = 0; ky < k; ++ky) {
+                    const int y2 = oy * stride - pad + ky;
+                    if ((unsigned)y2 >= (unsigned)H) continue;
+                    for (int kx = 0; kx < k; ++kx) {
+                        const int x2 = ox * stride - pad + kx;
+                        if ((unsigned)x2 >= (unsigned)W) continue;
+                        const float v = x[((b * H + y2) * W + x2) * ldx + c];
+                        if (by < 0 || v > best) { best = v; by = y2; bx = x2; }
+                    }
+                }
+                if (by == yy && bx == xx) {
+                    const long long o = ((b * Ho + oy) * Wo + ox) * ldy + c;
+                    g += dy[o];
+                    if (dy2 != nullptr) g += dy2[o];
+                }
+            }
+        dx[p * lddx + c] = g;
     }
 }
 
@@ -476,15 +541,17 @@ extern "C" int y2_bn_finalize(const double* stats, double count, const float* ga
     return Y2_OK;
 }
 
-extern "C" int y2_bn_act_fwd(const float* z, const float* scale, const float* shift, float slope, float* y, float* y_pool,
-                             int B, int H, int W, int C, int ldz, int ldy, int coff, int ldp, int poff, int out_mode, y2_stream_t stream) {
+extern "C" int y2_bn_act_fwd_ex(const float* z, const float* scale, const float* shift, float slope, const float* residual, int ldr, float* y, float* y_pool,
+                                int B, int H, int W, int C, int ldz, int ldy, int coff, int ldp, int poff, int out_mode, y2_stream_t stream) {
     if (!z || (!y && !y_pool) || B <= 0 || H <= 0 || W <= 0 || C <= 0) return Y2_EINVAL;
     const bool pool = y_pool != nullptr;
     if ((pool || out_mode == 1) && ((H & 1) || (W & 1))) return Y2_EINVAL;
     ActArgs a;
     a.z = z; a.scale = scale; a.shift = shift; a.y = y; a.y_pool = y_pool;
     a.B = B; a.H = H; a.W = W; a.C = C; a.ldz = ldz; a.ldy = ldy; a.coff = coff; a.ldp = ldp; a.poff = poff; a.out_mode = out_mode; a.slope = slope;
-    const bool vec = !(C & 3) && !(ldz & 3) && (!y || (!(ldy & 3) && !(coff & 3) && y2_aligned16(y))) && (!pool || (!(ldp & 3) && !(poff & 3) && y2_aligned16(y_pool))) && y2_aligned16(z);
+    a.res = residual; a.ldr = ldr;
+    if (residual != nullptr && ldr < C) return Y2_EINVAL;
+    const bool vec = (!residual || (!(ldr & 3) && y2_aligned16(residual))) && !(C & 3) && !(ldz & 3) && (!y || (!(ldy & 3) && !(coff & 3) && y2_aligned16(y))) && (!pool || (!(ldp & 3) && !(poff & 3) && y2_aligned16(y_pool))) && y2_aligned16(z);
     const long long pix = (long long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
     const long long total = pix * (vec ? C / 4 : C);
     const int grid = stream_grid(total, 256);
@@ -495,9 +562,10 @@ extern "C" int y2_bn_act_fwd(const float* z, const float* scale, const float* sh
     return Y2_OK;
 }
 
-extern "C" int y2_bn_act_bwd(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,
-                             float slope, const float* dy_full, int ldf, int foff, int fmode, const float* dy_pool, int ldp, int poff,
-                             double* sums, float* dz, int ldd, int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream) {
+extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,
+                                float slope, const float* dy_full, int ldf, int foff, int fmode, const float* dy_pool, int ldp, int poff,
+                                const float* dy_full2, int ld2, const float* residual, int ldr, float* dres, int lddr,
+                                double* sums, float* dz, int ldd, int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream) {
     if (!z || (!dy_full && !dy_pool) || !sums || !dz || B <= 0 || H <= 0 || W <= 0 || C <= 0) return Y2_EINVAL;
     if (has_bn && (!mean || !invstd || !gamma)) return Y2_EINVAL;
     const bool pool = dy_pool != nullptr;
@@ -508,7 +576,8 @@ extern "C" int y2_bn_act_bwd(const float* z, const float* scale, const float* sh
     a.dy_full = dy_full; a.dy_pool = dy_pool; a.sums = sums; a.dz = dz;
     a.B = B; a.H = H; a.W = W; a.C = C; a.ldz = ldz; a.ldf = ldf; a.foff = foff; a.fmode = fmode; a.ldp = ldp; a.poff = poff; a.ldd = ldd;
     a.slope = slope; a.n = (double)B * H * W; a.has_bn = has_bn;
-    const bool vec = !(C & 3) && !(ldz & 3) && !(ldd & 3) && y2_aligned16(z) && y2_aligned16(dz) &&
+    a.dy_full2 = dy_full2; a.ld2 = ld2; a.res = residual; a.ldr = ldr; a.dres = dres; a.lddr = lddr;
+    const bool vec = (!dy_full2 || (!(ld2 & 3) && y2_aligned16(dy_full2))) && (!residual || (!(ldr & 3) && y2_aligned16(residual))) && (!dres || (!(lddr & 3) && y2_aligned16(dres))) && !(C & 3) && !(ldz & 3) && !(ldd & 3) && y2_aligned16(z) && y2_aligned16(dz) &&
                      (!dy_full || (!(ldf & 3) && !(foff & 3) && y2_aligned16(dy_full))) && (!pool || (!(ldp & 3) && !(poff & 3) && y2_aligned16(dy_pool)));
     const int Cg = vec ? C / 4 : C;
     const long long pix = (long long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
@@ -534,6 +603,18 @@ extern "C" int y2_bn_act_bwd(const float* z, const float* scale, const float* sh
 #undef Y2_BWD
     Y2_LAUNCH_CHECK();
     return Y2_OK;
+}
+
+extern "C" int y2_bn_act_fwd(const float* z, const float* scale, const float* shift, float slope, float* y, float* y_pool,
+                             int B, int H, int W, int C, int ldz, int ldy, int coff, int ldp, int poff, int out_mode, y2_stream_t stream) {
+    return y2_bn_act_fwd_ex(z, scale, shift, slope, nullptr, 0, y, y_pool, B, H, W, C, ldz, ldy, coff, ldp, poff, out_mode, stream);
+}
+
+extern "C" int y2_bn_act_bwd(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,
+                             float slope, const float* dy_full, int ldf, int foff, int fmode, const float* dy_pool, int ldp, int poff,
+                             double* sums, float* dz, int ldd, int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream) {
+    return y2_bn_act_bwd_ex(z, scale, shift, mean, invstd, gamma, slope, dy_full, ldf, foff, fmode, dy_pool, ldp, poff, nullptr, 0, nullptr, 0, nullptr, 0,
+                            sums, dz, ldd, B, H, W, C, ldz, has_bn, stream);
 }
 
 extern "C" int y2_colsum(const float* x, long long M, int C, int ld, double* out, y2_stream_t stream) {
@@ -617,6 +698,17 @@ extern "C" int y2_region_loss_bwd(const float* iou, const float* center_offset, 
 extern "C" int y2_region_loss_finalize(const double* sums, double cnt, int cross_entropy, float* loss_out, y2_stream_t stream) {
     if (!sums || !loss_out || cnt <= 0) return Y2_EINVAL;
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, y2_s(stream), sums, cnt, cross_entropy, loss_out);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_maxpool_bwd(const float* x, const float* dy, const float* dy2, float* dx, int B, int H, int W, int C, int ldx, int ldy, int lddx,
+                              int ksize, int stride, int pad, int pad_end, y2_stream_t stream) {
+    if (!x || !dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || pad_end < 0) return Y2_EINVAL;
+    const int Ho = (H + pad + pad_end - ksize) / stride + 1, Wo = (W + pad + pad_end - ksize) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return Y2_EINVAL;
+    const long long total = (long long)B * H * W * C;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, dy, dy2, dx, H, W, Ho, Wo, C, ldx, ldy, lddx, ksize, stride, pad, total);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

@@ -10,8 +10,8 @@ convolution — 7x7/s2 stem, 3x3/s2, 1x1/s2 down-sample, 1x1, 3x3 — is one y2_
 LDS-DMA kernel with BatchNorm folded into the epilogue, ReLU as LeakyReLU(slope 0), and the residual addition of
 BasicBlock / Bottleneck (model/resnet.py:59,101) fused into the epilogue of the block's last convolution; the stem
 max-pool is y2_maxpool_fwd.  The whole chain is one y2_conv_fwd_batch call per stage list, built once per input shape.
-nn.Conv2d / nn.BatchNorm2d objects are parameter containers only.  Training of this plugin (strided dgrad) is not
-implemented yet: forward in training mode with grad enabled raises.
+nn.Conv2d / nn.BatchNorm2d objects are parameter containers only.  Training runs through model/train_graph.py
+(ResNetTrainFn: batch-statistics BN, strided data gradients as transposed convolutions, general weight gradient).
 """
 import ctypes
 import logging
@@ -92,6 +92,7 @@ class ResNet(nn.Module):
         self._cache = None
         self._plan_cache = None
         self.profile = None
+        self.grad_ready_hook = None   # train.DataParallelRCCL: called as hook(param, grad) from inside backward
 
     def _make_layer(self, config_channels, prefix, block, channels, blocks, stride=1):
         layers = [block(config_channels, '%s.%d' % (prefix, 0), channels, stride)]
@@ -252,7 +253,8 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         if self.training and torch.is_grad_enabled():
-            raise NotImplementedError('model.resnet: the HIP training graph (strided dgrad / wgrad) is not implemented yet; use eval() / no_grad()')
+            from model import train_graph
+            return train_graph.resnet_forward(self, x)
         with torch.no_grad():
             out = self.forward_nhwc(x)
         return out.permute(0, 3, 1, 2)

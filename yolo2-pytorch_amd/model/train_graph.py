@@ -391,3 +391,189 @@ def loss(anchors, data, pred, threshold):
         else:
             _data[key] = torch.gather(t, 1, flat.unsqueeze(-1).expand(-1, -1, t.shape[-1])).view(*best_idx.shape, -1)
     return result, dict(iou=best_iou, data=_data, positive=positive_b, negative=negative)
+
+
+# ------------------------------------------------------------------------------------------------ ResNet plugins
+class _ROp(object):
+    """One recorded operation of the ResNet training forward (conv+BN+ReLU[+residual], or the stem max-pool)."""
+    __slots__ = ('kind', 'conv', 'bn', 'x', 'ldx', 'h', 'w', 'ho', 'wo', 'stride', 'pad', 'k', 'cin', 'cout', 'z', 'scale', 'shift', 'mean', 'invstd',
+                 'residual', 'y', 'slope', 'first')
+
+
+def resnet_forward(net, x):
+    params = [p for p in net.parameters()]
+    out = ResNetTrainFn.apply(net, x, *params)
+    return out.permute(0, 3, 1, 2)
+
+
+def _gen_conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, stride, pad, stats=None, transposed=False, out_hw=None):
+    p = _hip.ConvParams()
+    p.x, p.w, p.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
+    p.stats = stats.data_ptr() if stats is not None else None
+    p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize = B, H, W, cin, ldx, cout, k
+    p.ldy, p.slope, p.tile = cout, 1.0, 0
+    p.stride, p.pad_plus1 = stride, pad + 1
+    if transposed:
+        p.transposed, p.out_h, p.out_w = 1, out_hw[0], out_hw[1]
+    _hip.autotune_conv(p, x.device)
+    _hip.conv_workspace(p, x.device)
+    _hip.check(L.y2_conv_fwd(ctypes.byref(p), st), 'y2_conv_fwd')
+
+
+class ResNetTrainFn(torch.autograd.Function):
+    """Training graph of model.resnet.ResNet (model/resnet.py:29-158): per convolution {raw general conv with BN statistics in the
+    epilogue -> y2_bn_finalize (momentum 0.1) -> y2_bn_act_fwd_ex (affine [+ residual] + ReLU)}; backward in reverse with
+    gradient fan-in per tensor: y2_bn_act_bwd_ex (ReLU mask from the recomputed pre-activation, BN backward, gradient of
+    the residual input) -> y2_conv_wgrad_ex -> data gradient (stride 1: forward kernel on rotated weights; stride 2:
+    transposed mode of the general kernel); the stem max-pool goes through y2_maxpool_fwd / y2_maxpool_bwd."""
+    MOMENTUM = 0.1
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        _hip.require_gpu(x)
+        L = _hip.lib()
+        st = _hip.stream()
+        x = _hip.f32c(x.detach())
+        B, cin0, H, W = x.shape
+        if H % 32 or W % 32:
+            raise ValueError('input size must be a multiple of 32 (got %dx%d)' % (H, W))
+        dev = x.device
+        ops = []
+        cpad = (cin0 + 3) // 4 * 4
+        x4 = _new(dev, B, H, W, cpad)
+        _hip.check(L.y2_nchw_to_nhwc(_hip.ptr(x), _hip.ptr(x4), B, cin0, H, W, cpad, st), 'y2_nchw_to_nhwc')
+
+        def conv_bn(conv, bn, xin, ldx, h, w, stride, pad, slope, residual=None, first=False):
+            op = _ROp()
+            weight = _hip.f32c(conv.weight.detach())
+            cout, cin_true, k, _ = weight.shape
+            if ldx % 4 or (cin_true % 4 and not first):
+                raise RuntimeError('training needs conv input channel counts that are multiples of 4 (got %d)' % cin_true)
+            if cin_true != ldx:           # stem: zero-padded input channels
+                wpad = torch.zeros(cout, ldx, k, k, dtype=torch.float32, device=dev)
+                wpad[:, :cin_true] = weight
+                weight = wpad
+            wp = _new(dev, weight.numel())
+            _hip.check(L.y2_pack_weight(_hip.ptr(weight), _hip.ptr(wp), cout, ldx, k, 0, st), 'y2_pack_weight')
+            ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+            z = _new(dev, B, ho, wo, cout)
+            stats = torch.zeros(_hip.STATS_REPL * 2 * cout, dtype=torch.float64, device=dev) if bn is not None else None
+            _gen_conv(L, st, xin, wp, z, B, h, w, ldx, ldx, cout, k, stride, pad, stats=stats)
+            op.kind, op.conv, op.bn, op.x, op.ldx, op.h, op.w, op.ho, op.wo = 'conv', conv, bn, xin, ldx, h, w, ho, wo
+            op.stride, op.pad, op.k, op.cin, op.cout, op.z, op.residual, op.slope, op.first = stride, pad, k, cin_true, cout, z, residual, slope, first
+            if bn is not None:
+                op.scale, op.shift, op.mean, op.invstd = (_new(dev, cout) for _ in range(4))
+                _hip.check(L.y2_bn_finalize(_hip.ptr(stats), float(B * ho * wo), _hip.ptr(bn.weight.detach()), _hip.ptr(bn.bias.detach()),
+                                            _hip.ptr(bn.running_mean), _hip.ptr(bn.running_var), ResNetTrainFn.MOMENTUM, BN_EPS,
+                                            _hip.ptr(op.scale), _hip.ptr(op.shift), _hip.ptr(op.mean), _hip.ptr(op.invstd), cout, st), 'y2_bn_finalize')
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
+            else:
+                op.scale = op.mean = op.invstd = None
+                op.shift = _hip.f32c(conv.bias.detach()) if conv.bias is not None else None
+            y = _new(dev, B, ho, wo, cout)
+            _hip.check(L.y2_bn_act_fwd_ex(_hip.ptr(z), _hip.ptr(op.scale), _hip.ptr(op.shift), slope, _hip.ptr(residual), cout if residual is not None else 0,
+                                          _hip.ptr(y), None, B, ho, wo, cout, cout, cout, 0, 0, 0, 0, st), 'y2_bn_act_fwd_ex')
+            op.y = y
+            ops.append(op)
+            return y, ho, wo, cout
+
+        cur, h, w, ld = conv_bn(net.conv1, net.bn1, x4, cpad, H, W, 2, 3, 0.0, first=True)
+        pool = _ROp()
+        pool.kind, pool.x, pool.h, pool.w, pool.cout = 'pool', cur, h, w, ld
+        ph, pw = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        pooled = _new(dev, B, ph, pw, ld)
+        _hip.check(L.y2_maxpool_fwd(_hip.ptr(cur), _hip.ptr(pooled), B, h, w, ld, ld, ld, 3, 2, 1, 1, st), 'y2_maxpool_fwd')
+        pool.y, pool.ho, pool.wo = pooled, ph, pw
+        ops.append(pool)
+        cur, h, w = pooled, ph, pw
+        for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+            for blk in layer:
+                residual = cur
+                if blk.downsample is not None:
+                    residual, _, _, _ = conv_bn(blk.downsample[0], blk.downsample[1], cur, ld, h, w, blk.stride, 0, 1.0)
+                t, th, tw, tld = cur, h, w, ld
+                convs = blk.convs()
+                for i, (conv, bn, cs, cp) in enumerate(convs):
+                    last = i == len(convs) - 1
+                    t, th, tw, tld = conv_bn(conv, bn, t, tld, th, tw, cs, cp, 0.0, residual=residual if last else None)
+                cur, h, w, ld = t, th, tw, tld
+        out, _, _, _ = conv_bn(net.conv, None, cur, ld, h, w, 1, 0, 1.0)
+        ctx.net, ctx.ops, ctx.B = net, ops, B
+        ctx.param_ids = [id(p) for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _hip.lib()
+        st = _hip.stream()
+        net, ops, B = ctx.net, ctx.ops, ctx.B
+        dev = dout.device
+        grads = {}
+        hook = getattr(net, 'grad_ready_hook', None)
+
+        def ready(param, g):
+            grads[id(param)] = g
+            if hook is not None:
+                hook(param, g)
+        G = {id(ops[-1].y): [_hip.f32c(dout)]}      # gradient sources per activation tensor
+        for op in reversed(ops):
+            srcs = G.pop(id(op.y), [])
+            assert 1 <= len(srcs) <= 2, len(srcs)
+            if op.kind == 'pool':
+                dx = _new(dev, B, op.h, op.w, op.cout)
+                _hip.check(L.y2_maxpool_bwd(_hip.ptr(op.x), _hip.ptr(srcs[0]), _hip.ptr(srcs[1]) if len(srcs) > 1 else None, _hip.ptr(dx),
+                                            B, op.h, op.w, op.cout, op.cout, op.cout, op.cout, 3, 2, 1, 1, st), 'y2_maxpool_bwd')
+                G.setdefault(id(op.x), []).append(dx)
+                continue
+            cout, cin, k, ho, wo = op.cout, op.ldx, op.k, op.ho, op.wo
+            cop = (cout + 3) // 4 * 4
+            sums = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
+            dz = _new(dev, B, ho, wo, cop) if cop == cout else torch.zeros(B, ho, wo, cop, dtype=torch.float32, device=dev)
+            dres = _new(dev, B, ho, wo, cout) if op.residual is not None else None
+            has_bn = op.bn is not None
+            _hip.check(L.y2_bn_act_bwd_ex(_hip.ptr(op.z), _hip.ptr(op.scale), _hip.ptr(op.shift), _hip.ptr(op.mean), _hip.ptr(op.invstd),
+                                          _hip.ptr(op.bn.weight.detach()) if has_bn else None, op.slope,
+                                          _hip.ptr(srcs[0]), cout, 0, 0, None, 0, 0,
+                                          _hip.ptr(srcs[1]) if len(srcs) > 1 else None, cout,
+                                          _hip.ptr(op.residual), cout if op.residual is not None else 0, _hip.ptr(dres), cout,
+                                          _hip.ptr(sums), _hip.ptr(dz), cop, B, ho, wo, cout, cout, int(has_bn), st), 'y2_bn_act_bwd_ex')
+            if op.residual is not None:
+                G.setdefault(id(op.residual), []).append(dres)
+            if has_bn:
+                gb = _new(dev, 2 * cout)
+                _hip.check(L.y2_f64_to_f32(_hip.ptr(sums), _hip.ptr(gb), 2 * cout, 1.0, st), 'y2_f64_to_f32')
+                ready(op.bn.bias, gb[:cout])
+                ready(op.bn.weight, gb[cout:])
+            elif op.conv.bias is not None:
+                gb = _new(dev, cout)
+                _hip.check(L.y2_f64_to_f32(_hip.ptr(sums), _hip.ptr(gb), cout, 1.0, st), 'y2_f64_to_f32')
+                ready(op.conv.bias, gb)
+            # ---- weight gradient
+            dwp = torch.zeros(cop * k * k * cin, dtype=torch.float32, device=dev)
+            _hip.check(L.y2_conv_wgrad_ex(_hip.ptr(op.x), _hip.ptr(dz), _hip.ptr(dwp), B, op.h, op.w, cin, cin, cop, cop, k, op.stride, op.pad, st), 'y2_conv_wgrad_ex')
+            dw = _new(dev, cop, cin, k, k)
+            _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cop, cin, k, st), 'y2_unpack_weight_grad')
+            ready(op.conv.weight, dw if (cop == cout and cin == op.cin) else dw[:cout, :op.cin].contiguous())
+            op.z = None
+            if op.first:
+                continue
+            # ---- data gradient
+            wsrc = _hip.f32c(op.conv.weight.detach())
+            if cop != cout:
+                wpad = torch.zeros(cop, cin, k, k, dtype=torch.float32, device=dev)
+                wpad[:cout] = wsrc
+                wsrc = wpad
+            wd = _new(dev, wsrc.numel())
+            _hip.check(L.y2_pack_weight(_hip.ptr(wsrc), _hip.ptr(wd), cop, cin, k, 1, st), 'y2_pack_weight')
+            dx = _new(dev, B, op.h, op.w, cin)
+            if op.stride == 1:
+                _gen_conv(L, st, dz, wd, dx, B, ho, wo, cop, cop, cin, k, 1, k - 1 - op.pad)
+            else:
+                _gen_conv(L, st, dz, wd, dx, B, ho, wo, cop, cop, cin, k, op.stride, op.pad, transposed=True, out_hw=(op.h, op.w))
+            G.setdefault(id(op.x), []).append(dx)
+        out = [None, None]
+        for pid in ctx.param_ids:
+            out.append(grads.get(pid))
+        ctx.ops = None
+        return tuple(out)
