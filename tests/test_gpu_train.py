@@ -336,11 +336,17 @@ def test_resnet_training_step_matches_oracle_autograd(arch):
     oloss.total(lo).backward()
     for k in lo:
         np.testing.assert_allclose(loss[k].item(), lo[k].item(), rtol=5e-4)   # fp32 vs fp64 through up to 53 batch-stat BN layers on 27 samples per channel
+    # the same step on the oracle in fp32: its deviation from fp64 is the noise floor of fp32 arithmetic through ~50 batch-stat
+    # BN layers, ReLU and max-pool decisions; the HIP path must stay within a small multiple of it
+    sd32 = {k: v.clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    l32, _ = oloss.loss(anchors, data, ohead.decode(ores.forward(x, sd32, arch, training=True), anchors), 0.6)
+    oloss.total(l32).backward()
     ours = dict(net.named_parameters())
     for k, v in sd64.items():
         if v.requires_grad:
             assert ours[k].grad is not None, k
-            assert rel(ours[k].grad, v.grad) <= 2e-3, (k, rel(ours[k].grad, v.grad))
+            floor = rel(sd32[k].grad, v.grad)
+            assert rel(ours[k].grad, v.grad) <= max(2e-3, 4 * floor), (k, rel(ours[k].grad, v.grad), floor)
     bufs = dict(net.named_buffers())
     for prefix, (rm, rv) in stats.items():
         np.testing.assert_allclose(bufs[prefix + '.running_mean'].cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-6)
