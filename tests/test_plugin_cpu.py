@@ -82,3 +82,24 @@ def test_resnet_state_dict_matches_reference_layout(arch, width):
     for k, v in ref.items():
         assert ours[k] == tuple(v.shape), k
     assert utils.parse_attr('model.resnet.' + arch) is getattr(model.resnet, arch)
+
+
+def test_utils_config_helpers(tmp_path):
+    """ini overlay / modify / anchors / plugin resolution with the reference's file formats (config.ini, config/anchors/*.tsv)."""
+    (tmp_path / 'anchors.tsv').write_text('width\theight\n1.08\t1.19\n3.42\t4.41\n')
+    (tmp_path / 'cat').write_text('aeroplane\nbicycle\n')
+    (tmp_path / 'a.ini').write_text('[config]\nroot = %s\n[model]\nname = model\nanchors = %s\ndnn = model.yolo2.Tiny\n[cache]\nname = cache\ncategory = %s\n[train]\nclip_ = 5\n'
+                                    % (tmp_path, tmp_path / 'anchors.tsv', tmp_path / 'cat'))
+    (tmp_path / 'b.ini').write_text('[model]\ndnn = model.yolo2.Darknet\n')
+    cfg = configparser.ConfigParser()
+    utils.load_config(cfg, [str(tmp_path / 'a.ini'), str(tmp_path / 'b.ini')])
+    assert cfg.get('model', 'dnn') == 'model.yolo2.Darknet'           # later files overlay earlier ones
+    a = utils.get_anchors(cfg)
+    assert a.dtype.name == 'float32' and a.tolist() == [[pytest.approx(1.19), pytest.approx(1.08)], [pytest.approx(4.41), pytest.approx(3.42)]]   # (height, width)
+    assert utils.get_category(cfg) == ['aeroplane', 'bicycle']
+    assert utils.get_model_dir(cfg) == str(tmp_path / 'model' / 'model.yolo2.Darknet')
+    utils.modify_config(cfg, 'model/dnn=model.resnet.resnet50')
+    assert utils.parse_attr(cfg.get('model', 'dnn')) is __import__('model.resnet').resnet.resnet50
+    utils.modify_config(cfg, 'train/clip_=')
+    assert not cfg.has_option('train', 'clip_')
+    utils.modify_config(cfg, 'nosuch/option=')                          # silently ignored like the reference
