@@ -593,9 +593,9 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
 
 // Adds the K-parts of the split remainder tiles and applies the ordinary epilogue (one workgroup per split tile, same
 // thread -> accumulator mapping as conv_fwd_dma_kernel).
-template <int BM, int BN, int WAVES_M, bool POOLORD>
-__global__ __launch_bounds__(NT) void conv_splitk_fixup_kernel(const ConvArgs a) {
-    constexpr int WAVES_N = 4 / WAVES_M;
+template <int BM, int BN, int WAVES_M, bool POOLORD, int NTHR = NT>
+__global__ __launch_bounds__(NTHR) void conv_splitk_fixup_kernel(const ConvArgs a) {
+    constexpr int WAVES_N = (NTHR / 64) / WAVES_M;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MB = WM / 32, NB = WN / 32;
     const int t = threadIdx.x;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(NT) void conv_splitk_fixup_kernel(const ConvArgs a)
                 f32x4 sum = {0.f, 0.f, 0.f, 0.f};
                 for (int p = 0; p < a.ksplit; ++p) {
                     const float* src = a.partial + ((size_t)blockIdx.x * a.ksplit + p) * (BM * BN);
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (((i * NB + j) * 4 + g) * NT + t) * 4);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (((i * NB + j) * 4 + g) * NTHR + t) * 4);
                     sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
                 }
                 acc[i][j][4 * g] = sum[0]; acc[i][j][4 * g + 1] = sum[1]; acc[i][j][4 * g + 2] = sum[2]; acc[i][j][4 * g + 3] = sum[3];
@@ -649,9 +649,8 @@ int launch(const ConvArgs& a0, hipStream_t stream) {
 // Remainder split: T tiles on P CUs run floor(T/P) full rounds; the last T mod P tiles would occupy only part of the chip
 // for a whole tile time.  They are cut into s K-slices each (s chosen to minimise ceil(rem*s/P)/s) and a tiny fixup kernel
 // adds the slices.  Needs caller workspace; without it (or when nothing is gained) tiles run whole.
-inline void plan_split(long long tiles, int nk, long long tile_elems, size_t ws_bytes, int& full_tiles, int& ksplit) {
+inline void plan_split(long long tiles, int nk, long long tile_elems, size_t ws_bytes, int& full_tiles, int& ksplit, int P = Y2_NUM_CU) {
     full_tiles = (int)tiles; ksplit = 1;
-    const int P = Y2_NUM_CU;
     const long long rem = tiles % P;
     if (rem == 0 || nk < 8) return;
     double best = 1.0; int bs = 1;
@@ -710,6 +709,242 @@ int launch_dma(const ConvArgs& a0, hipStream_t stream, float* ws, size_t ws_byte
     return Y2_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ wave-private kernel
+// Barrier-free variant for the standard convolutions (3x3 / 1x1, stride 1, Cin % 16 == 0): ONE wave owns a 64 x 64 output tile
+// and its own LDS ring, so there is no workgroup barrier and no coupling between the four SIMDs of a CU (in the workgroup
+// kernel a wave that shares its SIMD with a busier neighbour delays the other three waves at every slab barrier).
+//   * workgroup = 64 threads; slab = 16 floats of K (64-B rows): A 64 rows + B 64 rows = 8 KB per stage, 4 stages = 32 KB,
+//     four waves per CU = one per SIMD; the ring keeps up to three slabs (6144 MFMA cycles) in flight with counted vmcnt;
+//   * LDS-DMA with the XOR swizzle of the 64-B-row geometry: physical 16-B slot p of row r holds logical chunk p ^ ((r>>2)&3)
+//     (4 rows share one 256-B bank row), fragment reads apply the same involution -> conflict-free ds_read_b128;
+//   * per slab: 8 DMA instructions, 8 ds_read_b128, 32 MFMAs (2048 cycles) and no s_barrier at all.
+template <bool POOLORD, int STAGES = 4, int BK = 16>
+__global__ __launch_bounds__(64) void conv_fwd_wave_kernel(const ConvArgs a) {
+    constexpr int TM = 64, TN = 64;
+    constexpr int CH = BK / 4;                       // 16-B chunks per row
+    constexpr int RP = 64 / CH;                      // rows per DMA instruction
+    constexpr int NP = 64 / RP;                      // DMA instructions per operand per slab
+    constexpr int QG = BK / 8;                       // k-groups (one ds_read_b128 per block each) per slab
+    constexpr int STAGE = (TM + TN) * BK;            // floats per stage
+    constexpr unsigned OOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int lane = threadIdx.x;
+    const int l31 = lane & 31, half = lane >> 5;
+    const bool is_split = (int)blockIdx.x >= a.full_tiles;
+    int tile, part = 0;
+    if (!is_split) {
+        tile = y2_xcd_remap(blockIdx.x, min((int)gridDim.x, a.full_tiles));
+    } else {
+        const int r = y2_xcd_remap(blockIdx.x - a.full_tiles, gridDim.x - a.full_tiles);
+        tile = a.full_tiles + r / a.ksplit;
+        part = r % a.ksplit;
+    }
+    const int tile_n = tile % a.tiles_n;
+    const int tile_m = tile / a.tiles_n;
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
+
+    // staging: lane -> physical slot p = lane % CH of row lane / CH + RP*i; it fetches logical chunk p ^ swz(row)
+    // swz: rows sharing one 256-B bank row get different XOR masks (BK = 16: 4 rows per bank row; BK = 32: 2 rows)
+    const int srow = lane / CH;
+    const int lchunk = (lane % CH) ^ (BK == 32 ? ((srow >> 1) & 7) : ((srow >> 2) & 3));
+    unsigned a_base[NP], a_mask[NP], b_base[NP];
+    const int up_left = (a.taps == 9) ? (a.W + 1) : 0;
+    const int ktot = a.taps * a.Cin;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int m = m0 + srow + RP * i;
+        unsigned mask = 0;
+        int pix = 0;
+        if (m < a.M) {
+            int y, x;
+            decode_row<POOLORD>(a, m, pix, y, x);
+            if (a.taps == 9) {
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                    if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) mask |= 1u << tp;
+                }
+            } else {
+                mask = 1u;
+            }
+        }
+        a_mask[i] = mask;
+        a_base[i] = (unsigned)(((long long)(pix - up_left) * a.ldx + 4 * lchunk) * 4);
+        const int n = n0 + srow + RP * i;
+        b_base[i] = n < a.Cout ? (unsigned)(((size_t)n * ktot + 4 * lchunk) * 4) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+
+    auto issue_slab = [&](int tap, int c0, int stage) {
+        const int ky = (a.taps == 9) ? tap / 3 : 0, kx = (a.taps == 9) ? tap % 3 : 0;
+        const unsigned toff = (unsigned)(((ky * a.W + kx) * a.ldx + c0) * 4);
+        const unsigned tbit = 1u << tap;
+        float* sa = smem + stage * STAGE;
+        float* sb = sa + TM * BK;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const unsigned voff = (a_mask[i] & tbit) ? a_base[i] + toff : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * RP * BK), 16, (int)voff, 0, 0, 0);
+        }
+        const unsigned woff = (unsigned)((tap * a.Cin + c0) * 4);
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sb + i * RP * BK), 16, (int)b_base[i], (int)woff, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment offsets (floats): row l31 (+32 per block), logical chunk 2q + half -> physical chunk (same involution)
+    const int sw = BK == 32 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
+    int foff[QG];
+#pragma unroll
+    for (int q = 0; q < QG; ++q) foff[q] = l31 * BK + (((2 * q + half) ^ sw) << 2);
+
+    // software-pipelined fragment reads: while the 16 MFMAs of one k-group run, the fragments of the next group (possibly of
+    // the next slab, after its counted vmcnt) are already being read from LDS
+    auto load_frags = [&](int stage, int q, f32x4 (&fa4)[2], f32x4 (&fb4)[2]) {
+        const float* sbuf = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa4[i] = *reinterpret_cast<const f32x4*>(sbuf + i * 32 * BK + foff[q]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb4[j] = *reinterpret_cast<const f32x4*>(sbuf + TM * BK + j * 32 * BK + foff[q]);
+    };
+    auto mfma_group = [&](const f32x4 (&fa4)[2], const f32x4 (&fb4)[2]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa4[i][e], fb4[j][e], acc[i][j], 0, 0, 0);
+    };
+    constexpr int PER = 2 * NP;                       // DMA instructions per slab
+    auto wait_slab = [&](int ks, int nk) {             // slab ks landed; up to min(STAGES-2, nk-1-ks) younger slabs stay in flight
+        const int ahead = min(STAGES - 2, nk - 1 - ks);
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    const int cch = a.Cin / BK;                      // chunks per tap
+    const int nk_all = a.taps * cch;
+    int ks0 = 0, ks1 = nk_all;
+    if (is_split) {
+        ks0 = (int)((long long)nk_all * part / a.ksplit);
+        ks1 = (int)((long long)nk_all * (part + 1) / a.ksplit);
+    }
+    const int nk = ks1 - ks0;
+    int tap = ks0 / cch, c0 = (ks0 % cch) * BK;      // position of the NEXT slab to issue
+    auto advance = [&]() { c0 += BK; if (c0 >= a.Cin) { c0 = 0; ++tap; } };
+    int issued = 0;
+    for (; issued < min(STAGES - 1, nk); ++issued) { issue_slab(tap, c0, issued); advance(); }
+    f32x4 xa[2], xb[2], ya[2], yb[2];
+    if (nk > 0) {
+        wait_slab(0, nk);
+        load_frags(0, 0, xa, xb);
+    }
+    int cur = 0, nxt = STAGES - 1;
+    int ks = 0;
+    // one slab: QG k-groups alternating between the fragment sets X (even groups) and Y (odd groups)
+    auto slab_body = [&](bool steady) {
+        const int nc = cur == STAGES - 1 ? 0 : cur + 1;
+#pragma unroll
+        for (int q = 0; q < QG; q += 2) {
+            load_frags(cur, q + 1, ya, yb);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(xa, xb);
+            if (q + 2 < QG) {
+                load_frags(cur, q + 2, xa, xb);
+            } else if (steady) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * (STAGES - 2)) : "memory");   // slab ks+1 landed; the younger ones stay in flight
+                load_frags(nc, 0, xa, xb);
+            } else if (ks + 1 < nk) {
+                wait_slab(ks + 1, nk);
+                load_frags(nc, 0, xa, xb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(ya, yb);
+        }
+        cur = nc;
+        nxt = nxt == STAGES - 1 ? 0 : nxt + 1;
+    };
+    // steady state (branch-free body: exact lgkmcnt / vmcnt counts): slab ks + STAGES - 1 exists
+    for (; ks + (STAGES - 1) < nk; ++ks) {
+        issue_slab(tap, c0, nxt); advance(); ++issued;     // into the stage of slab ks-1 (fully read)
+        slab_body(true);
+    }
+    // drain
+    for (; ks < nk; ++ks) {
+        if (issued < nk) { issue_slab(tap, c0, nxt); advance(); ++issued; }
+        slab_body(false);
+    }
+
+    if (is_split) {
+        float* dst = a.partial + ((size_t)(tile - a.full_tiles) * a.ksplit + part) * (TM * TN);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(dst + (((i * 2 + j) * 4 + g) * 64 + lane) * 4) = v;
+                }
+        return;
+    }
+    conv_epilogue<2, 2, 64, 64, POOLORD>(a, acc, m0, n0, 0, 0, l31, half);
+}
+
+template <bool POOLORD>
+int launch_wave(const ConvArgs& a0, hipStream_t stream, float* ws, size_t ws_bytes, size_t* ws_need) {
+    ConvArgs a = a0;
+    a.tiles_m = y2_cdiv(a.M, 64);
+    a.tiles_n = y2_cdiv(a.Cout, 64);
+    const char* bke = getenv("Y2_WAVE_BK");
+    const int nk_all = a.taps * (a.Cin / ((bke && atoi(bke) == 32) ? 32 : 16));
+    const long long tiles = (long long)a.tiles_m * a.tiles_n;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return Y2_EINVAL;
+    const int P = 4 * Y2_NUM_CU;     // one tile stream per SIMD
+    if (ws_need != nullptr) {
+        int ft, ks;
+        plan_split(tiles, nk_all, 64 * 64, (size_t)-1, ft, ks, P);
+        *ws_need = (size_t)(tiles - ft) * ks * 64 * 64 * sizeof(float);
+        return Y2_OK;
+    }
+    plan_split(tiles, nk_all, 64 * 64, ws != nullptr ? ws_bytes : 0, a.full_tiles, a.ksplit, P);
+    a.partial = ws;
+    const long long grid = a.full_tiles + (tiles - a.full_tiles) * a.ksplit;
+    static int stages = -1, bk = 16;
+    if (stages < 0) { const char* e = getenv("Y2_WAVE_STAGES"); stages = e ? atoi(e) : 4; const char* b = getenv("Y2_WAVE_BK"); bk = (b && atoi(b) == 32) ? 32 : 16; }
+    if (bk == 32 && (a.Cin % 32) != 0) return Y2_ENOSUP;
+    const size_t lds = (size_t)stages * (64 + 64) * bk * sizeof(float);
+    static bool attr = false;
+#define Y2_WAVE(ST, BKV)                                                                                                          \
+    do {                                                                                                                          \
+        auto kern = conv_fwd_wave_kernel<POOLORD, ST, BKV>;                                                                       \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, stream, a);                                                 \
+    } while (0)
+    (void)attr;
+    if (bk == 32) { if (stages == 2) Y2_WAVE(2, 32); else if (stages == 3) Y2_WAVE(3, 32); else Y2_WAVE(4, 32); }
+    else { if (stages == 2) Y2_WAVE(2, 16); else if (stages == 3) Y2_WAVE(3, 16); else Y2_WAVE(4, 16); }
+#undef Y2_WAVE
+    if (a.ksplit > 1)
+        hipLaunchKernelGGL((conv_splitk_fixup_kernel<64, 64, 1, POOLORD, 64>), dim3((unsigned)(tiles - a.full_tiles)), dim3(64), 0, stream, a);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
 template <bool POOLORD, bool GEN = false>
 int dispatch_dma(const ConvArgs& a, int tile, hipStream_t s, float* ws, size_t ws_bytes, size_t* ws_need) {
     switch (tile) {
@@ -717,7 +952,8 @@ int dispatch_dma(const ConvArgs& a, int tile, hipStream_t s, float* ws, size_t w
         case 2: return launch_dma<128, 64, 2, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);
         case 3: return launch_dma<64, 64, 2, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);
         case 5: return launch_dma<64, 128, 2, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);
-        case 6: return launch_dma<128, 32, 4, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);   // narrow outputs (Cout <= 32: dgrad into the first layers)
+        case 6: return launch_dma<128, 32, 4, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);
+        case 7: if (!GEN) return launch_wave<POOLORD>(a, s, ws, ws_bytes, ws_need); return Y2_ENOSUP;   // barrier-free wave-private 64x64 tiles   // narrow outputs (Cout <= 32: dgrad into the first layers)
         default: return Y2_ENOSUP;
     }
 }
@@ -837,9 +1073,10 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
     // path for channel counts / strides that are not multiples of 4, e.g. pruned checkpoints).  Strided / 7x7 / padded
     // variants and small Cin (K handled as one linear axis) use the GEN instantiation of the DMA kernel.
     const unsigned long long xb = (unsigned long long)Min * p->ldx * 4ull, wb = (unsigned long long)p->Cout * a.taps * p->Cin * 4ull;
-    const bool dma_tile = (tile == 1 || tile == 2 || tile == 3 || tile == 5 || tile == 6);
+    if (tile == 7 && (!standard || (p->Cin % 16) != 0)) tile = 3;      // the wave-private kernel covers the standard convolutions only
+    const bool dma_tile = (tile == 1 || tile == 2 || tile == 3 || tile == 5 || tile == 6 || tile == 7);
     const bool dma_ok = vec && xb < 0x7fffffffull && wb < 0x7fffffffull && dma_tile;
-    const bool gen = !standard || (dma_ok && p->Cin < 32 && !pool && p->out_mode == 0);
+    const bool gen = !standard || (dma_ok && tile != 7 && p->Cin < 32 && !pool && p->out_mode == 0);
     float* ws = p->workspace;
     const size_t wsb = (ws != nullptr && y2_aligned16(ws)) ? (size_t)p->workspace_bytes : 0;
     if (gen) {
