@@ -362,6 +362,30 @@ def test_detect_batch_end_to_end_vs_oracle(golden):
                     np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize('threshold', [1.5, 0.0])
+def test_detect_batch_nothing_visible_and_everything_visible(golden, threshold):
+    """threshold above every score -> every image yields None (detect.py:69 returns nothing to draw); threshold 0 -> all
+    845 cells x anchors are candidates and NMS runs on the full list (limit 200): still equal to the oracle."""
+    import detect
+    g = golden('decode_voc')
+    feat = to_nhwc(torch.from_numpy(g['feature'])).to(dev())[:2].contiguous()
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    d = detect.detect_batch(feat, anchors, fix=False, threshold=threshold)
+    res = detect.postprocess_batch(d, fix=False)
+    B = feat.size(0)
+    iou = d['iou'].view(B, -1).cpu().numpy()
+    mn, mx = d['yx_min'].view(B, -1, 2).cpu().numpy(), d['yx_max'].view(B, -1, 2).cpu().numpy()
+    prob = d['prob'].view(B, iou.shape[1], -1).cpu().numpy()
+    for b in range(B):
+        ref = odet.postprocess(iou[b], mn[b], mx[b], prob[b], fix=False, threshold=threshold)
+        if threshold > 1:
+            assert ref is None and res[b] is None and int(d['count'][b]) == 0
+        else:
+            assert int(d['count'][b]) == iou.shape[1]
+            for got, want in zip(res[b], ref[:5]):
+                np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
 # ------------------------------------------------------------------ general convolution (ResNet plugin: model/resnet.py)
 GEN_CASES = [
     # B, Cin, Cout, H, W, k, stride, pad, residual, tile

@@ -177,6 +177,35 @@ def test_region_loss_matches_reference_fixture(golden, onehot):
     np.testing.assert_allclose(f.grad.cpu().numpy(), gr, rtol=2e-4, atol=1e-6 * np.abs(gr).max())
 
 
+@pytest.mark.parametrize('onehot', [False, True])
+@pytest.mark.parametrize('case', synth.EDGE_CASES, ids=[c[0] for c in synth.EDGE_CASES])
+def test_region_loss_edge_cases_match_reference_fixture(golden, case, onehot):
+    """Image without objects, duplicate boxes, three boxes in one cell, first/last cell, 1-px and degenerate boxes, on the
+    10/13/19 grids of the reference's training sizes: fixture from the reference (oracle/make_golden_loss_edge.py)."""
+    import model
+    name, S, rows = case
+    g = golden('loss_edge')
+    tag = '%s_%s_' % (name, 'onehot' if onehot else 'ce')
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    f = synth.edge_feature(5, 5, 20, rows, rows).to(dev()).requires_grad_(True)
+
+    class Id(torch.nn.Module):
+        def forward(self, t):
+            return t
+    pred = model._inference(model.Inference(None, Id(), anchors), f)
+    data = synth.norm_data(synth.edge_labels(S, S, 20, onehot), S, S, rows, rows)
+    loss, debug = model.loss(anchors, data, pred, 0.6)
+    sum(loss[k] * w for k, w in oloss.HPARAM.items()).backward()
+    for k in ('foreground', 'background', 'center', 'size', 'cls'):
+        np.testing.assert_allclose(loss[k].item(), g[tag + k], rtol=3e-5)
+    np.testing.assert_array_equal(debug['positive'].cpu().numpy().astype(bool), g[tag + 'positive'].astype(bool))
+    np.testing.assert_array_equal(debug['negative'].cpu().numpy().astype(bool), g[tag + 'negative'].astype(bool))
+    # IoUs of ~1e-2 against the 1-px box are differences of nearly equal fp32 coordinates: device expf vs host expf shows
+    np.testing.assert_allclose(debug['iou'].cpu().numpy(), g[tag + 'best_iou'], rtol=1e-4, atol=1e-6)
+    gr = g[tag + 'grad']
+    np.testing.assert_allclose(f.grad.cpu().numpy(), gr, rtol=2e-4, atol=1e-6 * np.abs(gr).max())
+
+
 def test_region_loss_coco_and_single_class_vs_oracle():
     import model
     for C, A in ((80, 5), (0, 5)):

@@ -145,3 +145,25 @@ def test_loss_matches_reference(golden, onehot):
     np.testing.assert_array_equal(debug['negative'].numpy(), g[tag + 'negative'].astype(bool))
     np.testing.assert_array_equal(debug['iou'].numpy(), g[tag + 'best_iou'])
     np.testing.assert_allclose(feat.grad.numpy(), g[tag + 'grad'], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('onehot', [False, True])
+@pytest.mark.parametrize('case', synth.EDGE_CASES, ids=[c[0] for c in synth.EDGE_CASES])
+def test_loss_edge_cases_match_reference(golden, case, onehot):
+    """Empty image, duplicate boxes, cell collisions, border cells, degenerate boxes (oracle/make_golden_loss_edge.py)."""
+    name, S, rows = case
+    g = golden('loss_edge')
+    tag = '%s_%s_' % (name, 'onehot' if onehot else 'ce')
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    feat = synth.edge_feature(5, 5, 20, rows, rows).requires_grad_(True)
+    pred = ohead.decode(feat, anchors)
+    data = synth.norm_data(synth.edge_labels(S, S, 20, onehot), S, S, rows, rows)
+    loss, debug = oloss.loss(anchors, data, pred, 0.6)
+    oloss.total(loss).backward()
+    for k in ('foreground', 'background', 'center', 'size', 'cls'):
+        np.testing.assert_allclose(loss[k].item(), g[tag + k], rtol=1e-5)
+    np.testing.assert_array_equal(debug['positive'].numpy().astype(bool), g[tag + 'positive'].astype(bool))
+    np.testing.assert_array_equal(debug['negative'].numpy().astype(bool), g[tag + 'negative'].astype(bool))
+    gr = g[tag + 'grad']
+    assert np.isfinite(gr).all()
+    np.testing.assert_allclose(feat.grad.numpy(), gr, rtol=1e-4, atol=1e-6 * np.abs(gr).max())
