@@ -95,8 +95,19 @@ typedef struct y2_conv_params {
     int32_t transposed;  /* != 0: data gradient of a conv with this (ksize, stride, pad): x = dz [B,H,W,Cin=Cout_fwd], w = y2_pack_weight
                             mode 1 of the forward weight, result [B,out_h,out_w,Cout=Cin_fwd] (fractionally strided convolution) */
     int32_t out_h, out_w; /* transposed only: spatial size of the forward conv's input */
-    int32_t reserved;
+    int32_t algo;        /* Y2_ALGO_DIRECT (0): implicit GEMM, w = y2_pack_weight output.
+                            Y2_ALGO_WINOGRAD (1): F(2x2,3x3) for 3x3 / stride 1 / same padding: w = y2_wino_weight output
+                            [16][Cout][Cin]; `workspace` is REQUIRED (transformed input + products, y2_conv_fwd_workspace_bytes) */
 } y2_conv_params;
+
+#define Y2_ALGO_DIRECT 0
+#define Y2_ALGO_WINOGRAD 1
+
+/* Winograd F(2x2,3x3) filter transform U[p][co][ci] = (G g G^T)[p], p = 4*xi + nu, from a packed 3x3 weight
+ * (y2_pack_weight mode 0 for the forward conv, mode 1 for the data gradient: [Cout][9][Cin]).  Same role as the cuDNN
+ * WINOGRAD algorithm the reference's nn.Conv2d (model/yolo2.py:57) may pick for fp32 3x3 convolutions: 2.25x fewer
+ * multiplications, results within fp32 rounding of the direct sum (tests state the tolerance). */
+int y2_wino_weight(const float* w_packed, float* u, int32_t Cout, int32_t Cin, y2_stream_t stream);
 
 int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream);
 

@@ -39,7 +39,7 @@ def rel_err(got, ref64):
     return (got.double().cpu() - ref64).abs().max().item() / max(rms, 1e-30)
 
 
-def run_conv(x_nchw, w, scale, shift, slope, k, pool=False, both=False, tile=0, reorg=False, coff=0, extra=0, stats=False):
+def run_conv(x_nchw, w, scale, shift, slope, k, pool=False, both=False, tile=0, reorg=False, coff=0, extra=0, stats=False, wino=False):
     """Drive y2_conv_fwd directly (NHWC in/out); returns dict of outputs as NCHW CPU tensors."""
     import _hip
     L = _hip.lib()
@@ -53,6 +53,10 @@ def run_conv(x_nchw, w, scale, shift, slope, k, pool=False, both=False, tile=0, 
     p = _hip.ConvParams()
     sc = scale.to(d) if scale is not None else None
     sh = shift.to(d) if shift is not None else None
+    if wino:
+        u = torch.empty(16 * w.numel() // 9, device=d)
+        _hip.check(L.y2_wino_weight(_hip.ptr(wp), _hip.ptr(u), cout, cin, _hip.stream()), 'wino_weight')
+        wp, p.algo = u, 1
     p.x, p.w = x.data_ptr(), wp.data_ptr()
     p.scale = sc.data_ptr() if sc is not None else None
     p.shift = sh.data_ptr() if sh is not None else None
@@ -120,6 +124,36 @@ def test_conv_fwd_matches_fp64_reference(B, cin, cout, H, W, k, tile):
     s1, s2 = z.sum((0, 2, 3)), (z * z).sum((0, 2, 3))
     np.testing.assert_allclose(out['stats'][:cout].numpy(), s1.numpy(), rtol=1e-5, atol=1e-5 * float(s2.max().sqrt()))
     np.testing.assert_allclose(out['stats'][cout:].numpy(), s2.numpy(), rtol=1e-5)
+
+
+WINO_CASES = [
+    # B, Cin, Cout, H, W, tile, pool, both
+    (2, 32, 64, 16, 24, 0, False, False), (3, 512, 256, 13, 13, 0, False, False), (1, 64, 128, 13, 13, 3, False, False),
+    (2, 128, 64, 7, 9, 5, False, False), (2, 256, 512, 26, 26, 1, False, False), (2, 32, 48, 12, 20, 2, True, False),
+    (2, 64, 32, 8, 8, 0, True, True), (1, 16, 20, 5, 3, 0, False, False), (2, 1280, 1024, 13, 13, 0, False, False),
+]
+
+
+@pytest.mark.parametrize('B,cin,cout,H,W,tile,pool,both', WINO_CASES)
+def test_conv_fwd_winograd_matches_fp64_reference(B, cin, cout, H, W, tile, pool, both):
+    """algo = Y2_ALGO_WINOGRAD: F(2x2,3x3) input/filter/output transforms around the grouped MFMA GEMM.  Odd sizes (ragged
+    last tile row/column), concat-style channel windows, negative scales before the fused pool.  The transforms cost a
+    few ulps: tolerance 4x the direct kernel's (still ~1e-5 of the output rms against the fp64 truth)."""
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout + H)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    scale = torch.randn(cout, generator=g)
+    shift = torch.randn(cout, generator=g) * 0.1
+    _, ref = ref_conv(x, w, scale, shift, 0.1, 3)
+    out = run_conv(x, w, scale, shift, 0.1, 3, tile=tile, pool=pool, both=both, extra=0 if pool else 4, coff=0 if pool else 8, wino=True)
+    if pool:
+        assert rel_err(out['y_pool'].permute(0, 3, 1, 2), F.max_pool2d(ref, 2)) <= 4 * CONV_TOL
+    if both or not pool:
+        y = out['y']
+        c0 = 0 if pool else 8
+        if not pool:
+            assert torch.all(y[..., :8] == -7.0) and torch.all(y[..., 8 + cout:] == -7.0), 'wrote outside its channel window'
+        assert rel_err(y[..., c0:c0 + cout].permute(0, 3, 1, 2), ref) <= 4 * CONV_TOL
 
 
 @pytest.mark.parametrize('tile', [1, 2, 3, 5, 7])

@@ -28,7 +28,7 @@ class ConvParams(ctypes.Structure):
                 ('out_mode', ctypes.c_int32), ('slope', c_float), ('tile', ctypes.c_int32),
                 ('workspace', c_void_p), ('workspace_bytes', ctypes.c_int64),
                 ('residual', c_void_p), ('ldr', ctypes.c_int32), ('stride', ctypes.c_int32), ('pad_plus1', ctypes.c_int32),
-                ('transposed', ctypes.c_int32), ('out_h', ctypes.c_int32), ('out_w', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('transposed', ctypes.c_int32), ('out_h', ctypes.c_int32), ('out_w', ctypes.c_int32), ('algo', ctypes.c_int32)]
 
 
 # name -> argtypes; restype is int for everything except y2_build_info
@@ -39,6 +39,7 @@ SIGNATURES = {
     'y2_bn_fold': [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p],
     'y2_conv_fwd': [ctypes.POINTER(ConvParams), c_void_p],
     'y2_conv_fwd_workspace_bytes': [ctypes.POINTER(ConvParams)],
+    'y2_wino_weight': [c_void_p, c_void_p, c_int, c_int, c_void_p],
     'y2_conv_fwd_batch': [ctypes.POINTER(ConvParams), c_int, c_void_p],
     'y2_conv0_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
@@ -162,50 +163,83 @@ TUNE_CACHE = os.environ.get('Y2_TUNE_CACHE')      # optional JSON file persistin
 if TUNE_CACHE and os.path.exists(TUNE_CACHE):
     try:
         import json as _json
-        _TUNE.update({tuple(_json.loads(k)): v for k, v in _json.load(open(TUNE_CACHE)).items()})
+        _TUNE.update({tuple(_json.loads(k)): v for k, v in _json.load(open(TUNE_CACHE)).items()})   # v = [algo, tile]
     except Exception:
         pass
 
 
-def autotune_conv(params, dev):
-    """Measure-don't-guess tile selection for one y2_conv_fwd problem: the first time a problem shape is seen, every
-    tile configuration is timed (HIP events, 3 launches each) and the fastest is cached for the process; later calls only
-    look the answer up.  The outputs written while timing are the real outputs (same arithmetic for every tile).
-    Never called while a hipGraph is being captured (plans are built during warm-up)."""
+WINOGRAD = os.environ.get('Y2_WINOGRAD', '1') != '0'     # 0: never pick the Winograd F(2x2,3x3) algorithm
+WINO_MIN_CIN = 64                                        # below this the transforms cost more than the GEMM saves (measured)
+
+
+def wino_eligible(cout, cin, k, stride=1):
+    """Shapes y2_conv_fwd accepts with algo = Y2_ALGO_WINOGRAD and where it can pay off."""
+    return WINOGRAD and k == 3 and stride in (0, 1) and cin % 4 == 0 and cout % 4 == 0 and cin >= WINO_MIN_CIN
+
+
+def wino_weight(wp, cout, cin):
+    """U [16][Cout][Cin] from a packed 3x3 weight (y2_pack_weight mode 0 or 1)."""
+    u = torch.empty(16 * cout * cin, dtype=torch.float32, device=wp.device)
+    check(lib().y2_wino_weight(ptr(wp), ptr(u), cout, cin, stream()), 'y2_wino_weight')
+    return u
+
+
+def _time_conv(L, params, st):
+    t = float('inf')
+    for _ in range(2):          # best of two batches of 3 launches (DVFS / neighbour noise)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            L.y2_conv_fwd(ctypes.byref(params), st)
+        e1.record()
+        e1.synchronize()
+        t = min(t, e0.elapsed_time(e1))
+    return t
+
+
+def autotune_conv(params, dev, wino_w=None):
+    """Measure-don't-guess algorithm + tile selection for one y2_conv_fwd problem: the first time a problem shape is seen,
+    every tile configuration of the direct kernel - and, when `wino_w` (y2_wino_weight output) is given, of the Winograd
+    path - is timed (HIP events, best of 2 x 3 launches) and the fastest is cached for the process; later calls only
+    look the answer up.  Sets params.algo / params.tile / params.w.  The outputs written while timing are real outputs.
+    Never measures while a hipGraph is being captured (plans are built during warm-up)."""
+    wino_ok = (wino_w is not None and WINOGRAD and params.ksize == 3 and params.stride in (0, 1) and params.pad_plus1 in (0, 2)
+               and not params.transposed and not params.residual and not params.stats and params.out_mode == 0)
     key = (params.B, params.H, params.W, params.Cin, params.ldx, params.Cout, params.ksize, bool(params.y), bool(params.y_pool),
-           bool(params.stats), params.out_mode, params.stride, params.pad_plus1, bool(params.residual), params.transposed, params.out_h, params.out_w, str(dev))
+           bool(params.stats), params.out_mode, params.stride, params.pad_plus1, bool(params.residual), params.transposed, params.out_h, params.out_w, str(dev),
+           bool(wino_ok))
+    w_direct = params.w
+
+    def apply(choice):
+        algo, tile = choice
+        params.algo, params.tile = algo, tile
+        params.w = wino_w.data_ptr() if algo == 1 else w_direct
+        return choice
     hit = _TUNE.get(key)
     if hit is not None:
-        params.tile = hit
-        return hit
+        return apply(tuple(hit) if isinstance(hit, (list, tuple)) else (0, hit))
     if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
-        params.tile = 0
-        return 0
+        return apply((0, 0))
     L = lib()
     st = stream()
-    cands = [5, 3, 2, 1] + ([6] if params.Cout <= 32 else [])
-    best, best_t = 0, float('inf')
+    cands = [(0, t) for t in [5, 3, 2, 1] + ([6] if params.Cout <= 32 else [])]
+    if wino_ok:
+        cands += [(1, t) for t in (5, 3, 2, 1)]
+    best, best_t = (0, 0), float('inf')
     stats_save = params.stats
     params.stats = None          # timing launches must not accumulate statistics twice
-    for tile in cands:
-        params.tile = tile
-        conv_workspace(params, dev)
+    for choice in cands:
+        apply(choice)
+        if conv_workspace(params, dev) < 0:
+            continue
         if L.y2_conv_fwd(ctypes.byref(params), st) != 0:
             continue
-        t = float('inf')
-        for _ in range(2):          # best of two batches of 3 launches (DVFS / neighbour noise)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                L.y2_conv_fwd(ctypes.byref(params), st)
-            e1.record()
-            e1.synchronize()
-            t = min(t, e0.elapsed_time(e1))
+        t = _time_conv(L, params, st)
         if t < best_t:
-            best, best_t = tile, t
+            best, best_t = choice, t
     params.stats = stats_save
-    params.tile = best
-    _TUNE[key] = best
+    apply(best)
+    _TUNE[key] = list(best)
     if TUNE_CACHE:
         try:
             import json as _json

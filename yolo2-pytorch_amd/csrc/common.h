@@ -17,6 +17,11 @@ static inline hipStream_t y2_s(y2_stream_t s) { return reinterpret_cast<hipStrea
 static inline int y2_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline bool y2_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// library-internal cross-file entry points (hidden: not part of the C ABI)
+__attribute__((visibility("hidden"))) int y2_internal_conv_grouped(const y2_conv_params* p, int groups, long long gx, long long gw, long long gy,
+                                                                    y2_stream_t stream, size_t* ws_need);
+__attribute__((visibility("hidden"))) int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need);
+
 constexpr int Y2_NUM_CU = 256;   // MI355X: 8 XCD x 32 CU
 constexpr int Y2_NUM_XCD = 8;
 

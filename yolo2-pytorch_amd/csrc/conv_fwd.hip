@@ -65,6 +65,10 @@ struct ConvArgs {
     const float* res;                   // optional residual added before the activation: res[m*ldr + n]
     int ldr;
     y2_fastdiv d_cin, d_kw, d_howo, d_wo;
+    // grouped (batched) GEMM: `groups` independent problems of identical shape; group g reads x + g*gx, w + g*gw and writes
+    // y + g*gy (floats).  Tiles are numbered group-major.  Used by the Winograd path (16 transform positions).
+    int groups;
+    long long gx, gw, gy;
 };
 
 // pixel index (b*H + y)*W + x and (y, x) of GEMM row m
@@ -374,6 +378,15 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
         tile = a.full_tiles + r / a.ksplit;
         part = r % a.ksplit;
     }
+    const int flat_tile = tile;                   // group-major tile number (split-K scratch is indexed by it)
+    int grp = 0;
+    if (a.groups > 1) {
+        const int tpg = a.tiles_m * a.tiles_n;
+        grp = tile / tpg;
+        tile -= grp * tpg;
+    }
+    const float* gx_ptr = a.x + (size_t)grp * a.gx;
+    const float* gw_ptr = a.w + (size_t)grp * a.gw;
     const int tile_n = tile % a.tiles_n;
     const int tile_m = tile / a.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -430,8 +443,8 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
         const int n = n0 + srow + 32 * i;
         b_base[i] = n < a.Cout ? (unsigned)(((size_t)n * ktot + (GEN ? 0 : 4 * lchunk)) * 4) : OOB;
     }
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gx_ptr), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gw_ptr), 0, a.w_bytes, 0x00020000);
 
     auto issue_slab = [&](int ks_abs, int tap, int c0, int buf) {
         float* sa = smem + buf * STAGE + wave * (8 * BK);
@@ -576,7 +589,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
     if (is_split) {
         // raw accumulators -> partial[(tile - full_tiles) * ksplit + part][MB][NB][4][256 threads][4]: 16-B coalesced stores;
         // conv_splitk_fixup_kernel (same thread geometry) adds the parts and runs the ordinary epilogue
-        float* dst = a.partial + ((size_t)(tile - a.full_tiles) * a.ksplit + part) * (BM * BN);
+        float* dst = a.partial + ((size_t)(flat_tile - a.full_tiles) * a.ksplit + part) * (BM * BN);
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -586,6 +599,12 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
                     f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                     *reinterpret_cast<f32x4*>(dst + (((i * NB + j) * 4 + g) * NT + t) * 4) = v;
                 }
+        return;
+    }
+    if (a.groups > 1) {
+        ConvArgs e = a;
+        e.y = a.y + (size_t)grp * a.gy;
+        conv_epilogue<MB, NB, WM, WN, POOLORD>(e, acc, m0, n0, wm, wn, l31, half);
         return;
     }
     conv_epilogue<MB, NB, WM, WN, POOLORD>(a, acc, m0, n0, wm, wn, l31, half);
@@ -603,7 +622,13 @@ __global__ __launch_bounds__(NTHR) void conv_splitk_fixup_kernel(const ConvArgs 
     const int wave = t >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l31 = lane & 31, half = lane >> 5;
-    const int tile = a.full_tiles + blockIdx.x;
+    int tile = a.full_tiles + blockIdx.x;
+    int grp = 0;
+    if (a.groups > 1) {
+        const int tpg = a.tiles_m * a.tiles_n;
+        grp = tile / tpg;
+        tile -= grp * tpg;
+    }
     const int tile_n = tile % a.tiles_n;
     const int tile_m = tile / a.tiles_n;
     f32x16 acc[MB][NB];
@@ -621,6 +646,12 @@ __global__ __launch_bounds__(NTHR) void conv_splitk_fixup_kernel(const ConvArgs 
                 }
                 acc[i][j][4 * g] = sum[0]; acc[i][j][4 * g + 1] = sum[1]; acc[i][j][4 * g + 2] = sum[2]; acc[i][j][4 * g + 3] = sum[3];
             }
+    if (a.groups > 1) {
+        ConvArgs e = a;
+        e.y = a.y + (size_t)grp * a.gy;
+        conv_epilogue<MB, NB, WM, WN, POOLORD>(e, acc, tile_m * BM, tile_n * BN, wm, wn, l31, half);
+        return;
+    }
     conv_epilogue<MB, NB, WM, WN, POOLORD>(a, acc, tile_m * BM, tile_n * BN, wm, wn, l31, half);
 }
 
@@ -674,7 +705,7 @@ int launch_dma(const ConvArgs& a0, hipStream_t stream, float* ws, size_t ws_byte
     const size_t lds = 2u * (BM + BN) * 32 * sizeof(float);
     const bool ctail = !GEN && (a.Cin % 32) != 0;
     const int nk_all = GEN ? y2_cdiv(a.K, 32) : a.taps * a.cchunks;
-    const long long tiles = (long long)a.tiles_m * a.tiles_n;
+    const long long tiles = (long long)a.tiles_m * a.tiles_n * (a.groups > 1 ? a.groups : 1);
     if (tiles <= 0 || tiles > 0x7fffffffLL) return Y2_EINVAL;
     if (ws_need != nullptr) {   // workspace query: the largest split this layer could use
         int ft, ks;
@@ -1007,8 +1038,10 @@ int choose_tile(long long M, int Cout, int nk) {
 
 }  // namespace
 
-static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need) {
+static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need, int groups = 1, long long gx = 0, long long gw = 0, long long gy = 0) {
     if (ws_need != nullptr) *ws_need = 0;
+    if (p != nullptr && p->algo == Y2_ALGO_WINOGRAD && groups == 1) return y2_internal_wino_conv(p, stream, ws_need);
+    if (p != nullptr && p->algo != Y2_ALGO_DIRECT && groups == 1) return Y2_EINVAL;
     if (p == nullptr || p->x == nullptr || p->w == nullptr) return Y2_EINVAL;
     if (p->y == nullptr && p->y_pool == nullptr && p->stats == nullptr) return Y2_EINVAL;
     if (p->B <= 0 || p->H <= 0 || p->W <= 0 || p->Cin <= 0 || p->Cout <= 0) return Y2_EINVAL;
@@ -1046,6 +1079,7 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
     a.tiles_m = a.tiles_n = 0;
     a.x_bytes = a.w_bytes = 0;
     a.full_tiles = 0x7fffffff; a.ksplit = 1; a.partial = nullptr;
+    a.groups = groups; a.gx = gx; a.gw = gw; a.gy = gy;
     a.d_hw = y2_make_fastdiv((uint32_t)(p->H * p->W)); a.d_w = y2_make_fastdiv((uint32_t)p->W); a.d_w2 = y2_make_fastdiv((uint32_t)(2 * p->W));
     a.stride = stride; a.pad = pad; a.KW = p->ksize; a.Ho = Ho; a.Wo = Wo; a.K = a.taps * p->Cin;
     a.tstride = 1; a.d_ts = y2_make_fastdiv(1);
@@ -1067,16 +1101,17 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
 
     const bool vec = (p->Cin % 4 == 0) && (p->ldx % 4 == 0) && y2_aligned16(p->x) && y2_aligned16(p->w);
     const int nk = standard ? a.taps * y2_cdiv(p->Cin, 32) : y2_cdiv(a.K, 32);
-    int tile = p->tile > 0 ? p->tile : choose_tile(M, p->Cout, nk);
+    int tile = p->tile > 0 ? p->tile : choose_tile(M * groups, p->Cout, nk);
     hipStream_t s = y2_s(stream);
     // tile ids 1,2,3,5,6: LDS-DMA kernel when the operands allow it; 101.. force the register-staged kernel (also the
     // path for channel counts / strides that are not multiples of 4, e.g. pruned checkpoints).  Strided / 7x7 / padded
     // variants and small Cin (K handled as one linear axis) use the GEN instantiation of the DMA kernel.
     const unsigned long long xb = (unsigned long long)Min * p->ldx * 4ull, wb = (unsigned long long)p->Cout * a.taps * p->Cin * 4ull;
-    if (tile == 7 && (!standard || (p->Cin % 16) != 0)) tile = 3;      // the wave-private kernel covers the standard convolutions only
+    if (tile == 7 && (!standard || (p->Cin % 16) != 0 || groups > 1)) tile = 3;      // the wave-private kernel covers the standard convolutions only
     const bool dma_tile = (tile == 1 || tile == 2 || tile == 3 || tile == 5 || tile == 6 || tile == 7);
     const bool dma_ok = vec && xb < 0x7fffffffull && wb < 0x7fffffffull && dma_tile;
-    const bool gen = !standard || (dma_ok && tile != 7 && p->Cin < 32 && !pool && p->out_mode == 0);
+    const bool gen = !standard || (groups == 1 && dma_ok && tile != 7 && p->Cin < 32 && !pool && p->out_mode == 0);
+    if (groups > 1 && (!dma_ok || gen || pool || p->out_mode != 0 || p->stats != nullptr || p->residual != nullptr)) return Y2_ENOSUP;
     float* ws = p->workspace;
     const size_t wsb = (ws != nullptr && y2_aligned16(ws)) ? (size_t)p->workspace_bytes : 0;
     if (gen) {
@@ -1096,6 +1131,12 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
 }
 
 extern "C" int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream) { return conv_fwd_impl(p, stream, nullptr); }
+
+// `groups` independent GEMMs of one shape in one launch (see ConvArgs::groups); library-internal (wino.hip).
+int y2_internal_conv_grouped(const y2_conv_params* p, int groups, long long gx, long long gw, long long gy, y2_stream_t stream, size_t* ws_need) {
+    if (groups < 1) return Y2_EINVAL;
+    return conv_fwd_impl(p, stream, ws_need, groups, gx, gw, gy);
+}
 
 // Bytes of scratch y2_conv_fwd can use for this problem (0 = none needed); pass it via y2_conv_params.workspace.
 extern "C" long long y2_conv_fwd_workspace_bytes(const y2_conv_params* p) {

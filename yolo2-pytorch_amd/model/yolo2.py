@@ -167,12 +167,14 @@ class Darknet(nn.Module):
             else:
                 scale = None
                 shift = _hip.f32c(blk.conv.bias.detach()) if blk.conv.bias is not None else None
-            prep[blk] = (wp, scale, shift)
+            # Winograd-transformed copy of the deep 3x3 filters (the plan picks direct or Winograd per layer by measurement)
+            u = _hip.wino_weight(wp, cout, cin) if (blk is not first and _hip.wino_eligible(cout, cin, k)) else None
+            prep[blk] = (wp, scale, shift, u)
         self._cache = (ver, prep)
         return prep
 
     def _conv_params(self, prep, blk, x, B, H, W, ldx, y=None, y_pool=None, ldy=0, coff=0, ldp=0, poff=0, out_mode=0):
-        wp, scale, shift = prep[blk]
+        wp, scale, shift, _ = prep[blk]
         cout, cin = blk.conv.weight.shape[:2]
         p = _hip.ConvParams()
         p.x, p.w, p.scale, p.shift = x.data_ptr(), wp.data_ptr(), (scale.data_ptr() if scale is not None else None), (shift.data_ptr() if shift is not None else None)
@@ -195,9 +197,12 @@ class Darknet(nn.Module):
         b1, b2, b3 = self._blocks()
         plist, flops, keep = [], 0.0, []
 
-        def add(*args, **kw):
-            p, f = self._conv_params(prep, *args, **kw)
+        ulist = []
+
+        def add(blk, *args, **kw):
+            p, f = self._conv_params(prep, blk, *args, **kw)
             plist.append(p)
+            ulist.append(prep[blk][3])
             return f
         name, blk0, pool = b1[0]
         c = blk0.conv.weight.shape[0]
@@ -250,14 +255,18 @@ class Darknet(nn.Module):
                 flops += add(blk, cur, B, h, w, ld, y=out, ldy=c)
                 cur, ld = out, c
                 keep.append(out)
-        for p in plist:
-            _hip.autotune_conv(p, dev)      # per-layer tile choice by measurement (cached per problem shape)
+        for p, u in zip(plist, ulist):
+            _hip.autotune_conv(p, dev, wino_w=u)      # per-layer algorithm + tile choice by measurement (cached per problem shape)
         need = max([_hip.lib().y2_conv_fwd_workspace_bytes(ctypes.byref(p)) for p in plist] + [0])
         ws = _hip.workspace(dev, need) if need > 0 else None
         for p in plist:
             p.workspace, p.workspace_bytes = (ws.data_ptr(), ws.numel() * 4) if ws is not None else (None, 0)
         arr = (_hip.ConvParams * len(plist))(*plist)
-        plan = dict(arr=arr, n=len(plist), first=first, head_index=head_index, head_shape=head_shape, flops=flops,
+        # multiply-adds the MFMA pipe really executes: a Winograd layer runs 16 GEMMs over ceil(H/2)*ceil(W/2) tiles per image
+        executed = sum(2.0 * p.Cin * p.Cout * (16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo == 1 else p.ksize ** 2 * p.B * p.H * p.W)
+                       for p in plist)
+        plan = dict(arr=arr, n=len(plist), first=first, head_index=head_index, head_shape=head_shape, flops=flops, flops_executed=executed,
+                    algos=[int(p.algo) for p in plist],
                     flops0=2.0 * cin0 * blk0.conv.weight.shape[0] * 9 * B * H * W, keep=(keep, full_last, cat, prep, ws))
         self._plan_cache = (key, plan)
         return plan
@@ -276,7 +285,7 @@ class Darknet(nn.Module):
         plan = self._plan(prep, dev, B, cin0, H, W)
         st = _hip.stream()
         blk0 = self.layers1[0]
-        wp, scale, shift = prep[blk0]
+        wp, scale, shift, _ = prep[blk0]
         c = blk0.conv.weight.shape[0]
         out = torch.empty(plan['head_shape'], dtype=torch.float32, device=dev)
         plan['arr'][plan['head_index']].y = out.data_ptr()
@@ -292,7 +301,7 @@ class Darknet(nn.Module):
         if prof is not None:
             ev[2].record()
             prof.append(('conv0', plan['flops0'], ev[0], ev[1]))
-            prof.append(('conv_fwd', plan['flops'], ev[1], ev[2]))
+            prof.append(('conv_fwd', plan['flops'], ev[1], ev[2], plan['flops_executed'], sum(plan['algos'])))
         return out
 
     def forward(self, x):
@@ -365,7 +374,7 @@ class Tiny(Darknet):
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         mods = list(self.layers)
         blk0 = mods[0]
-        wp, scale, shift = prep[blk0]
+        wp, scale, shift, _ = prep[blk0]
         c = blk0.conv.weight.shape[0]
         cur = new(B, H // 2, W // 2, c)
         _hip.check(L.y2_conv0_fwd(_hip.ptr(x), _hip.ptr(wp), _hip.ptr(scale), _hip.ptr(shift), None, _hip.ptr(cur), None,
@@ -383,7 +392,7 @@ class Tiny(Darknet):
                 else:
                     out = new(B, h, w, c)
                     p, _ = self._conv_params(prep, m, cur, B, h, w, ld, y=out, ldy=c)
-                _hip.autotune_conv(p, dev)
+                _hip.autotune_conv(p, dev, wino_w=prep[m][3])
                 _hip.conv_workspace(p, dev)
                 _hip.check(L.y2_conv_fwd(ctypes.byref(p), st), 'y2_conv_fwd')
                 cur, ld = out, c
