@@ -144,8 +144,11 @@ def test_conv_fwd_winograd_matches_fp64_reference(B, cin, cout, H, W, tile, pool
     w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
     scale = torch.randn(cout, generator=g)
     shift = torch.randn(cout, generator=g) * 0.1
-    _, ref = ref_conv(x, w, scale, shift, 0.1, 3)
-    out = run_conv(x, w, scale, shift, 0.1, 3, tile=tile, pool=pool, both=both, extra=0 if pool else 4, coff=0 if pool else 8, wino=True)
+    z, ref = ref_conv(x, w, scale, shift, 0.1, 3)
+    out = run_conv(x, w, scale, shift, 0.1, 3, tile=tile, pool=pool, both=both, extra=0 if pool else 4, coff=0 if pool else 8, wino=True, stats=True)
+    s1, s2 = z.sum((0, 2, 3)), (z * z).sum((0, 2, 3))      # training-mode BN statistics from the output transform (valid pixels only)
+    np.testing.assert_allclose(out['stats'][:cout].numpy(), s1.numpy(), rtol=1e-5, atol=2e-5 * float(s2.max().sqrt()))
+    np.testing.assert_allclose(out['stats'][cout:].numpy(), s2.numpy(), rtol=2e-5)
     if pool:
         assert rel_err(out['y_pool'].permute(0, 3, 1, 2), F.max_pool2d(ref, 2)) <= 4 * CONV_TOL
     if both or not pool:

@@ -204,7 +204,7 @@ def autotune_conv(params, dev, wino_w=None):
     look the answer up.  Sets params.algo / params.tile / params.w.  The outputs written while timing are real outputs.
     Never measures while a hipGraph is being captured (plans are built during warm-up)."""
     wino_ok = (wino_w is not None and WINOGRAD and params.ksize == 3 and params.stride in (0, 1) and params.pad_plus1 in (0, 2)
-               and not params.transposed and not params.residual and not params.stats and params.out_mode == 0)
+               and not params.transposed and not params.residual and params.out_mode == 0)
     key = (params.B, params.H, params.W, params.Cin, params.ldx, params.Cout, params.ksize, bool(params.y), bool(params.y_pool),
            bool(params.stats), params.out_mode, params.stride, params.pad_plus1, bool(params.residual), params.transposed, params.out_h, params.out_w, str(dev),
            bool(wino_ok))

@@ -15,7 +15,8 @@
 //   2. 16 independent GEMMs M[p] = V[p] (T x Cin) * U[p]^T (Cin x Cout) in ONE launch of conv_fwd_dma_kernel (its grouped
 //      mode): the same LDS-DMA / MFMA 32x32x2 fp32 pipeline, 16*T*Cin*Cout MACs instead of 9*H*W*Cin*Cout (2.25x fewer
 //      for even H, W)
-//   3. wino_output_kernel:  y = act(scale * (A^T M A) + shift), 2x2 pixels per tile, optional in-thread 2x2 max-pool
+//   3. wino_output_kernel:  y = act(scale * (A^T M A) + shift), 2x2 pixels per tile, optional in-thread 2x2 max-pool and
+//      per-channel sum / sum of squares of the raw output (training-mode BatchNorm statistics)
 // Stages 1 and 3 are streaming kernels (HBM/Infinity-Cache bound: V is 4x the input, M is 4x the output).
 #include "common.h"
 
@@ -76,70 +77,109 @@ struct WinoOutArgs {
     const float* shift;
     float* y;
     float* y_pool;
-    int B, H, W, Cout, ldy, coff, ldp, poff, th, tw, T, n4n;
+    double* stats;
+    int B, H, W, Cout, ldy, coff, ldp, poff, th, tw, T, n4n, loop;
     float slope;
-    y2_fastdiv d_n4, d_tt, d_tw;
+    y2_fastdiv d_tt, d_tw;
 };
 
+// Block = blockDim.x channel quads x blockDim.y tiles (256 threads); thread (x, y) handles channel quad
+// blockIdx.y*blockDim.x + x of the tiles (blockIdx.x*loop + i)*blockDim.y + y, i < loop.  STATS: per-channel sum / sum of
+// squares of the raw convolution output z (training-mode BatchNorm, model/yolo2.py:59) over the VALID pixels, reduced over
+// the block's tiles in registers + LDS and added with one fp64 atomic pair per channel per block into replicated
+// accumulators (Y2_STATS_REPL, as conv_fwd.hip's epilogue).
+template <bool STATS>
 __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs a) {
-    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t t = y2_div(idx, a.d_n4);
-    if (t >= (uint32_t)a.T) return;
-    const int n4 = (int)(idx - t * (uint32_t)a.n4n);
-    const int b = (int)y2_div(t, a.d_tt);
-    const int r = (int)t - b * a.th * a.tw;
-    const int ty = (int)y2_div((uint32_t)r, a.d_tw);
-    const int tx = r - ty * a.tw;
-    const float* src = a.m + (size_t)t * a.Cout + 4 * n4;
-    const size_t plane = (size_t)a.T * a.Cout;
-    f32x4 m[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const f32x4*>(src + (4 * i + j) * plane);
-    f32x4 s[2][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        s[0][j] = m[0][j] + m[1][j] + m[2][j];
-        s[1][j] = m[1][j] - m[2][j] - m[3][j];
-    }
-    f32x4 o[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        o[i][0] = s[i][0] + s[i][1] + s[i][2];
-        o[i][1] = s[i][1] - s[i][2] - s[i][3];
-    }
+    __shared__ float red[STATS ? 256 * 8 : 1];
+    const int n4 = blockIdx.y * blockDim.x + threadIdx.x;
+    const bool nok = n4 < a.n4n;
     const int n = 4 * n4;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (a.scale != nullptr) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-    if (a.shift != nullptr) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+    if (nok && a.scale != nullptr) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+    if (nok && a.shift != nullptr) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    const size_t plane = (size_t)a.T * a.Cout;
+    for (int it = 0; it < a.loop; ++it) {
+        const int t = (blockIdx.x * a.loop + it) * blockDim.y + threadIdx.y;
+        if (t >= a.T || !nok) continue;
+        const int b = (int)y2_div((uint32_t)t, a.d_tt);
+        const int r = t - b * a.th * a.tw;
+        const int ty = (int)y2_div((uint32_t)r, a.d_tw);
+        const int tx = r - ty * a.tw;
+        const float* src = a.m + (size_t)t * a.Cout + n;
+        f32x4 m[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const f32x4*>(src + (4 * i + j) * plane);
+        f32x4 s[2][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float u = o[i][j][e] * sc[e] + sh[e];
-                o[i][j][e] = u > 0.f ? u : u * a.slope;
-            }
-    if (a.y != nullptr) {
+        for (int j = 0; j < 4; ++j) {
+            s[0][j] = m[0][j] + m[1][j] + m[2][j];
+            s[1][j] = m[1][j] - m[2][j] - m[3][j];
+        }
+        f32x4 o[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int yy = 2 * ty + i;
-            if (yy >= a.H) break;
+            o[i][0] = s[i][0] + s[i][1] + s[i][2];
+            o[i][1] = s[i][1] - s[i][2] - s[i][3];
+        }
+        const bool y1 = 2 * ty + 1 < a.H, x1 = 2 * tx + 1 < a.W;
+        if (STATS) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int xx = 2 * tx + j;
-                if (xx >= a.W) break;
-                *reinterpret_cast<f32x4*>(a.y + ((size_t)(b * a.H + yy) * a.W + xx) * a.ldy + a.coff + n) = o[i][j];
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if ((i == 1 && !y1) || (j == 1 && !x1)) continue;
+                    s1 += o[i][j];
+                    s2 += o[i][j] * o[i][j];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = o[i][j][e] * sc[e] + sh[e];
+                    o[i][j][e] = u > 0.f ? u : u * a.slope;
+                }
+        if (a.y != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i == 1 && !y1) break;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (j == 1 && !x1) break;
+                    *reinterpret_cast<f32x4*>(a.y + ((size_t)(b * a.H + 2 * ty + i) * a.W + 2 * tx + j) * a.ldy + a.coff + n) = o[i][j];
+                }
             }
         }
-    }
-    if (a.y_pool != nullptr) {   // H, W even (host check): the tile IS one pooling window
-        f32x4 p;
+        if (a.y_pool != nullptr) {   // H, W even (host check): the tile IS one pooling window
+            f32x4 p;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) p[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
-        *reinterpret_cast<f32x4*>(a.y_pool + ((size_t)(b * a.th + ty) * a.tw + tx) * a.ldp + a.poff + n) = p;
+            for (int e = 0; e < 4; ++e) p[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
+            *reinterpret_cast<f32x4*>(a.y_pool + ((size_t)(b * a.th + ty) * a.tw + tx) * a.ldp + a.poff + n) = p;
+        }
+    }
+    if (STATS) {
+        float* mine = red + (threadIdx.y * blockDim.x + threadIdx.x) * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { mine[e] = s1[e]; mine[4 + e] = s2[e]; }
+        __syncthreads();
+        if (threadIdx.y == 0 && nok) {
+            double* st = a.stats + (size_t)(blockIdx.x % Y2_STATS_REPL) * 2 * a.Cout;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t1 = 0.f, t2 = 0.f;
+                for (int yy = 0; yy < (int)blockDim.y; ++yy) {
+                    t1 += red[(yy * blockDim.x + threadIdx.x) * 8 + e];
+                    t2 += red[(yy * blockDim.x + threadIdx.x) * 8 + 4 + e];
+                }
+                atomicAdd(st + n + e, (double)t1);
+                atomicAdd(st + a.Cout + n + e, (double)t2);
+            }
+        }
     }
 }
 
@@ -186,12 +226,12 @@ extern "C" int y2_wino_weight(const float* w_packed, float* u, int32_t Cout, int
 int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need) {
     if (ws_need != nullptr) *ws_need = 0;
     if (p == nullptr || p->x == nullptr || p->w == nullptr) return Y2_EINVAL;
-    if (p->y == nullptr && p->y_pool == nullptr) return Y2_EINVAL;
+    if (p->y == nullptr && p->y_pool == nullptr && p->stats == nullptr) return Y2_EINVAL;
     if (p->B <= 0 || p->H <= 0 || p->W <= 0 || p->Cin <= 0 || p->Cout <= 0 || p->ldx < p->Cin) return Y2_EINVAL;
     const int stride = p->stride > 0 ? p->stride : 1;
     const int pad = p->pad_plus1 > 0 ? p->pad_plus1 - 1 : 1;
     if (p->ksize != 3 || stride != 1 || pad != 1 || p->transposed != 0) return Y2_ENOSUP;
-    if (p->residual != nullptr || p->out_mode != 0 || p->stats != nullptr) return Y2_ENOSUP;
+    if (p->residual != nullptr || p->out_mode != 0) return Y2_ENOSUP;
     if ((p->Cin % 4) != 0 || (p->Cout % 4) != 0 || (p->ldx % 4) != 0 || !y2_aligned16(p->x) || !y2_aligned16(p->w)) return Y2_ENOSUP;
     if (p->y != nullptr && (p->ldy < p->coff + p->Cout)) return Y2_EINVAL;
     if (p->y != nullptr && ((p->ldy % 4) != 0 || (p->coff % 4) != 0 || !y2_aligned16(p->y))) return Y2_ENOSUP;
@@ -236,11 +276,17 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     if (rc != Y2_OK) return rc;
 
     WinoOutArgs oa;
-    oa.m = M; oa.scale = p->scale; oa.shift = p->shift; oa.y = p->y; oa.y_pool = p->y_pool;
+    oa.m = M; oa.scale = p->scale; oa.shift = p->shift; oa.y = p->y; oa.y_pool = p->y_pool; oa.stats = p->stats;
     oa.B = p->B; oa.H = p->H; oa.W = p->W; oa.Cout = p->Cout; oa.ldy = p->ldy; oa.coff = p->coff; oa.ldp = p->ldp; oa.poff = p->poff;
     oa.th = th; oa.tw = tw; oa.T = (int)T; oa.n4n = p->Cout / 4; oa.slope = p->slope;
-    oa.d_n4 = y2_make_fastdiv((uint32_t)oa.n4n); oa.d_tt = ia.d_tt; oa.d_tw = ia.d_tw;
-    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)y2_cdiv(T * oa.n4n, 256)), dim3(256), 0, s, oa);
+    oa.d_tt = ia.d_tt; oa.d_tw = ia.d_tw;
+    int nx = 64;
+    while (nx > 4 && nx / 2 >= oa.n4n) nx /= 2;
+    const int ny = 256 / nx;
+    oa.loop = p->stats != nullptr ? 8 : 1;
+    const dim3 grid((unsigned)y2_cdiv(T, (long long)ny * oa.loop), (unsigned)y2_cdiv(oa.n4n, nx));
+    if (p->stats != nullptr) hipLaunchKernelGGL(wino_output_kernel<true>, grid, dim3(nx, ny), 0, s, oa);
+    else hipLaunchKernelGGL(wino_output_kernel<false>, grid, dim3(nx, ny), 0, s, oa);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

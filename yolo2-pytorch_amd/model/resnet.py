@@ -127,6 +127,8 @@ class ResNet(nn.Module):
         st = _hip.stream()
         prep = {}
 
+        wino = {}
+
         def fold(conv, bn):
             w = _hip.f32c(conv.weight.detach())
             _hip.require_gpu(w)
@@ -144,6 +146,8 @@ class ResNet(nn.Module):
             else:
                 scale, shift = None, (_hip.f32c(conv.bias.detach()) if conv.bias is not None else None)
             prep[conv] = (wp, scale, shift, cin, cout, k)
+            if _hip.wino_eligible(cout, cin, k, conv.stride[0]) and conv.padding[0] == 1:
+                wino[id(wp)] = _hip.wino_weight(wp, cout, cin)     # Winograd copy of the stride-1 3x3 filters (conv2 of every block)
         fold(self.conv1, self.bn1)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
@@ -152,6 +156,7 @@ class ResNet(nn.Module):
                 if blk.downsample is not None:
                     fold(blk.downsample[0], blk.downsample[1])
         fold(self.conv, None)
+        prep['wino'] = wino
         self._cache = (ver, prep)
         return prep
 
@@ -160,7 +165,7 @@ class ResNet(nn.Module):
         if self._plan_cache is not None and self._plan_cache[0] == key:
             return self._plan_cache[1]
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        keep, flops = [], [0.0]
+        keep, flops, ulist = [], [0.0], {}
 
         def conv_params(conv, x, h, w, ldx, y, stride, pad, slope, residual=None):
             wp, scale, shift, cin, cout, k = prep[conv]
@@ -171,6 +176,7 @@ class ResNet(nn.Module):
             p.y, p.ldy = y.data_ptr(), cout
             p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize = B, h, w, cin, ldx, cout, k
             p.stride, p.pad_plus1, p.slope, p.tile = stride, pad + 1, slope, 0
+            ulist[id(p)] = prep['wino'].get(id(wp))
             if residual is not None:
                 p.residual, p.ldr = residual.data_ptr(), cout
             ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
@@ -213,7 +219,7 @@ class ResNet(nn.Module):
         plist.append(conv_params(self.conv, cur, h, w, ld, cur, 1, 0, 1.0))
         head_shape = (B, h, w, self.conv.weight.shape[0])
         for p in [p_stem] + plist:
-            _hip.autotune_conv(p, dev) if p is not plist[head_index] else None
+            _hip.autotune_conv(p, dev, wino_w=ulist.get(id(p))) if p is not plist[head_index] else None
         need = max([_hip.lib().y2_conv_fwd_workspace_bytes(ctypes.byref(p)) for p in [p_stem] + plist[:head_index]] + [0])
         ws = _hip.workspace(dev, need) if need > 0 else None
         for p in [p_stem] + plist:

@@ -45,7 +45,9 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
     p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize = B, H, W, cin, ldx, cout, k
     p.ldy, p.coff, p.ldp, p.poff, p.out_mode = ldy, coff, ldp, 0, out_mode
     p.slope, p.tile = slope, 0
-    _hip.autotune_conv(p, x.device)
+    # 3x3 layers: also offer the Winograd algorithm (filter transform of the packed weight: fprop and dgrad alike)
+    u = _hip.wino_weight(wp, cout, cin) if (out_mode == 0 and _hip.wino_eligible(cout, cin, k)) else None
+    _hip.autotune_conv(p, x.device, wino_w=u)
     _hip.conv_workspace(p, x.device)
     _hip.check(L.y2_conv_fwd(ctypes.byref(p), st), 'y2_conv_fwd')
 
@@ -415,7 +417,8 @@ def _gen_conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, stride, pad, stats=No
     p.stride, p.pad_plus1 = stride, pad + 1
     if transposed:
         p.transposed, p.out_h, p.out_w = 1, out_hw[0], out_hw[1]
-    _hip.autotune_conv(p, x.device)
+    u = _hip.wino_weight(wp, cout, cin) if (not transposed and stride == 1 and pad == 1 and _hip.wino_eligible(cout, cin, k)) else None
+    _hip.autotune_conv(p, x.device, wino_w=u)
     _hip.conv_workspace(p, x.device)
     _hip.check(L.y2_conv_fwd(ctypes.byref(p), st), 'y2_conv_fwd')
 
