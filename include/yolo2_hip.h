@@ -109,6 +109,13 @@ typedef struct y2_conv_params {
  * multiplications, results within fp32 rounding of the direct sum (tests state the tolerance). */
 int y2_wino_weight(const float* w_packed, float* u, int32_t Cout, int32_t Cin, y2_stream_t stream);
 
+/* Winograd form of y2_conv_wgrad for a 3x3 / stride-1 / same-padding convolution: dw_packed[Cout][9][Cin] = (not +=) the
+ * weight gradient; 16 reductions over ceil(H/2)*ceil(W/2) tiles per image instead of 9 over H*W pixels.  Cin, Cout, ldx,
+ * ldz multiples of 4; workspace of y2_wino_wgrad_workspace_bytes() bytes (transformed input, transformed gradient, dU). */
+long long y2_wino_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
+int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t ldx,
+                  int32_t Cout, int32_t ldz, float* workspace, long long workspace_bytes, y2_stream_t stream);
+
 int y2_conv_fwd(const y2_conv_params* p, y2_stream_t stream);
 
 /* Scratch bytes this problem can use (tiles that do not fill the last round of the 256 CUs are split along K into a

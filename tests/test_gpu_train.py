@@ -60,6 +60,39 @@ def test_conv_wgrad_and_dgrad(B, cin, cout, H, W, k):
     assert rel(dx.permute(0, 3, 1, 2), x.grad) <= TOL
 
 
+@pytest.mark.parametrize('B,cin,cout,H,W', [(2, 32, 64, 8, 12), (3, 256, 128, 13, 13), (1, 128, 256, 26, 26), (2, 40, 72, 7, 5), (4, 512, 1024, 13, 13)])
+def test_winograd_wgrad_and_dgrad(B, cin, cout, H, W):
+    """y2_wino_wgrad (16 grouped reductions over tiles) and the Winograd data gradient (algo = 1 on the rotated filter)
+    against fp64 autograd; odd sizes exercise the ragged last tile row / column."""
+    import _hip
+    L = _hip.lib()
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(B, cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    dz = torch.randn(B, cout, H, W, generator=g, dtype=torch.float64)
+    F.conv2d(x, w, padding=1).backward(dz)
+    d = dev()
+    xd, dzd = nhwc(x.detach().float()).to(d), nhwc(dz.float()).to(d)
+    need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
+    ws = torch.empty(need // 4 + 4, device=d)
+    dwp = torch.full((w.numel(),), 7.0, device=d)      # overwritten, not accumulated
+    _hip.check(L.y2_wino_wgrad(_hip.ptr(xd), _hip.ptr(dzd), _hip.ptr(dwp), B, H, W, cin, cin, cout, cout, _hip.ptr(ws), ws.numel() * 4, _hip.stream()), 'wino_wgrad')
+    dw = torch.empty(cout, cin, 3, 3, device=d)
+    _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cout, cin, 3, _hip.stream()), 'unpack')
+    assert rel(dw, w.grad) <= 4 * TOL
+    wd = torch.empty(w.numel(), device=d)
+    wdev = w.detach().float().to(d).contiguous()
+    _hip.check(L.y2_pack_weight(_hip.ptr(wdev), _hip.ptr(wd), cout, cin, 3, 1, _hip.stream()), 'pack1')
+    u = _hip.wino_weight(wd, cin, cout)
+    dx = torch.empty(B, H, W, cin, device=d)
+    p = _hip.ConvParams()
+    p.x, p.w, p.y, p.algo = dzd.data_ptr(), u.data_ptr(), dx.data_ptr(), 1
+    p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize, p.ldy, p.slope = B, H, W, cout, cout, cin, 3, cin, 1.0
+    _hip.conv_workspace(p, d)
+    _hip.check(L.y2_conv_fwd(ctypes.byref(p), _hip.stream()), 'wino dgrad')
+    assert rel(dx.permute(0, 3, 1, 2), x.grad) <= 4 * TOL
+
+
 @pytest.mark.parametrize('B,cin,cout,H,W', [(2, 3, 32, 16, 32), (1, 3, 40, 9, 13), (2, 1, 8, 6, 6)])
 def test_conv0_wgrad(B, cin, cout, H, W):
     import _hip

@@ -40,6 +40,8 @@ SIGNATURES = {
     'y2_conv_fwd': [ctypes.POINTER(ConvParams), c_void_p],
     'y2_conv_fwd_workspace_bytes': [ctypes.POINTER(ConvParams)],
     'y2_wino_weight': [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    'y2_wino_wgrad_workspace_bytes': [c_int, c_int, c_int, c_int, c_int],
+    'y2_wino_wgrad': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, ctypes.c_longlong, c_void_p],
     'y2_conv_fwd_batch': [ctypes.POINTER(ConvParams), c_int, c_void_p],
     'y2_conv0_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
@@ -104,6 +106,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = c_int
         l.y2_conv_fwd_workspace_bytes.restype = ctypes.c_longlong
+        l.y2_wino_wgrad_workspace_bytes.restype = ctypes.c_longlong
         l.y2_build_info.argtypes = []
         l.y2_build_info.restype = ctypes.c_char_p
         _lib = l
@@ -247,6 +250,56 @@ def autotune_conv(params, dev, wino_w=None):
         except Exception:
             pass
     return best
+
+
+_WGRAD_TUNE = {}
+_WGRAD_WS = {}
+
+
+def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k):
+    """Packed weight gradient dw[cout][k*k][cin] of a stride-1 "same" convolution: y2_conv_wgrad (9 shifted reductions
+    over pixels) or, for 3x3 layers where it measures faster, y2_wino_wgrad (16 reductions over 2x2 tiles).  The choice
+    is timed once per problem shape and cached."""
+    L, st, dev = lib(), stream(), x.device
+    dwp = torch.zeros(cout * cin * k * k, dtype=torch.float32, device=dev)
+
+    def direct():
+        check(L.y2_conv_wgrad(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, k, st), 'y2_conv_wgrad')
+    if not wino_eligible(cout, cin, k) or (ldx % 4) or (ldz % 4):
+        direct()
+        return dwp
+    need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
+    ws = _WGRAD_WS.get(str(dev))
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=dev)
+        _WGRAD_WS[str(dev)] = ws
+
+    def wino():
+        check(L.y2_wino_wgrad(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, ptr(ws), ws.numel() * 4, st), 'y2_wino_wgrad')
+    key = (B, H, W, cin, ldx, cout, ldz, str(dev))
+    choice = _WGRAD_TUNE.get(key)
+    if choice is None:
+        if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+            choice = 1 if cin >= 128 else 0
+        else:
+            times = []
+            for fn in (direct, wino):
+                fn()
+                t = float('inf')
+                for _ in range(2):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    fn()
+                    fn()
+                    e1.record()
+                    e1.synchronize()
+                    t = min(t, e0.elapsed_time(e1))
+                times.append(t)
+            choice = 1 if times[1] < times[0] else 0
+            _WGRAD_TUNE[key] = choice
+            dwp.zero_()          # the timing launches of the direct kernel accumulated into dwp
+    (wino if choice == 1 else direct)()
+    return dwp
 
 
 def f32c(t):

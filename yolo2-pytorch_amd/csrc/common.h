@@ -20,6 +20,8 @@ static inline bool y2_aligned16(const void* p) { return (reinterpret_cast<uintpt
 // library-internal cross-file entry points (hidden: not part of the C ABI)
 __attribute__((visibility("hidden"))) int y2_internal_conv_grouped(const y2_conv_params* p, int groups, long long gx, long long gw, long long gy,
                                                                     y2_stream_t stream, size_t* ws_need);
+__attribute__((visibility("hidden"))) int y2_internal_wgrad_grouped(const float* x, const float* dz, float* dw, long long M, int Cin, int Cout, int groups,
+                                                                     long long gx, long long gz, long long gw, y2_stream_t stream);
 __attribute__((visibility("hidden"))) int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need);
 
 constexpr int Y2_NUM_CU = 256;   // MI355X: 8 XCD x 32 CU

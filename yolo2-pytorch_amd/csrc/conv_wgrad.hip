@@ -30,6 +30,9 @@ struct WgradArgs {
     int Hi, Wi, stride, pad, KW;              // conv input size, stride, padding, kernel width
     int M, tiles_i, tiles_j, splits, slabs_per_split;
     unsigned x_bytes, dz_bytes;
+    // grouped mode (Winograd wgrad: 16 independent reductions of one shape): group g uses x + g*gx, dz + g*gz, dw + g*gw
+    int groups;
+    long long gx, gz, gw;
 };
 
 template <int TI, int WAVES_I>
@@ -52,6 +55,15 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     const int l31 = lane & 31, half = lane >> 5;
 
     int bid = blockIdx.x;
+    int grp = 0;
+    if (a.groups > 1) {
+        const int per = a.tiles_i * a.tiles_j * a.splits;
+        grp = bid / per;
+        bid -= grp * per;
+    }
+    const float* gx_ptr = a.x + (size_t)grp * a.gx;
+    const float* gz_ptr = a.dz + (size_t)grp * a.gz;
+    float* gw_ptr = a.dw + (size_t)grp * a.gw;
     const int split = bid % a.splits; bid /= a.splits;
     const int tj = bid % a.tiles_j;
     const int ti = bid / a.tiles_j;
@@ -90,8 +102,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         py[p] = idx / a.W;
         px[p] = idx - py[p] * a.W;
     }
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz), 0, a.dz_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gx_ptr), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gz_ptr), 0, a.dz_bytes, 0x00020000);
 
     auto issue_slab = [&](int slab, int buf) {
         float* sa = smem + buf * STAGE + wave * 256;          // every DMA instruction of a wave fills 256 contiguous floats
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int co = i0 + wm * WI + ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (co < a.Cout) {
-                    float* dst = a.dw + (size_t)co * ncols + j;
+                    float* dst = gw_ptr + (size_t)co * ncols + j;
                     if (a.splits > 1) atomicAdd(dst, acc[ib][jbk][r]);
                     else *dst = acc[ib][jbk][r];
                 }
@@ -183,8 +195,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 
 // dW[Cout][k*k][Cin] (packed layout, y2_unpack_weight_grad converts to the state_dict layout) += / = wgrad.
 // dw must be zero-filled by the caller when the kernel decides to split (it always may): zero it unconditionally.
-extern "C" int y2_conv_wgrad_ex(const float* x, const float* dz, float* dw, int B, int Hi, int Wi, int Cin, int ldx, int Cout, int ldz,
-                                int ksize, int stride, int pad, y2_stream_t stream) {
+static int wgrad_impl(const float* x, const float* dz, float* dw, int B, int Hi, int Wi, int Cin, int ldx, int Cout, int ldz,
+                      int ksize, int stride, int pad, y2_stream_t stream, int groups, long long gx, long long gz, long long gw) {
     if (!x || !dz || !dw || B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0) return Y2_EINVAL;
     if (ksize < 1 || ksize > 7 || stride < 1 || pad < 0) return Y2_ENOSUP;
     if (ldx < Cin || ldz < Cout) return Y2_EINVAL;
@@ -199,20 +211,21 @@ extern "C" int y2_conv_wgrad_ex(const float* x, const float* dz, float* dw, int 
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.Cout = Cout; a.ldz = ldz; a.taps = ksize * ksize;
     a.Hi = Hi; a.Wi = Wi; a.stride = stride; a.pad = pad; a.KW = ksize;
     a.M = (int)M;
+    a.groups = groups; a.gx = gx; a.gz = gz; a.gw = gw;
     const int TI = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
     a.tiles_i = y2_cdiv(Cout, TI);
     a.tiles_j = y2_cdiv(a.taps * Cin, TJ);
     const int tiles = a.tiles_i * a.tiles_j;
     const int slabs = y2_cdiv(M, KS);
     // enough workgroups to fill the chip several times over, but >= 8 slabs each so the atomic epilogue stays small
-    int splits = y2_cdiv(4 * Y2_NUM_CU, tiles);
+    int splits = y2_cdiv(4 * Y2_NUM_CU, (long long)tiles * groups);
     const int max_splits = slabs / 8 > 0 ? slabs / 8 : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     a.slabs_per_split = y2_cdiv(slabs, splits);
     a.splits = y2_cdiv(slabs, a.slabs_per_split);
     a.x_bytes = (unsigned)xb; a.dz_bytes = (unsigned)zb;
-    const long long grid = (long long)tiles * a.splits;
+    const long long grid = (long long)tiles * a.splits * groups;
     if (grid > 0x7fffffffLL) return Y2_EINVAL;
     hipStream_t s = y2_s(stream);
     const size_t lds = 2u * (size_t)(KS * TI + KS * TJ) * sizeof(float);
@@ -320,6 +333,19 @@ extern "C" int y2_conv0_wgrad(const float* x_nchw, const float* dz, float* dw, i
     else hipLaunchKernelGGL((conv0_wgrad_kernel<2>), dim3(grid), dim3(256), 0, y2_s(stream), a);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
+}
+
+extern "C" int y2_conv_wgrad_ex(const float* x, const float* dz, float* dw, int B, int Hi, int Wi, int Cin, int ldx, int Cout, int ldz,
+                                int ksize, int stride, int pad, y2_stream_t stream) {
+    return wgrad_impl(x, dz, dw, B, Hi, Wi, Cin, ldx, Cout, ldz, ksize, stride, pad, stream, 1, 0, 0, 0);
+}
+
+// `groups` independent 1x1 weight gradients dw_g[Cout][Cin] (+)= sum_m dz_g[m][Cout] * x_g[m][Cin] in one launch; dw pre-zeroed.
+// Library-internal (wino.hip).
+int y2_internal_wgrad_grouped(const float* x, const float* dz, float* dw, long long M, int Cin, int Cout, int groups, long long gx, long long gz,
+                              long long gw, y2_stream_t stream) {
+    if (M <= 0 || M > 0x7fffffffLL || groups < 1) return Y2_EINVAL;
+    return wgrad_impl(x, dz, dw, 1, 1, (int)M, Cin, Cin, Cout, Cout, 1, 1, 0, stream, groups, gx, gz, gw);
 }
 
 extern "C" int y2_conv_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int ldx, int Cout, int ldz,

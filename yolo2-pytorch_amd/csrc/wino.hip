@@ -210,6 +210,79 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     }
 }
 
+// ---- weight gradient:  dU[p][co][ci] = sum_t dM[p][t][co] * V[p][t][ci],   dM = A dz A^T (4x4 from the 2x2 gradient tile),
+//      dg = G^T dU G.  16 reductions over T tiles instead of 9 shifted reductions over 4T pixels (2.25x fewer MACs).
+struct WinoDzArgs {
+    const float* dz;
+    float* dm;
+    int B, H, W, Cout, ldz, th, tw, T, c4n;
+    y2_fastdiv d_c4, d_tt, d_tw;
+};
+
+__global__ __launch_bounds__(256) void wino_dz_kernel(const WinoDzArgs a) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t t = y2_div(idx, a.d_c4);
+    if (t >= (uint32_t)a.T) return;
+    const int c4 = (int)(idx - t * (uint32_t)a.c4n);
+    const int b = (int)y2_div(t, a.d_tt);
+    const int r = (int)t - b * a.th * a.tw;
+    const int ty = (int)y2_div((uint32_t)r, a.d_tw);
+    const int tx = r - ty * a.tw;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 d[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int yy = 2 * ty + i, xx = 2 * tx + j;
+            d[i][j] = (yy < a.H && xx < a.W) ? *reinterpret_cast<const f32x4*>(a.dz + ((size_t)(b * a.H + yy) * a.W + xx) * a.ldz + 4 * c4) : zero;
+        }
+    f32x4 s[4][2];                 // A d   (A = [1 0; 1 1; 1 -1; 0 -1])
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        s[0][j] = d[0][j];
+        s[1][j] = d[0][j] + d[1][j];
+        s[2][j] = d[0][j] - d[1][j];
+        s[3][j] = -d[1][j];
+    }
+    float* dst = a.dm + (size_t)t * a.Cout + 4 * c4;
+    const size_t plane = (size_t)a.T * a.Cout;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f32x4*>(dst + (4 * i + 0) * plane) = s[i][0];
+        *reinterpret_cast<f32x4*>(dst + (4 * i + 1) * plane) = s[i][0] + s[i][1];
+        *reinterpret_cast<f32x4*>(dst + (4 * i + 2) * plane) = s[i][0] - s[i][1];
+        *reinterpret_cast<f32x4*>(dst + (4 * i + 3) * plane) = -s[i][1];
+    }
+}
+
+// dw_packed[co][tap][ci] = (G^T dU G)[tap]
+__global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ du, float* __restrict__ dw, int Cout, int Cin) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)Cout * Cin) return;
+    const int ci = (int)(idx % Cin);
+    const int co = (int)(idx / Cin);
+    const size_t plane = (size_t)Cout * Cin;
+    const float* src = du + (size_t)co * Cin + ci;
+    float u[4][4];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) u[p / 4][p % 4] = src[p * plane];
+    float s[3][4];                 // G^T u   (G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1])
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+        s[1][j] = 0.5f * (u[1][j] - u[2][j]);
+        s[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float* dst = dw + ((size_t)co * 9 + 3 * i) * Cin + ci;
+        dst[0] = s[i][0] + 0.5f * (s[i][1] + s[i][2]);
+        dst[Cin] = 0.5f * (s[i][1] - s[i][2]);
+        dst[2 * (size_t)Cin] = 0.5f * (s[i][1] + s[i][2]) + s[i][3];
+    }
+}
+
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -287,6 +360,48 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     const dim3 grid((unsigned)y2_cdiv(T, (long long)ny * oa.loop), (unsigned)y2_cdiv(oa.n4n, nx));
     if (p->stats != nullptr) hipLaunchKernelGGL(wino_output_kernel<true>, grid, dim3(nx, ny), 0, s, oa);
     else hipLaunchKernelGGL(wino_output_kernel<false>, grid, dim3(nx, ny), 0, s, oa);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+// Winograd weight gradient of a 3x3 / stride-1 / same-padding convolution (replaces y2_conv_wgrad for the deep layers).
+extern "C" long long y2_wino_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return Y2_EINVAL;
+    const long long T = (long long)B * ((H + 1) / 2) * ((W + 1) / 2);
+    return (long long)(align256((size_t)16 * T * Cin * 4) + align256((size_t)16 * T * Cout * 4) + align256((size_t)16 * Cout * Cin * 4));
+}
+
+extern "C" int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t ldx,
+                             int32_t Cout, int32_t ldz, float* workspace, long long workspace_bytes, y2_stream_t stream) {
+    if (x == nullptr || dz == nullptr || dw_packed == nullptr || workspace == nullptr) return Y2_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldz < Cout) return Y2_EINVAL;
+    if ((Cin & 3) || (Cout & 3) || (ldx & 3) || (ldz & 3) || !y2_aligned16(x) || !y2_aligned16(dz) || !y2_aligned16(workspace)) return Y2_EALIGN;
+    if (workspace_bytes < y2_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return Y2_EINVAL;
+    const int th = (H + 1) / 2, tw = (W + 1) / 2;
+    const long long T = (long long)B * th * tw;
+    if (T * (Cin / 4) >= 0xffffffffLL || T * (Cout / 4) >= 0xffffffffLL || T > 0x7fffffff) return Y2_ENOSUP;
+    float* V = workspace;
+    float* DM = V + align256((size_t)16 * T * Cin * 4) / 4;
+    float* DU = DM + align256((size_t)16 * T * Cout * 4) / 4;
+    hipStream_t s = y2_s(stream);
+    const size_t du_bytes = (size_t)16 * Cout * Cin * 4;
+    hipError_t e = hipMemsetAsync(DU, 0, du_bytes, s);       // the grouped reduction adds split partial sums atomically
+    if (e != hipSuccess) return -(1000 + (int)e);
+
+    WinoInArgs ia;
+    ia.x = x; ia.v = V; ia.B = B; ia.H = H; ia.W = W; ia.Cin = Cin; ia.ldx = ldx; ia.th = th; ia.tw = tw; ia.T = (int)T; ia.c4n = Cin / 4;
+    ia.d_c4 = y2_make_fastdiv((uint32_t)ia.c4n); ia.d_tt = y2_make_fastdiv((uint32_t)(th * tw)); ia.d_tw = y2_make_fastdiv((uint32_t)tw);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)y2_cdiv(T * ia.c4n, 256)), dim3(256), 0, s, ia);
+
+    WinoDzArgs za;
+    za.dz = dz; za.dm = DM; za.B = B; za.H = H; za.W = W; za.Cout = Cout; za.ldz = ldz; za.th = th; za.tw = tw; za.T = (int)T; za.c4n = Cout / 4;
+    za.d_c4 = y2_make_fastdiv((uint32_t)za.c4n); za.d_tt = ia.d_tt; za.d_tw = ia.d_tw;
+    hipLaunchKernelGGL(wino_dz_kernel, dim3((unsigned)y2_cdiv(T * za.c4n, 256)), dim3(256), 0, s, za);
+
+    const int rc = y2_internal_wgrad_grouped(V, DM, DU, T, Cin, Cout, 16, T * Cin, T * Cout, (long long)Cout * Cin, stream);
+    if (rc != Y2_OK) return rc;
+    const long long n = (long long)Cout * Cin;
+    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)y2_cdiv(n, 256)), dim3(256), 0, s, DU, dw_packed, Cout, Cin);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

@@ -226,8 +226,7 @@ class DarknetTrainFn(torch.autograd.Function):
                 _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw4), cop, 4, k, st), 'y2_unpack_weight_grad')
                 ready(weight, dw4[:cout, :cin].contiguous())
             else:
-                dwp = torch.zeros(cop * cin * k * k, dtype=torch.float32, device=dev)
-                _hip.check(L.y2_conv_wgrad(_hip.ptr(blk.x), _hip.ptr(dz), _hip.ptr(dwp), B, h, w, cin, blk.ldx, cop, cop, k, st), 'y2_conv_wgrad')
+                dwp = _hip.conv_wgrad(blk.x, dz, B, h, w, cin, blk.ldx, cop, cop, k)     # direct or Winograd, by measurement
                 dw = _new(dev, cop, cin, k, k)
                 _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cop, cin, k, st), 'y2_unpack_weight_grad')
                 ready(weight, dw if cop == cout else dw[:cout].contiguous())
@@ -553,8 +552,11 @@ class ResNetTrainFn(torch.autograd.Function):
                 _hip.check(L.y2_f64_to_f32(_hip.ptr(sums), _hip.ptr(gb), cout, 1.0, st), 'y2_f64_to_f32')
                 ready(op.conv.bias, gb)
             # ---- weight gradient
-            dwp = torch.zeros(cop * k * k * cin, dtype=torch.float32, device=dev)
-            _hip.check(L.y2_conv_wgrad_ex(_hip.ptr(op.x), _hip.ptr(dz), _hip.ptr(dwp), B, op.h, op.w, cin, cin, cop, cop, k, op.stride, op.pad, st), 'y2_conv_wgrad_ex')
+            if k == 3 and op.stride == 1 and op.pad == 1:
+                dwp = _hip.conv_wgrad(op.x, dz, B, op.h, op.w, cin, cin, cop, cop, k)     # direct or Winograd, by measurement
+            else:
+                dwp = torch.zeros(cop * k * k * cin, dtype=torch.float32, device=dev)
+                _hip.check(L.y2_conv_wgrad_ex(_hip.ptr(op.x), _hip.ptr(dz), _hip.ptr(dwp), B, op.h, op.w, cin, cin, cop, cop, k, op.stride, op.pad, st), 'y2_conv_wgrad_ex')
             dw = _new(dev, cop, cin, k, k)
             _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cop, cin, k, st), 'y2_unpack_weight_grad')
             ready(op.conv.weight, dw if (cop == cout and cin == op.cin) else dw[:cout, :op.cin].contiguous())
