@@ -243,16 +243,19 @@ def autotune_conv(params, dev, wino_w=None):
     params.stats = stats_save
     apply(best)
     _TUNE[key] = list(best)
+    _tune_save()
+    return best
+
+
+def _tune_save():
     if TUNE_CACHE:
         try:
             import json as _json
             _json.dump({_json.dumps(list(k)): v for k, v in _TUNE.items()}, open(TUNE_CACHE, 'w'))
         except Exception:
             pass
-    return best
 
 
-_WGRAD_TUNE = {}
 _WGRAD_WS = {}
 
 
@@ -276,8 +279,8 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k):
 
     def wino():
         check(L.y2_wino_wgrad(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, ptr(ws), ws.numel() * 4, st), 'y2_wino_wgrad')
-    key = (B, H, W, cin, ldx, cout, ldz, str(dev))
-    choice = _WGRAD_TUNE.get(key)
+    key = ('wgrad', B, H, W, cin, ldx, cout, ldz, str(dev))
+    choice = _TUNE.get(key)
     if choice is None:
         if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             choice = 1 if cin >= 128 else 0
@@ -296,7 +299,8 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k):
                     t = min(t, e0.elapsed_time(e1))
                 times.append(t)
             choice = 1 if times[1] < times[0] else 0
-            _WGRAD_TUNE[key] = choice
+            _TUNE[key] = choice
+            _tune_save()
             dwp.zero_()          # the timing launches of the direct kernel accumulated into dwp
     (wino if choice == 1 else direct)()
     return dwp
