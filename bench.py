@@ -147,6 +147,7 @@ def main():
     ap.add_argument('--classes', type=int, default=20)
     ap.add_argument('--mode', default='detect', choices=['detect', 'forward'])
     ap.add_argument('--model', default='darknet', help="darknet (default, BASELINE configs[1]) or a model.resnet plugin name, e.g. resnet50 (configs[4] forward: --size 608 --classes 80)")
+    ap.add_argument('--no-direct-leg', action='store_true', help='skip the extra Winograd-off measurement (roofline.direct_only)')
     ap.add_argument('--no-graph', action='store_true', help='launch the detect step eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--train-steps', type=int, default=6, help='extra leg: timed training steps (fwd + region loss + bwd + SGD), 0 = skip')
     ap.add_argument('--train-batch', type=int, default=64, help='per-GPU batch of the training leg (BASELINE configs[2])')
@@ -184,60 +185,78 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    # roofline leg: eager steps with one HIP event pair around the conv chain (events cannot be queried inside a graph)
-    dnn.profile = []
-    for _ in range(min(args.steps, 10)):
-        step()
-    barrier()
-    prof, dnn.profile = dnn.profile, None
-    graphed = None
-    if not args.no_graph and args.mode == 'detect':
+    import _hip
+
+    def conv_chain_rate(prof):
+        """(executed TF/s, direct-equivalent TF/s, chain ms/step, conv0 ms/step, Winograd layer count, flops/step, executed flops/step)"""
+        fl = fl_exec = ms = ms0 = 0.0
+        n_launch = n_wino = 0
+        for rec in prof:
+            name, flops, e0, e1 = rec[:4]
+            d = e0.elapsed_time(e1)
+            if name.startswith('conv_fwd'):
+                fl += flops
+                fl_exec += rec[4] if len(rec) > 4 else flops
+                n_wino = rec[5] if len(rec) > 5 else 0
+                ms += d
+                n_launch += 1
+            else:
+                ms0 += d
+        n = max(1, n_launch)
+        rate = lambda f: f / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return rate(fl_exec), rate(fl), ms / n, ms0 / n, n_wino, fl / n, fl_exec / n
+
+    def measure(steps, warmup):
+        """W untimed warm-up steps, a roofline leg (eager steps, one HIP event pair around the conv chain each: events cannot
+        be queried inside a graph), then EXACTLY `steps` timed steps (hipGraph replay) between barrier + synchronize."""
+        for _ in range(warmup):
+            step()
+        barrier()
+        dnn.profile = []
+        for _ in range(min(steps, 10)):
+            step()
+        barrier()
+        prof, dnn.profile = dnn.profile, None
+        graphed = None
+        if not args.no_graph and args.mode == 'detect':
+            try:
+                graphed = detect.GraphedDetector(dnn, anchors, x, fix=True, threshold_cls=0.005, overlap=0.45, limit=200)
+            except Exception as e:   # capture not possible -> eager launches
+                print('hipGraph capture failed (%s); eager launches' % e, file=sys.stderr)
+                graphed = None
+        run = (lambda: graphed.run()) if graphed is not None else step
+        for _ in range(2):
+            run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        host_dt = time.perf_counter() - t0
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item(), host_dt, prof, graphed is not None
+
+    dt, host_dt, prof, was_graphed = measure(args.steps, args.warmup)
+    executed, direct_equiv, chain_ms, conv0_ms, n_wino, fl_step, fl_exec_step = conv_chain_rate(prof)
+
+    # second leg, reported beside the metric: the same step with the Winograd algorithm disabled = pure implicit-GEMM
+    # convolutions (executed == algorithmic multiply-adds), the conv-MFMA roofline fraction north_star asks for
+    direct_leg = None
+    if n_wino > 0 and not args.no_direct_leg:
+        _hip.WINOGRAD = False
+        dnn._plan_cache = None
         try:
-            graphed = detect.GraphedDetector(dnn, anchors, x, fix=True, threshold_cls=0.005, overlap=0.45, limit=200)
-        except Exception as e:   # capture not possible -> eager launches
-            print('hipGraph capture failed (%s); eager launches' % e, file=sys.stderr)
-            graphed = None
-    run = (lambda: graphed.run()) if graphed is not None else step
-    for _ in range(2):
-        run()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    host_dt = time.perf_counter() - t0
-    barrier()
-    dt = time.perf_counter() - t0
-
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = t.item()
-
-    # roofline of the dominant kernel family, live from the timed region
-    fl = ms = 0.0
-    n_launch = 0
-    fl0 = ms0 = 0.0
-    fl_exec, n_wino = 0.0, 0
-    for rec in prof:
-        name, flops, e0, e1 = rec[:4]
-        d = e0.elapsed_time(e1)
-        if name.startswith('conv_fwd'):
-            fl += flops
-            fl_exec += rec[4] if len(rec) > 4 else flops
-            n_wino = rec[5] if len(rec) > 5 else 0
-            ms += d
-            n_launch += 1
-        else:
-            fl0 += flops
-            ms0 += d
-    # `achieved` counts the multiply-adds the MFMA pipe EXECUTES (a Winograd layer runs 16/36 of the direct count), so the
-    # fraction is an MFMA utilisation and cannot exceed 1; the direct-equivalent (algorithmic) rate is beside it
-    achieved = fl_exec / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    direct_equiv = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    n_prof = max(1, n_launch)   # profiled steps (one conv-chain event pair each)
+            ddt, _, dprof, _ = measure(min(args.steps, 10), 2)
+            dex, _, dchain, _, _, _, _ = conv_chain_rate(dprof)
+            direct_leg = {'images_per_sec': round(args.batch * min(args.steps, 10) * world / ddt, 2), 'achieved': round(dex, 2),
+                          'frac': round(dex / PEAK_FP32_MFMA_TFLOPS, 4), 'conv_chain_ms_per_step': round(dchain, 4),
+                          'note': 'Y2_WINOGRAD=0: every 3x3 layer through the implicit-GEMM MFMA kernel'}
+        finally:
+            _hip.WINOGRAD = True
+            dnn._plan_cache = None
 
     train_out = None
     if args.train_steps > 0:
@@ -256,20 +275,22 @@ def main():
             'metric': 'images/sec (416x416) detect, Darknet-19 YOLOv2',
             'value': round(images / dt, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic', 'launch': 'hipGraph replay' if graphed is not None else 'eager', 'host_ms_per_step': round(host_dt / args.steps * 1e3, 4),
+            'dtype': 'f32', 'data': 'synthetic', 'launch': 'hipGraph replay' if was_graphed else 'eager', 'host_ms_per_step': round(host_dt / args.steps * 1e3, 4),
             'config': {'model': args.model, 'workload': 'Darknet-19 YOLOv2 %dx%d batch-%d/GPU inference: conv stack + decode + filter + NMS (BASELINE configs[1])'
                                    % (args.size, args.size, args.batch) if args.mode == 'detect' else
                                    'Darknet-19 YOLOv2 %dx%d batch-%d/GPU conv stack only' % (args.size, args.size, args.batch),
                        'classes': args.classes, 'global_batch': args.batch * world, 'parallelism': 'replicas x%d (no collective)' % world,
                        'weights': 'random-init seed 0'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_fwd_dma_kernel family (fp32 MFMA GEMMs: implicit-GEMM direct convs + the grouped GEMMs of the Winograd layers, with their transform kernels; the 22-layer chain timed as one event pair, inter-launch gaps included)',
-                         'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         'direct_equivalent_tflops': round(direct_equiv, 2), 'direct_equivalent_frac': round(direct_equiv / PEAK_FP32_MFMA_TFLOPS, 4),
-                         'winograd_layers': n_wino, 'executed_flops_per_step': fl_exec / n_prof,
-                         'flops_per_step': fl / n_prof, 'ms_per_step': round(ms / n_prof, 4),
-                         'conv0_ms_per_step': round(ms0 / n_prof, 4), 'traffic': traffic,
-                         'traffic_note': 'bytes per step (22 launches) from rocprofv3 PMC FETCH_SIZE(x2, gfx950 correction)+WRITE_SIZE, profiles/; L2 memory-side requests incl. Infinity-Cache hits'},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_fwd_dma_kernel family (fp32 MFMA GEMMs: implicit-GEMM direct convs + the grouped GEMMs of the Winograd layers, with their transform kernels; the 22-layer chain timed as one event pair per step, inter-launch gaps included)',
+                         'achieved': round(direct_equiv, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(direct_equiv / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'definition': 'ALGORITHMIC conv FLOPs (SURVEY.md 8d: 2*Cin*Cout*k*k*H*W per layer, 29.061 GFLOP/img) / measured chain time; it may exceed 1 because %d layers run Winograd F(2x2,3x3), which executes 16/36 of those multiply-adds' % n_wino,
+                         'mfma_executed_tflops': round(executed, 2), 'mfma_utilisation': round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'winograd_layers': n_wino, 'executed_flops_per_step': fl_exec_step,
+                         'flops_per_step': fl_step, 'ms_per_step': round(chain_ms, 4),
+                         'conv0_ms_per_step': round(conv0_ms, 4), 'traffic': traffic,
+                         'traffic_note': 'bytes per step (conv chain) from rocprofv3 PMC FETCH_SIZE(x2, gfx950 correction)+WRITE_SIZE, profiles/; L2 memory-side requests incl. Infinity-Cache hits',
+                         'direct_only': direct_leg},
         }
         if train_out is not None:
             out['train'] = train_out
