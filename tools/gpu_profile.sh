@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.." || exit 1
 R=$PWD; mkdir -p gpurun_out/prof; export TMPDIR=/tmp
 export Y2_TUNE_CACHE=/tmp/y2_tune.json
-CMD="python $R/bench.py --steps ${STEPS:-5} --warmup 2 --cpu-sample 0 --train-steps 0"
+CMD="python $R/bench.py --steps ${STEPS:-5} --warmup 2 --cpu-sample 0 --train-steps 0 --no-direct-leg ${BENCH_ARGS}"
 $CMD > /dev/null 2>&1   # populate the tile-autotune cache so the profiled runs contain only steady-state launches
 cd /tmp
 rm -rf $R/gpurun_out/prof/*
@@ -18,5 +18,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE S
   timeout 600 rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/prof/pmc$i -o pmc -- $CMD > $R/gpurun_out/prof/pmc$i.log 2>&1
 done
 python3 $R/tools/rocprof_summary.py pmc $(find $R/gpurun_out/prof/pmc* -name '*.db') > $R/gpurun_out/prof/pmc_summary.txt
-grep -E "conv_fwd|conv0" $R/gpurun_out/prof/pmc_summary.txt | cut -c1-60,91- | head -60
+python3 $R/tools/traffic_from_pmc.py $R/gpurun_out/prof/pmc_summary.txt > $R/gpurun_out/prof/traffic.json
+grep -E "MFMA_BUSY|GRBM_GUI" $R/gpurun_out/prof/pmc_summary.txt | grep -E "conv_fwd|wino" | cut -c1-60,91- | head -30; grep traffic_bytes $R/gpurun_out/prof/traffic.json
 find $R/gpurun_out/prof -name '*.db' -delete

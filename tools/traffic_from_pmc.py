@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""profiles/*_traffic.json from a tools/rocprof_summary.py `pmc` text: HBM-side bytes per bench step of the conv chain.
+
+    python tools/traffic_from_pmc.py gpurun_out/prof/pmc_summary.txt > profiles/rNN_detect_b32_traffic.json
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch (TCC-EA requests, summed over the 16 channels/XCDs); on gfx950
+FETCH_SIZE counts half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) and is doubled.  The conv
+chain = conv_fwd_dma_kernel family + split-K fix-up + the Winograd transform kernels; steps = conv0 dispatches."""
+import json
+import re
+import sys
+
+FAMILY = re.compile(r'conv_fwd_dma_kernel|conv_splitk_fixup_kernel|wino_(input|output)_kernel')
+rows = []
+for line in open(sys.argv[1]):
+    m = re.match(r'(\S+)\s+(\S+)\s+dispatches=\s*(\d+)\s+mean_per_dispatch=([0-9.eE+-]+)', line)
+    if m:
+        rows.append((m.group(1), m.group(2), int(m.group(3)), float(m.group(4))))
+steps = max([n for k, c, n, v in rows if 'conv0_kernel' in k and c == 'FETCH_SIZE'] + [1])
+tot = {'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0}
+launches = 0
+for k, c, n, v in rows:
+    if FAMILY.search(k) and c in tot:
+        tot[c] += n * v * 1024.0
+        if c == 'FETCH_SIZE':
+            launches += n
+fetch, write = tot['FETCH_SIZE'] / steps, tot['WRITE_SIZE'] / steps
+print(json.dumps({
+    'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile.sh) on `bench.py --steps 5 --warmup 2 --cpu-sample 0 --train-steps 0` (autotune cache pre-populated); conv_fwd_dma_kernel family + split-K fix-up + Winograd transform kernels',
+    'kernel_launches_profiled': launches, 'steps_profiled': steps,
+    'fetch_size_bytes_raw_per_step': fetch, 'write_size_bytes_raw_per_step': write,
+    'correction': 'gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE uncorrected; counters are L2 memory-side requests, Infinity-Cache hits included',
+    'traffic_bytes_per_step': 2 * fetch + write,
+}, indent=1))
