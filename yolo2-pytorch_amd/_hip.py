@@ -189,7 +189,7 @@ def wino_weight(wp, cout, cin):
 
 def _time_conv(L, params, st):
     t = float('inf')
-    for _ in range(2):          # best of two batches of 3 launches (DVFS / neighbour noise)
+    for _ in range(3):          # best of three batches of 3 launches (DVFS / neighbour noise)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(3):
