@@ -170,13 +170,13 @@ def init_tiny_state_dict(num_anchors=5, num_cls=20, seed=0, div=1, head_scale=1.
     return collections.OrderedDict((k, v.to(dtype)) for k, v in sd.items())
 
 
-def tiny_forward(x, sd):
-    """model/yolo2.py:169-170 (eval): conv blocks, MaxPool2d(2), and ConstantPad2d((0,1,0,1), float32.min) + MaxPool2d(2, stride=1) (:151-152)."""
+def tiny_forward(x, sd, training=False, stats=None):
+    """model/yolo2.py:169-170: conv blocks, MaxPool2d(2), and ConstantPad2d((0,1,0,1), float32.min) + MaxPool2d(2, stride=1) (:151-152)."""
     for item in TINY:
         if item == 'M':
             x = F.max_pool2d(x, 2)
         elif item == 'P':
             x = F.max_pool2d(F.pad(x, (0, 1, 0, 1), value=float(torch.finfo(torch.float32).min)), 2, stride=1)
         else:
-            x = conv_block(x, sd, item[0], 3)
+            x = conv_block(x, sd, item[0], 3, training, stats)
     return F.conv2d(x, sd[TINY_HEAD + '.conv.weight'], sd[TINY_HEAD + '.conv.bias'])

@@ -413,3 +413,45 @@ def test_resnet_training_step_matches_oracle_autograd(arch):
     for prefix, (rm, rv) in stats.items():
         np.testing.assert_allclose(bufs[prefix + '.running_mean'].cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(bufs[prefix + '.running_var'].cpu().numpy(), rv.numpy(), rtol=1e-4)
+
+
+def test_tiny_training_step_matches_oracle_autograd():
+    """model.yolo2.Tiny in training mode: conv (general kernel, 4-channel padded stem) + batch-stat BN (momentum
+    0.01) + LeakyReLU, five MaxPool2d(2) and the padded stride-1 pool, region loss, full backward - against the oracle's
+    fp64 autograd on the same seeded step."""
+    import model
+    import model.yolo2
+    C = 20
+    sd = odark.init_tiny_state_dict(5, C, seed=0, div=4, head_scale=0.25)
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1'}})
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    net = model.yolo2.Tiny(model.ConfigChannels(cfg, sd), anchors, C)
+    assert not net.load_state_dict(sd, strict=False).unexpected_keys
+    inf = model.Inference(cfg, net, anchors).to(dev()).train()
+    S, B = 96, 3
+    x = synth.images(B, S, seed=1)
+    data = synth.norm_data(synth.labels(B, S, C, seed=2), S, S, S // 32, S // 32)
+    pred = model._inference(inf, x.to(dev()))
+    loss, _ = model.loss(anchors, data, pred, 0.6)
+    sum(loss[k] * oloss.HPARAM[k] for k in loss).backward()
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    stats = {}
+    f = odark.tiny_forward(x.double(), sd64, training=True, stats=stats)
+    lo, _ = oloss.loss(anchors.double(), {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}, ohead.decode(f, anchors.double()), 0.6)
+    oloss.total(lo).backward()
+    for k in lo:
+        np.testing.assert_allclose(loss[k].item(), lo[k].item(), rtol=2e-4)
+    sd32 = {k: v.clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    l32, _ = oloss.loss(anchors, data, ohead.decode(odark.tiny_forward(x, sd32, training=True), anchors), 0.6)
+    oloss.total(l32).backward()
+    ours = dict(net.named_parameters())
+    for k, v in sd64.items():
+        if v.requires_grad:
+            assert ours[k].grad is not None, k
+            floor = rel(sd32[k].grad, v.grad)      # fp32 noise floor of the same step on the oracle
+            assert rel(ours[k].grad, v.grad) <= max(1e-3, 4 * floor), (k, rel(ours[k].grad, v.grad), floor)
+    bufs = dict(net.named_buffers())
+    for prefix, (rm, rv) in stats.items():
+        np.testing.assert_allclose(bufs[prefix + '.bn.running_mean'].cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(bufs[prefix + '.bn.running_var'].cpu().numpy(), rv.numpy(), rtol=1e-4)

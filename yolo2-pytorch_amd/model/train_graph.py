@@ -398,10 +398,17 @@ def loss(anchors, data, pred, threshold):
 class _ROp(object):
     """One recorded operation of the ResNet training forward (conv+BN+ReLU[+residual], or the stem max-pool)."""
     __slots__ = ('kind', 'conv', 'bn', 'x', 'ldx', 'h', 'w', 'ho', 'wo', 'stride', 'pad', 'k', 'cin', 'cout', 'z', 'scale', 'shift', 'mean', 'invstd',
-                 'residual', 'y', 'slope', 'first')
+                 'residual', 'y', 'slope', 'first', 'pool')       # pool = (ksize, stride, pad, pad_end) of a 'pool' op
 
 
 def resnet_forward(net, x):
+    params = [p for p in net.parameters()]
+    out = ResNetTrainFn.apply(net, x, *params)
+    return out.permute(0, 3, 1, 2)
+
+
+def tiny_forward(net, x):
+    """Training-mode forward of model.yolo2.Tiny (model/yolo2.py:140-173) through the same op-list graph as the ResNets."""
     params = [p for p in net.parameters()]
     out = ResNetTrainFn.apply(net, x, *params)
     return out.permute(0, 3, 1, 2)
@@ -445,7 +452,7 @@ class ResNetTrainFn(torch.autograd.Function):
         x4 = _new(dev, B, H, W, cpad)
         _hip.check(L.y2_nchw_to_nhwc(_hip.ptr(x), _hip.ptr(x4), B, cin0, H, W, cpad, st), 'y2_nchw_to_nhwc')
 
-        def conv_bn(conv, bn, xin, ldx, h, w, stride, pad, slope, residual=None, first=False):
+        def conv_bn(conv, bn, xin, ldx, h, w, stride, pad, slope, residual=None, first=False, momentum=None):
             op = _ROp()
             weight = _hip.f32c(conv.weight.detach())
             cout, cin_true, k, _ = weight.shape
@@ -466,7 +473,7 @@ class ResNetTrainFn(torch.autograd.Function):
             if bn is not None:
                 op.scale, op.shift, op.mean, op.invstd = (_new(dev, cout) for _ in range(4))
                 _hip.check(L.y2_bn_finalize(_hip.ptr(stats), float(B * ho * wo), _hip.ptr(bn.weight.detach()), _hip.ptr(bn.bias.detach()),
-                                            _hip.ptr(bn.running_mean), _hip.ptr(bn.running_var), ResNetTrainFn.MOMENTUM, BN_EPS,
+                                            _hip.ptr(bn.running_mean), _hip.ptr(bn.running_var), ResNetTrainFn.MOMENTUM if momentum is None else momentum, BN_EPS,
                                             _hip.ptr(op.scale), _hip.ptr(op.shift), _hip.ptr(op.mean), _hip.ptr(op.invstd), cout, st), 'y2_bn_finalize')
                 if bn.num_batches_tracked is not None:
                     bn.num_batches_tracked += 1
@@ -480,15 +487,39 @@ class ResNetTrainFn(torch.autograd.Function):
             ops.append(op)
             return y, ho, wo, cout
 
+        def maxpool(cur, h, w, ld, ksize, stride, pad, pad_end):
+            pool = _ROp()
+            pool.kind, pool.x, pool.h, pool.w, pool.cout, pool.pool = 'pool', cur, h, w, ld, (ksize, stride, pad, pad_end)
+            ph, pw = (h + pad + pad_end - ksize) // stride + 1, (w + pad + pad_end - ksize) // stride + 1
+            pooled = _new(dev, B, ph, pw, ld)
+            _hip.check(L.y2_maxpool_fwd(_hip.ptr(cur), _hip.ptr(pooled), B, h, w, ld, ld, ld, ksize, stride, pad, pad_end, st), 'y2_maxpool_fwd')
+            pool.y, pool.ho, pool.wo = pooled, ph, pw
+            ops.append(pool)
+            return pooled, ph, pw
+
+        from model import yolo2 as _yolo2
+        if isinstance(net, _yolo2.Tiny):
+            # model/yolo2.py:140-173: nn.Sequential of Conv2d blocks (BN momentum 0.01, LeakyReLU 0.1), MaxPool2d(2) and the
+            # ConstantPad2d((0,1,0,1)) + MaxPool2d(2, stride=1) pair; the 3-channel input runs zero-padded to 4 NHWC channels
+            cur, h, w, ld = x4, H, W, cpad
+            mods = list(net.layers)
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                if isinstance(m, _yolo2.Conv2d):
+                    cur, h, w, ld = conv_bn(m.conv, m.bn, cur, ld, h, w, 1, (m.kernel_size - 1) // 2, LEAKY if m.has_act else 1.0,
+                                            first=(i == 0), momentum=BN_MOMENTUM)
+                elif isinstance(m, _yolo2._PadPool):
+                    cur, h, w = maxpool(cur, h, w, ld, 2, 1, 0, 1)
+                    i += 1          # the pad + pool pair
+                else:
+                    cur, h, w = maxpool(cur, h, w, ld, 2, 2, 0, 0)
+                i += 1
+            ctx.net, ctx.ops, ctx.B = net, ops, B
+            ctx.param_ids = [id(p) for p in params]
+            return cur
         cur, h, w, ld = conv_bn(net.conv1, net.bn1, x4, cpad, H, W, 2, 3, 0.0, first=True)
-        pool = _ROp()
-        pool.kind, pool.x, pool.h, pool.w, pool.cout = 'pool', cur, h, w, ld
-        ph, pw = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
-        pooled = _new(dev, B, ph, pw, ld)
-        _hip.check(L.y2_maxpool_fwd(_hip.ptr(cur), _hip.ptr(pooled), B, h, w, ld, ld, ld, 3, 2, 1, 1, st), 'y2_maxpool_fwd')
-        pool.y, pool.ho, pool.wo = pooled, ph, pw
-        ops.append(pool)
-        cur, h, w = pooled, ph, pw
+        cur, h, w = maxpool(cur, h, w, ld, 3, 2, 1, 1)
         for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
             for blk in layer:
                 residual = cur
@@ -524,8 +555,9 @@ class ResNetTrainFn(torch.autograd.Function):
             assert 1 <= len(srcs) <= 2, len(srcs)
             if op.kind == 'pool':
                 dx = _new(dev, B, op.h, op.w, op.cout)
+                pk, ps, pp, pe = op.pool
                 _hip.check(L.y2_maxpool_bwd(_hip.ptr(op.x), _hip.ptr(srcs[0]), _hip.ptr(srcs[1]) if len(srcs) > 1 else None, _hip.ptr(dx),
-                                            B, op.h, op.w, op.cout, op.cout, op.cout, op.cout, 3, 2, 1, 1, st), 'y2_maxpool_bwd')
+                                            B, op.h, op.w, op.cout, op.cout, op.cout, op.cout, pk, ps, pp, pe, st), 'y2_maxpool_bwd')
                 G.setdefault(id(op.x), []).append(dx)
                 continue
             cout, cin, k, ho, wo = op.cout, op.ldx, op.k, op.ho, op.wo

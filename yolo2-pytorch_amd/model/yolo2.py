@@ -409,7 +409,8 @@ class Tiny(Darknet):
 
     def forward(self, x):
         if self.training and torch.is_grad_enabled():
-            raise NotImplementedError('model.yolo2.Tiny: only the inference path runs on the HIP kernels so far')
+            from model import train_graph
+            return train_graph.tiny_forward(self, x)
         with torch.no_grad():
             out = self.forward_nhwc(x)
         return out.permute(0, 3, 1, 2)
