@@ -286,6 +286,30 @@ int y2_region_loss_bwd(const float* iou, const float* center_offset, const float
                        const float* best_iou, const int32_t* best_idx, const uint8_t* positive, const double* sums, const float* weights,
                        float* d_iou, float* d_center_offset, float* d_size_norm, float* d_logits, y2_stream_t stream);
 
+/* ---- fused multi-tensor optimizer -------------------------------------------------------------------
+ * One launch updates up to Y2_OPT_MAX_TENSORS parameter tensors (the pointer table is passed by value in the kernel
+ * arguments).  Replaces the per-tensor loops of `self.optimizer.step()` (train.py:357; optimizer from the ini lambda,
+ * config.ini:72) and `nn.utils.clip_grad_norm` (train.py:352-354).  All tensors fp32, contiguous. */
+#define Y2_OPT_MAX_TENSORS 48
+typedef struct {
+    float* param;
+    float* grad;
+    float* state1;   /* SGD: momentum buffer (NULL when momentum == 0); Adam: exp_avg */
+    float* state2;   /* Adam: exp_avg_sq; SGD: NULL */
+    int64_t numel;
+} y2_opt_tensor;
+
+/* torch.optim.SGD: d = g + wd*p; buf = first_step ? d : momentum*buf + (1-dampening)*d; d = nesterov ? d + momentum*buf : buf; p -= lr*d */
+int y2_opt_sgd(const y2_opt_tensor* tensors, int32_t count, float lr, float momentum, float dampening, float weight_decay,
+               int32_t nesterov, int32_t first_step, y2_stream_t stream);
+/* torch.optim.Adam (no amsgrad), `step` = 1-based step count of these tensors (bias corrections computed in double on the host) */
+int y2_opt_adam(const y2_opt_tensor* tensors, int32_t count, float lr, float beta1, float beta2, float eps, float weight_decay,
+                int32_t step, y2_stream_t stream);
+/* *sumsq (fp64, pre-zeroed, accumulated across calls) += sum of squares of all gradients; then y2_opt_clip_grads scales every
+ * gradient by max_norm / (sqrt(*sumsq) + 1e-6) when that is < 1 (torch.nn.utils.clip_grad_norm_, L2).  No host sync. */
+int y2_opt_grad_sumsq(const y2_opt_tensor* tensors, int32_t count, double* sumsq, y2_stream_t stream);
+int y2_opt_clip_grads(const y2_opt_tensor* tensors, int32_t count, const double* sumsq, float max_norm, y2_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

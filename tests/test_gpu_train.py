@@ -455,3 +455,59 @@ def test_tiny_training_step_matches_oracle_autograd():
     for prefix, (rm, rv) in stats.items():
         np.testing.assert_allclose(bufs[prefix + '.bn.running_mean'].cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(bufs[prefix + '.bn.running_var'].cpu().numpy(), rv.numpy(), rtol=1e-4)
+
+
+@pytest.mark.parametrize('kind', ['sgd', 'sgd_nesterov_wd', 'sgd_plain', 'adam', 'adam_wd'])
+def test_fused_optimizer_matches_torch_optim(kind):
+    """utils.optim (one launch per 48 tensors) against torch.optim on 60 tensors of assorted (odd, unaligned, large) sizes, 4 steps."""
+    import utils
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    shapes = [(125,), (1,), (3, 3, 3, 3), (1024, 1025), (7,), (64, 32, 3, 3), (33,), (4096,), (4097,), (2, 5)] * 6
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    ours = [torch.nn.Parameter(t.clone().to(d)) for t in init]
+    ref = [torch.nn.Parameter(t.clone().to(d)) for t in init]
+    # an unaligned view: parameter storage offset by one float (16-B alignment lost -> scalar path)
+    base_o, base_r = torch.randn(1001, generator=g).to(d), None
+    base_r = base_o.clone()
+    ours.append(torch.nn.Parameter(base_o[1:]))
+    ref.append(torch.nn.Parameter(base_r[1:]))
+    if kind.startswith('sgd'):
+        kw = dict(sgd=dict(momentum=0.9), sgd_nesterov_wd=dict(momentum=0.8, nesterov=True, weight_decay=1e-2), sgd_plain=dict())[kind]
+        a, b = utils.optim.SGD(ours, 0.05, **kw), torch.optim.SGD(ref, 0.05, **kw)
+    else:
+        kw = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=(1e-2 if kind == 'adam_wd' else 0.0))
+        a, b = utils.optim.Adam(ours, 1e-2, **kw), torch.optim.Adam(ref, 1e-2, **kw)
+    for step in range(4):
+        for po, pr in zip(ours, ref):
+            gr = torch.randn(po.shape, generator=g).to(d)
+            po.grad, pr.grad = gr.clone(), gr.clone()
+        if step == 2:       # a parameter that skips a step keeps its own step count / momentum state
+            ours[3].grad = None
+            ref[3].grad = None
+        a.step()
+        b.step()
+    for po, pr in zip(ours, ref):
+        np.testing.assert_allclose(po.detach().cpu().numpy(), pr.detach().cpu().numpy(), rtol=2e-5, atol=2e-7)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert set(sa['state'].keys()) == set(sb['state'].keys())
+    for k in sa['state']:
+        assert set(sa['state'][k].keys()) == set(sb['state'][k].keys())
+
+
+def test_fused_clip_grad_norm():
+    import utils
+    d = dev()
+    g = torch.Generator().manual_seed(4)
+    for scale, max_norm in ((1.0, 5.0), (1e-3, 5.0)):        # clipped / left alone
+        ps = [torch.nn.Parameter(torch.zeros(*s, device=d)) for s in [(125,), (512, 513), (3,), (64, 64, 3, 3)] * 15]
+        for p in ps:
+            p.grad = (torch.randn(p.shape, generator=g) * scale).to(d)
+        want = [p.grad.clone() for p in ps]
+        tn = torch.nn.utils.clip_grad_norm_([torch.nn.Parameter(w) for w in want], max_norm) if False else None
+        total = torch.sqrt(sum((w.double() ** 2).sum() for w in want))
+        coef = min(1.0, max_norm / (total.item() + 1e-6))
+        norm = utils.optim.clip_grad_norm_(ps, max_norm)
+        np.testing.assert_allclose(norm.item(), total.item(), rtol=1e-6)
+        for p, w in zip(ps, want):
+            np.testing.assert_allclose(p.grad.cpu().numpy(), (w * coef).cpu().numpy(), rtol=2e-6, atol=1e-12)

@@ -103,3 +103,19 @@ def test_utils_config_helpers(tmp_path):
     utils.modify_config(cfg, 'train/clip_=')
     assert not cfg.has_option('train', 'clip_')
     utils.modify_config(cfg, 'nosuch/option=')                          # silently ignored like the reference
+
+
+def test_fused_optimizer_is_torch_optim_compatible_and_has_no_cpu_fallback():
+    """utils.optim.{SGD,Adam}: torch.optim.Optimizer subclasses for the ini lambda (config.ini:72); CPU tensors must raise."""
+    import utils
+    p = torch.nn.Parameter(torch.randn(5, 3))
+    for cls, kw in ((utils.optim.SGD, dict(momentum=0.9)), (utils.optim.Adam, dict(betas=(0.9, 0.999), eps=1e-8))):
+        opt = eval('lambda params, lr: utils.optim.%s(params, lr, **kw)' % cls.__name__, dict(utils=utils, kw=kw))([p], 1e-3)
+        assert isinstance(opt, torch.optim.Optimizer) and opt.param_groups[0]['lr'] == 1e-3
+        torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[60, 90], gamma=0.1)      # config.ini:75
+        p.grad = torch.randn(5, 3)
+        with pytest.raises(RuntimeError, match='GPU'):
+            opt.step()
+        assert set(opt.state_dict().keys()) == {'state', 'param_groups'}
+    with pytest.raises(NotImplementedError):
+        utils.optim.Adam([p], amsgrad=True)

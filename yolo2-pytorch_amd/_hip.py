@@ -32,6 +32,13 @@ class ConvParams(ctypes.Structure):
 
 
 # name -> argtypes; restype is int for everything except y2_build_info
+class OptTensor(ctypes.Structure):
+    """y2_opt_tensor (include/yolo2_hip.h)."""
+    _fields_ = [('param', c_void_p), ('grad', c_void_p), ('state1', c_void_p), ('state2', c_void_p), ('numel', ctypes.c_int64)]
+
+
+OPT_MAX_TENSORS = 48
+
 SIGNATURES = {
     'y2_abi_version': [],
     'y2_pack_weight': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
@@ -40,6 +47,10 @@ SIGNATURES = {
     'y2_conv_fwd': [ctypes.POINTER(ConvParams), c_void_p],
     'y2_conv_fwd_workspace_bytes': [ctypes.POINTER(ConvParams)],
     'y2_wino_weight': [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    'y2_opt_sgd': [ctypes.POINTER(OptTensor), c_int, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p],
+    'y2_opt_adam': [ctypes.POINTER(OptTensor), c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p],
+    'y2_opt_grad_sumsq': [ctypes.POINTER(OptTensor), c_int, c_void_p, c_void_p],
+    'y2_opt_clip_grads': [ctypes.POINTER(OptTensor), c_int, c_void_p, c_float, c_void_p],
     'y2_wino_wgrad_workspace_bytes': [c_int, c_int, c_int, c_int, c_int],
     'y2_wino_wgrad': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, ctypes.c_longlong, c_void_p],
     'y2_conv_fwd_batch': [ctypes.POINTER(ConvParams), c_int, c_void_p],

@@ -78,3 +78,6 @@ def modify_config(config, cmd):
 def ensure_device(t, device_id=None, non_blocking=False):
     """utils/__init__.py:109-112 (`async` became a keyword in Python 3.7; the argument is now `non_blocking`)."""
     return t.cuda(device_id, non_blocking) if torch.cuda.is_available() else t
+
+
+from . import optim  # noqa: E402,F401  (utils.optim.SGD / Adam / clip_grad_norm_ for the ini lambda, config.ini:72)
