@@ -18,6 +18,7 @@
 //   3. wino_output_kernel:  y = act(scale * (A^T M A) + shift), 2x2 pixels per tile, optional in-thread 2x2 max-pool and
 //      per-channel sum / sum of squares of the raw output (training-mode BatchNorm statistics)
 // Stages 1 and 3 are streaming kernels (HBM/Infinity-Cache bound: V is 4x the input, M is 4x the output).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -285,6 +286,15 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
 
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// V + M bytes per batch chunk (Y2_WINO_CHUNK_MB).  Chunks small enough to keep V and M in the 256 MB Infinity Cache were
+// measured (B=32: 48 / 96 / 192 MB budgets -> 6.26 / 5.76 / 5.58 ms for the 22-layer chain against 5.50 ms unchunked): the
+// smaller GEMMs lose more than the transforms gain, so the default only bounds the workspace of very large batches.
+inline size_t wino_chunk_bytes() {
+    static long long mb = -1;
+    if (mb < 0) { const char* e = getenv("Y2_WINO_CHUNK_MB"); mb = (e != nullptr && atoll(e) > 0) ? atoll(e) : 4096; }
+    return (size_t)mb << 20;
+}
+
 }  // namespace
 
 extern "C" int y2_wino_weight(const float* w_packed, float* u, int32_t Cout, int32_t Cin, y2_stream_t stream) {
@@ -312,7 +322,14 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     if (p->y_pool != nullptr && ((p->ldp % 4) != 0 || (p->poff % 4) != 0 || !y2_aligned16(p->y_pool))) return Y2_ENOSUP;
     if ((p->scale != nullptr && !y2_aligned16(p->scale)) || (p->shift != nullptr && !y2_aligned16(p->shift))) return Y2_ENOSUP;
     const int th = (p->H + 1) / 2, tw = (p->W + 1) / 2;
-    const long long T = (long long)p->B * th * tw;
+    // Batch chunks bound the workspace (V = 4x the input, M = 4x the output of a chunk); see wino_chunk_bytes().
+    const size_t img_bytes = (size_t)16 * th * tw * ((size_t)p->Cin + p->Cout) * sizeof(float);
+    int cb = (int)(wino_chunk_bytes() / (img_bytes > 0 ? img_bytes : 1));
+    if (cb < 1) cb = 1;
+    if (cb > p->B) cb = p->B;
+    const int nchunks = y2_cdiv(p->B, cb);
+    cb = y2_cdiv(p->B, nchunks);                     // equal chunks
+    const long long T = (long long)cb * th * tw;    // tiles of a full chunk
     if (T * (p->Cin / 4) >= 0xffffffffLL || T * (p->Cout / 4) >= 0xffffffffLL || T > 0x7fffffff) return Y2_ENOSUP;
     const size_t vbytes = align256((size_t)16 * T * p->Cin * sizeof(float));
     const size_t mbytes = align256((size_t)16 * T * p->Cout * sizeof(float));
@@ -321,12 +338,11 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     y2_conv_params q = {};
     q.B = 1; q.H = 1; q.W = (int)T; q.Cin = p->Cin; q.ldx = p->Cin; q.Cout = p->Cout; q.ksize = 1;
     q.ldy = p->Cout; q.slope = 1.f; q.tile = p->tile; q.algo = Y2_ALGO_DIRECT;
-    const long long gx = T * p->Cin, gw = (long long)p->Cout * p->Cin, gy = T * p->Cout;
     if (ws_need != nullptr) {
         float* const dummy = reinterpret_cast<float*>(256);
         q.x = dummy; q.w = dummy; q.y = dummy;
         size_t inner = 0;
-        const int rc = y2_internal_conv_grouped(&q, 16, gx, gw, gy, stream, &inner);
+        const int rc = y2_internal_conv_grouped(&q, 16, T * p->Cin, (long long)p->Cout * p->Cin, T * p->Cout, stream, &inner);
         if (rc != Y2_OK) return rc;
         *ws_need = vbytes + mbytes + inner;
         return Y2_OK;
@@ -335,31 +351,41 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     float* V = p->workspace;
     float* M = V + vbytes / sizeof(float);
     hipStream_t s = y2_s(stream);
+    const y2_fastdiv d_tt = y2_make_fastdiv((uint32_t)(th * tw)), d_tw = y2_make_fastdiv((uint32_t)tw);
 
-    WinoInArgs ia;
-    ia.x = p->x; ia.v = V; ia.B = p->B; ia.H = p->H; ia.W = p->W; ia.Cin = p->Cin; ia.ldx = p->ldx; ia.th = th; ia.tw = tw; ia.T = (int)T;
-    ia.c4n = p->Cin / 4;
-    ia.d_c4 = y2_make_fastdiv((uint32_t)ia.c4n); ia.d_tt = y2_make_fastdiv((uint32_t)(th * tw)); ia.d_tw = y2_make_fastdiv((uint32_t)tw);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)y2_cdiv(T * ia.c4n, 256)), dim3(256), 0, s, ia);
+    for (int b0 = 0; b0 < p->B; b0 += cb) {
+        const int nb = p->B - b0 < cb ? p->B - b0 : cb;
+        const long long Tc = (long long)nb * th * tw;
+        const size_t in_off = (size_t)b0 * p->H * p->W;               // pixels before this chunk
 
-    q.x = V; q.w = p->w; q.y = M;
-    q.workspace = M + mbytes / sizeof(float);
-    q.workspace_bytes = (long long)((size_t)p->workspace_bytes - vbytes - mbytes);
-    const int rc = y2_internal_conv_grouped(&q, 16, gx, gw, gy, stream, nullptr);
-    if (rc != Y2_OK) return rc;
+        WinoInArgs ia;
+        ia.x = p->x + in_off * p->ldx; ia.v = V; ia.B = nb; ia.H = p->H; ia.W = p->W; ia.Cin = p->Cin; ia.ldx = p->ldx; ia.th = th; ia.tw = tw;
+        ia.T = (int)Tc; ia.c4n = p->Cin / 4;
+        ia.d_c4 = y2_make_fastdiv((uint32_t)ia.c4n); ia.d_tt = d_tt; ia.d_tw = d_tw;
+        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)y2_cdiv(Tc * ia.c4n, 256)), dim3(256), 0, s, ia);
 
-    WinoOutArgs oa;
-    oa.m = M; oa.scale = p->scale; oa.shift = p->shift; oa.y = p->y; oa.y_pool = p->y_pool; oa.stats = p->stats;
-    oa.B = p->B; oa.H = p->H; oa.W = p->W; oa.Cout = p->Cout; oa.ldy = p->ldy; oa.coff = p->coff; oa.ldp = p->ldp; oa.poff = p->poff;
-    oa.th = th; oa.tw = tw; oa.T = (int)T; oa.n4n = p->Cout / 4; oa.slope = p->slope;
-    oa.d_tt = ia.d_tt; oa.d_tw = ia.d_tw;
-    int nx = 64;
-    while (nx > 4 && nx / 2 >= oa.n4n) nx /= 2;
-    const int ny = 256 / nx;
-    oa.loop = p->stats != nullptr ? 8 : 1;
-    const dim3 grid((unsigned)y2_cdiv(T, (long long)ny * oa.loop), (unsigned)y2_cdiv(oa.n4n, nx));
-    if (p->stats != nullptr) hipLaunchKernelGGL(wino_output_kernel<true>, grid, dim3(nx, ny), 0, s, oa);
-    else hipLaunchKernelGGL(wino_output_kernel<false>, grid, dim3(nx, ny), 0, s, oa);
+        q.W = (int)Tc;
+        q.x = V; q.w = p->w; q.y = M;
+        q.workspace = M + mbytes / sizeof(float);
+        q.workspace_bytes = (long long)((size_t)p->workspace_bytes - vbytes - mbytes);
+        const int rc = y2_internal_conv_grouped(&q, 16, Tc * p->Cin, (long long)p->Cout * p->Cin, Tc * p->Cout, stream, nullptr);
+        if (rc != Y2_OK) return rc;
+
+        WinoOutArgs oa;
+        oa.m = M; oa.scale = p->scale; oa.shift = p->shift; oa.stats = p->stats;
+        oa.y = p->y != nullptr ? p->y + in_off * p->ldy : nullptr;
+        oa.y_pool = p->y_pool != nullptr ? p->y_pool + (size_t)b0 * th * tw * p->ldp : nullptr;
+        oa.B = nb; oa.H = p->H; oa.W = p->W; oa.Cout = p->Cout; oa.ldy = p->ldy; oa.coff = p->coff; oa.ldp = p->ldp; oa.poff = p->poff;
+        oa.th = th; oa.tw = tw; oa.T = (int)Tc; oa.n4n = p->Cout / 4; oa.slope = p->slope;
+        oa.d_tt = d_tt; oa.d_tw = d_tw;
+        int nx = 64;
+        while (nx > 4 && nx / 2 >= oa.n4n) nx /= 2;
+        const int ny = 256 / nx;
+        oa.loop = p->stats != nullptr ? 8 : 1;
+        const dim3 grid((unsigned)y2_cdiv(Tc, (long long)ny * oa.loop), (unsigned)y2_cdiv(oa.n4n, nx));
+        if (p->stats != nullptr) hipLaunchKernelGGL(wino_output_kernel<true>, grid, dim3(nx, ny), 0, s, oa);
+        else hipLaunchKernelGGL(wino_output_kernel<false>, grid, dim3(nx, ny), 0, s, oa);
+    }
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
