@@ -159,6 +159,27 @@ def test_conv_fwd_winograd_matches_fp64_reference(B, cin, cout, H, W, tile, pool
         assert rel_err(y[..., c0:c0 + cout].permute(0, 3, 1, 2), ref) <= 4 * CONV_TOL
 
 
+@pytest.mark.parametrize('pool', [False, True])
+def test_conv_fwd_winograd_batch_chunks(pool, monkeypatch):
+    """Y2_WINO_CHUNK_MB bounds the Winograd workspace by running the three stages per batch chunk: 5 images in chunks of 2+2+1
+    (ragged last chunk) must give the same output and the same BN statistics as one chunk."""
+    B, cin, cout, H, W = 5, 64, 96, 14 if pool else 13, 10 if pool else 11
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    scale, shift = torch.randn(cout, generator=g), torch.randn(cout, generator=g) * 0.1
+    z, ref = ref_conv(x, w, scale, shift, 0.1, 3)
+    per_image = 16 * ((H + 1) // 2) * ((W + 1) // 2) * (cin + cout) * 4
+    assert 2 * per_image < (1 << 20) < 3 * per_image          # 1 MB holds two images of this layer
+    monkeypatch.setenv('Y2_WINO_CHUNK_MB', '1')
+    out = run_conv(x, w, scale, shift, 0.1, 3, pool=pool, both=pool, wino=True, stats=True)
+    assert rel_err(out['y'].permute(0, 3, 1, 2), ref) <= 4 * CONV_TOL
+    if pool:
+        assert rel_err(out['y_pool'].permute(0, 3, 1, 2), F.max_pool2d(ref, 2)) <= 4 * CONV_TOL
+    np.testing.assert_allclose(out['stats'][:cout].numpy(), z.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=2e-5 * float((z * z).sum((0, 2, 3)).max().sqrt()))
+    np.testing.assert_allclose(out['stats'][cout:].numpy(), (z * z).sum((0, 2, 3)).numpy(), rtol=2e-5)
+
+
 @pytest.mark.parametrize('tile', [1, 2, 3, 5, 7])
 @pytest.mark.parametrize('both', [False, True])
 def test_conv_fwd_fused_maxpool(tile, both):

@@ -290,8 +290,8 @@ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 // measured (B=32: 48 / 96 / 192 MB budgets -> 6.26 / 5.76 / 5.58 ms for the 22-layer chain against 5.50 ms unchunked): the
 // smaller GEMMs lose more than the transforms gain, so the default only bounds the workspace of very large batches.
 inline size_t wino_chunk_bytes() {
-    static long long mb = -1;
-    if (mb < 0) { const char* e = getenv("Y2_WINO_CHUNK_MB"); mb = (e != nullptr && atoll(e) > 0) ? atoll(e) : 4096; }
+    const char* e = getenv("Y2_WINO_CHUNK_MB");          // read per call: tests shrink it to force several chunks
+    const long long mb = (e != nullptr && atoll(e) > 0) ? atoll(e) : 4096;
     return (size_t)mb << 20;
 }
 
