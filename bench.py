@@ -265,9 +265,12 @@ def main():
     traffic = None
     try:   # HBM-side bytes per step of the same kernel family from the committed rocprofv3 PMC passes (separate runs)
         import glob
-        tf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_detect_b32_traffic.json')))
-        if tf and args.batch == 32 and args.size == 416:
+        tf = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_detect_b32_traffic.json')) if '_direct_' not in os.path.basename(f))
+        if tf and args.batch == 32 and args.size == 416 and args.model == 'darknet':
             traffic = json.load(open(tf[-1]))['traffic_bytes_per_step']
+        tfd = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_direct_detect_b32_traffic.json')))
+        if direct_leg is not None and tfd and args.batch == 32 and args.size == 416 and args.model == 'darknet':
+            direct_leg['traffic'] = json.load(open(tfd[-1]))['traffic_bytes_per_step']
     except Exception:
         traffic = None
     if rank == 0:
