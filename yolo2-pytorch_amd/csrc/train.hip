@@ -48,6 +48,7 @@ struct ActArgs {
     int B, H, W, C, ldz, ldy, coff, ldp, poff, out_mode;
     float slope;
     const float* res; int ldr;     // optional residual added before the activation (model/resnet.py:59,101)
+    y2_fastdiv d_wo, d_ho;         // exact 32-bit division by the (pooled) output width / height
 };
 
 __device__ __forceinline__ float act1(float z, float sc, float sh, float slope) {
@@ -55,26 +56,39 @@ __device__ __forceinline__ float act1(float z, float sc, float sh, float slope) 
     return u > 0.f ? u : u * slope;
 }
 
+// The streaming BN/activation kernels run on a grid whose thread count is a multiple of the channel-group count Cg (host:
+// act_grid), so a thread keeps ONE channel group for its whole loop (per-channel constants loaded once) and walks pixels
+// p, p + step, ...; (b, yo, xo) come from two exact 32-bit fast divisions only where a pool / reorg mapping needs them.
+// (The first version did five 64-bit divisions per element and was ALU-bound at ~4 TB/s.)
+__device__ __forceinline__ void act_decode(uint32_t p, const y2_fastdiv& d_wo, const y2_fastdiv& d_ho, int Wo, int Ho, int& b, int& yo, int& xo) {
+    const uint32_t r = y2_div(p, d_wo);
+    xo = (int)(p - r * (uint32_t)Wo);
+    const uint32_t bb = y2_div(r, d_ho);
+    yo = (int)(r - bb * (uint32_t)Ho);
+    b = (int)bb;
+}
+
 // one thread = CV channels (4 with 16-B accesses, or 1) of one pixel (POOL = false) or of one 2x2 window (POOL = true)
 template <bool POOL, int CV>
 __global__ void bn_act_fwd_kernel(const ActArgs a, long long total) {
     const int Cg = a.C / CV;
     const int Wo = POOL ? a.W / 2 : a.W, Ho = POOL ? a.H / 2 : a.H;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % Cg) * CV;
-        const long long p = i / Cg;                 // (b*Ho + yo)*Wo + xo
-        const int xo = (int)(p % Wo);
-        const long long r = p / Wo;
-        const int yo = (int)(r % Ho);
-        const int b = (int)(r / Ho);
-        float sc[CV], sh[CV];
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;            // multiple of Cg (host: act_grid)
+    const int c = (int)(tid % Cg) * CV;
+    const uint32_t npix = (uint32_t)(total / Cg), pstep = (uint32_t)(nthreads / Cg);
+    float sc[CV], sh[CV];
 #pragma unroll
-        for (int e = 0; e < CV; ++e) { sc[e] = a.scale ? a.scale[c + e] : 1.f; sh[e] = a.shift ? a.shift[c + e] : 0.f; }
+    for (int e = 0; e < CV; ++e) { sc[e] = a.scale ? a.scale[c + e] : 1.f; sh[e] = a.shift ? a.shift[c + e] : 0.f; }
+    const bool need_yx = POOL || a.out_mode == 1;
+    for (uint32_t p = (uint32_t)(tid / Cg); p < npix; p += pstep) {           // p = (b*Ho + yo)*Wo + xo
+        int b = 0, yo = 0, xo = 0;
+        if (need_yx) act_decode(p, a.d_wo, a.d_ho, Wo, Ho, b, yo, xo);
         float pm[CV];
 #pragma unroll
         for (int q = 0; q < (POOL ? 4 : 1); ++q) {
             const int yy = POOL ? 2 * yo + (q >> 1) : yo, xx = POOL ? 2 * xo + (q & 1) : xo;
-            const long long pix = ((long long)b * a.H + yy) * a.W + xx;
+            const long long pix = need_yx ? ((long long)b * a.H + yy) * a.W + xx : (long long)p;
             float v[CV];
             if (CV == 4) {
                 const f32x4 zz = *reinterpret_cast<const f32x4*>(a.z + pix * a.ldz + c);
@@ -100,7 +114,7 @@ __global__ void bn_act_fwd_kernel(const ActArgs a, long long total) {
             for (int e = 0; e < CV; ++e) pm[e] = (q == 0) ? v[e] : fmaxf(pm[e], v[e]);
         }
         if (POOL && a.y_pool != nullptr) {
-            const long long o = p * a.ldp + a.poff + c;
+            const long long o = (long long)p * a.ldp + a.poff + c;
             if (CV == 4) { f32x4 w = {pm[0], pm[1], pm[2], pm[3]}; *reinterpret_cast<f32x4*>(a.y_pool + o) = w; }
             else a.y_pool[o] = pm[0];
         }
@@ -124,6 +138,7 @@ struct ActBwdArgs {
     float slope;
     double n;
     int has_bn;
+    y2_fastdiv d_wo, d_ho;
 };
 
 template <bool POOL, int CV, bool APPLY>
@@ -154,18 +169,17 @@ __global__ void bn_act_bwd_kernel(const ActBwdArgs a, long long total) {
 #pragma unroll
     for (int e = 0; e < CV; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 
-    for (long long i = tid; i < total; i += nthreads) {
-        const long long p = i / Cg;
-        const int xo = (int)(p % Wo);
-        const long long r = p / Wo;
-        const int yo = (int)(r % Ho);
-        const int b = (int)(r / Ho);
+    const uint32_t npix = (uint32_t)(total / Cg), pstep = (uint32_t)(nthreads / Cg);
+    const bool need_yx = POOL || a.fmode == 1;
+    for (uint32_t p = (uint32_t)(tid / Cg); p < npix; p += pstep) {
+        int b = 0, yo = 0, xo = 0;
+        if (need_yx) act_decode(p, a.d_wo, a.d_ho, Wo, Ho, b, yo, xo);
         float zv[POOL ? 4 : 1][CV], yv[POOL ? 4 : 1][CV];
         long long pixs[POOL ? 4 : 1];
 #pragma unroll
         for (int q = 0; q < (POOL ? 4 : 1); ++q) {
             const int yy = POOL ? 2 * yo + (q >> 1) : yo, xx = POOL ? 2 * xo + (q & 1) : xo;
-            pixs[q] = ((long long)b * a.H + yy) * a.W + xx;
+            pixs[q] = need_yx ? ((long long)b * a.H + yy) * a.W + xx : (long long)p;
             if (CV == 4) {
                 const f32x4 zz = *reinterpret_cast<const f32x4*>(a.z + pixs[q] * a.ldz + c);
 #pragma unroll
@@ -185,7 +199,7 @@ __global__ void bn_act_bwd_kernel(const ActBwdArgs a, long long total) {
         float dp[CV];
         int arg[CV];
         if (POOL) {
-            const long long o = p * a.ldp + a.poff + c;
+            const long long o = (long long)p * a.ldp + a.poff + c;
             if (CV == 4) { const f32x4 d = *reinterpret_cast<const f32x4*>(a.dy_pool + o);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dp[e] = d[e]; }
@@ -528,6 +542,18 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const LossArgs a, const d
     }
 }
 
+// grid for the BN/activation kernels: blocks of 256 threads, total thread count a multiple of Cg
+inline int act_grid(long long total, int Cg) {
+    int g = 256, r = Cg;
+    while (r) { const int t = g % r; g = r; r = t; }
+    const int unit = Cg / g;
+    long long want = (total + 256 * 8 - 1) / (256 * 8);
+    const long long cap = (long long)Y2_NUM_CU * 8;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    return (int)(((want + unit - 1) / unit) * unit);
+}
+
 }  // namespace
 
 // ================================================================================================ C ABI
@@ -553,8 +579,10 @@ extern "C" int y2_bn_act_fwd_ex(const float* z, const float* scale, const float*
     if (residual != nullptr && ldr < C) return Y2_EINVAL;
     const bool vec = (!residual || (!(ldr & 3) && y2_aligned16(residual))) && !(C & 3) && !(ldz & 3) && (!y || (!(ldy & 3) && !(coff & 3) && y2_aligned16(y))) && (!pool || (!(ldp & 3) && !(poff & 3) && y2_aligned16(y_pool))) && y2_aligned16(z);
     const long long pix = (long long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    if (pix >= 0x7fffffffLL || C > 8192) return Y2_ENOSUP;
     const long long total = pix * (vec ? C / 4 : C);
-    const int grid = stream_grid(total, 256);
+    const int grid = act_grid(total, vec ? C / 4 : C);
+    a.d_wo = y2_make_fastdiv((uint32_t)(pool ? W / 2 : W)); a.d_ho = y2_make_fastdiv((uint32_t)(pool ? H / 2 : H));
     hipStream_t s = y2_s(stream);
     if (pool) { if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<true, 4>), dim3(grid), dim3(256), 0, s, a, total); else hipLaunchKernelGGL((bn_act_fwd_kernel<true, 1>), dim3(grid), dim3(256), 0, s, a, total); }
     else { if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<false, 4>), dim3(grid), dim3(256), 0, s, a, total); else hipLaunchKernelGGL((bn_act_fwd_kernel<false, 1>), dim3(grid), dim3(256), 0, s, a, total); }
@@ -581,16 +609,10 @@ extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float*
                      (!dy_full || (!(ldf & 3) && !(foff & 3) && y2_aligned16(dy_full))) && (!pool || (!(ldp & 3) && !(poff & 3) && y2_aligned16(dy_pool)));
     const int Cg = vec ? C / 4 : C;
     const long long pix = (long long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    if (pix >= 0x7fffffffLL) return Y2_ENOSUP;
     const long long total = pix * Cg;
-    // total threads must be a multiple of Cg: blocks of 256 threads, grid a multiple of Cg / gcd(Cg, 256)
-    int g = 256, r = Cg;
-    while (r) { const int t = g % r; g = r; r = t; }
-    const int unit = Cg / g;
-    long long want = (total + 256 * 8 - 1) / (256 * 8);
-    const long long cap = (long long)Y2_NUM_CU * 8;
-    if (want > cap) want = cap;
-    if (want < 1) want = 1;
-    const int grid = (int)(((want + unit - 1) / unit) * unit);
+    const int grid = act_grid(total, Cg);     // total threads a multiple of Cg
+    a.d_wo = y2_make_fastdiv((uint32_t)(pool ? W / 2 : W)); a.d_ho = y2_make_fastdiv((uint32_t)(pool ? H / 2 : H));
     const size_t lds = (size_t)2 * C * sizeof(float);
     hipStream_t s = y2_s(stream);
 #define Y2_BWD(POOL, CV)                                                                                             \
