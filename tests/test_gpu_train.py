@@ -76,12 +76,26 @@ def test_winograd_wgrad_and_dgrad(B, cin, cout, H, W):
     need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
     ws = torch.empty(need // 4 + 4, device=d)
     dwp = torch.full((w.numel(),), 7.0, device=d)      # overwritten, not accumulated
-    _hip.check(L.y2_wino_wgrad(_hip.ptr(xd), _hip.ptr(dzd), _hip.ptr(dwp), B, H, W, cin, cin, cout, cout, _hip.ptr(ws), ws.numel() * 4, _hip.stream()), 'wino_wgrad')
+    _hip.check(L.y2_wino_wgrad(_hip.ptr(xd), _hip.ptr(dzd), _hip.ptr(dwp), B, H, W, cin, cin, cout, cout, None, _hip.ptr(ws), ws.numel() * 4, _hip.stream()), 'wino_wgrad')
     dw = torch.empty(cout, cin, 3, 3, device=d)
     _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cout, cin, 3, _hip.stream()), 'unpack')
     assert rel(dw, w.grad) <= 4 * TOL
-    wd = torch.empty(w.numel(), device=d)
     wdev = w.detach().float().to(d).contiguous()
+    # the same gradient from the transformed input a Winograd FORWARD leaves at the head of its workspace (no x needed)
+    wp = torch.empty(w.numel(), device=d)
+    _hip.check(L.y2_pack_weight(_hip.ptr(wdev), _hip.ptr(wp), cout, cin, 3, 0, _hip.stream()), 'pack0')
+    uf = _hip.wino_weight(wp, cout, cin)
+    yf = torch.empty(B, H, W, cout, device=d)
+    pf = _hip.ConvParams()
+    pf.x, pf.w, pf.y, pf.algo = xd.data_ptr(), uf.data_ptr(), yf.data_ptr(), 1
+    pf.B, pf.H, pf.W, pf.Cin, pf.ldx, pf.Cout, pf.ksize, pf.ldy, pf.slope = B, H, W, cin, cin, cout, 3, cout, 1.0
+    wsf = torch.empty(L.y2_conv_fwd_workspace_bytes(ctypes.byref(pf)) // 4 + 4, device=d)
+    pf.workspace, pf.workspace_bytes = wsf.data_ptr(), wsf.numel() * 4
+    _hip.check(L.y2_conv_fwd(ctypes.byref(pf), _hip.stream()), 'wino fwd')
+    dwp2 = torch.full((w.numel(),), -3.0, device=d)
+    _hip.check(L.y2_wino_wgrad(None, _hip.ptr(dzd), _hip.ptr(dwp2), B, H, W, cin, cin, cout, cout, _hip.ptr(wsf), _hip.ptr(ws), ws.numel() * 4, _hip.stream()), 'wino_wgrad(v)')
+    assert torch.equal(dwp2, dwp) or rel(dwp2, dwp.cpu()) <= 1e-5      # same arithmetic; split partial sums are added atomically
+    wd = torch.empty(w.numel(), device=d)
     _hip.check(L.y2_pack_weight(_hip.ptr(wdev), _hip.ptr(wd), cout, cin, 3, 1, _hip.stream()), 'pack1')
     u = _hip.wino_weight(wd, cin, cout)
     dx = torch.empty(B, H, W, cin, device=d)

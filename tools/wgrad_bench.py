@@ -53,7 +53,7 @@ def main():
             _hip.check(L.y2_conv_wgrad(_hip.ptr(x), _hip.ptr(dz), _hip.ptr(dw), B, H, W, cin, cin, cout, cout, 3, st), 'wgrad')
 
         def wino():
-            _hip.check(L.y2_wino_wgrad(_hip.ptr(x), _hip.ptr(dz), _hip.ptr(dw), B, H, W, cin, cin, cout, cout, _hip.ptr(ws), ws.numel() * 4, st), 'wino_wgrad')
+            _hip.check(L.y2_wino_wgrad(_hip.ptr(x), _hip.ptr(dz), _hip.ptr(dw), B, H, W, cin, cin, cout, cout, None, _hip.ptr(ws), ws.numel() * 4, st), 'wino_wgrad')
         td, tw = timeit(direct, args.reps), timeit(wino, args.reps)
         print('%-6s B=%d %3dx%-3d %4d->%-4d direct %7.3f ms %6.1f TF/s | winograd %7.3f ms %6.1f TF/s (equiv)  x%.2f' %
               (name, B, H, W, cin, cout, td, flops / td / 1e9, tw, flops / tw / 1e9, td / tw), flush=True)

@@ -52,7 +52,7 @@ SIGNATURES = {
     'y2_opt_grad_sumsq': [ctypes.POINTER(OptTensor), c_int, c_void_p, c_void_p],
     'y2_opt_clip_grads': [ctypes.POINTER(OptTensor), c_int, c_void_p, c_float, c_void_p],
     'y2_wino_wgrad_workspace_bytes': [c_int, c_int, c_int, c_int, c_int],
-    'y2_wino_wgrad': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, ctypes.c_longlong, c_void_p],
+    'y2_wino_wgrad': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_longlong, c_void_p],
     'y2_conv_fwd_batch': [ctypes.POINTER(ConvParams), c_int, c_void_p],
     'y2_conv0_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
@@ -270,10 +270,11 @@ def _tune_save():
 _WGRAD_WS = {}
 
 
-def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k):
+def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None):
     """Packed weight gradient dw[cout][k*k][cin] of a stride-1 "same" convolution: y2_conv_wgrad (9 shifted reductions
     over pixels) or, for 3x3 layers where it measures faster, y2_wino_wgrad (16 reductions over 2x2 tiles).  The choice
-    is timed once per problem shape and cached."""
+    is timed once per problem shape and cached.  `v`: the layer's transformed input kept from a Winograd forward (see
+    include/yolo2_hip.h, y2_wino_wgrad) - the weight gradient then skips its input transform."""
     L, st, dev = lib(), stream(), x.device
     dwp = torch.zeros(cout * cin * k * k, dtype=torch.float32, device=dev)
 
@@ -289,8 +290,8 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k):
         _WGRAD_WS[str(dev)] = ws
 
     def wino():
-        check(L.y2_wino_wgrad(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, ptr(ws), ws.numel() * 4, st), 'y2_wino_wgrad')
-    key = ('wgrad', B, H, W, cin, ldx, cout, ldz, str(dev))
+        check(L.y2_wino_wgrad(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, ptr(v), ptr(ws), ws.numel() * 4, st), 'y2_wino_wgrad')
+    key = ('wgrad', B, H, W, cin, ldx, cout, ldz, v is not None, str(dev))
     choice = _TUNE.get(key)
     if choice is None:
         if not AUTOTUNE or torch.cuda.is_current_stream_capturing():

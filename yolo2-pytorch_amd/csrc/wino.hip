@@ -398,8 +398,10 @@ extern "C" long long y2_wino_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t
 }
 
 extern "C" int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t ldx,
-                             int32_t Cout, int32_t ldz, float* workspace, long long workspace_bytes, y2_stream_t stream) {
-    if (x == nullptr || dz == nullptr || dw_packed == nullptr || workspace == nullptr) return Y2_EINVAL;
+                             int32_t Cout, int32_t ldz, const float* v_transformed, float* workspace, long long workspace_bytes, y2_stream_t stream) {
+    if ((x == nullptr && v_transformed == nullptr) || dz == nullptr || dw_packed == nullptr || workspace == nullptr) return Y2_EINVAL;
+    if (v_transformed != nullptr && !y2_aligned16(v_transformed)) return Y2_EALIGN;
+    if (x == nullptr) x = v_transformed;      // only the alignment checks below look at it
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldz < Cout) return Y2_EINVAL;
     if ((Cin & 3) || (Cout & 3) || (ldx & 3) || (ldz & 3) || !y2_aligned16(x) || !y2_aligned16(dz) || !y2_aligned16(workspace)) return Y2_EALIGN;
     if (workspace_bytes < y2_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return Y2_EINVAL;
@@ -417,14 +419,15 @@ extern "C" int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, 
     WinoInArgs ia;
     ia.x = x; ia.v = V; ia.B = B; ia.H = H; ia.W = W; ia.Cin = Cin; ia.ldx = ldx; ia.th = th; ia.tw = tw; ia.T = (int)T; ia.c4n = Cin / 4;
     ia.d_c4 = y2_make_fastdiv((uint32_t)ia.c4n); ia.d_tt = y2_make_fastdiv((uint32_t)(th * tw)); ia.d_tw = y2_make_fastdiv((uint32_t)tw);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)y2_cdiv(T * ia.c4n, 256)), dim3(256), 0, s, ia);
+    if (v_transformed == nullptr) hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)y2_cdiv(T * ia.c4n, 256)), dim3(256), 0, s, ia);
+    const float* Vsrc = v_transformed != nullptr ? v_transformed : V;
 
     WinoDzArgs za;
     za.dz = dz; za.dm = DM; za.B = B; za.H = H; za.W = W; za.Cout = Cout; za.ldz = ldz; za.th = th; za.tw = tw; za.T = (int)T; za.c4n = Cout / 4;
     za.d_c4 = y2_make_fastdiv((uint32_t)za.c4n); za.d_tt = ia.d_tt; za.d_tw = ia.d_tw;
     hipLaunchKernelGGL(wino_dz_kernel, dim3((unsigned)y2_cdiv(T * za.c4n, 256)), dim3(256), 0, s, za);
 
-    const int rc = y2_internal_wgrad_grouped(V, DM, DU, T, Cin, Cout, 16, T * Cin, T * Cout, (long long)Cout * Cin, stream);
+    const int rc = y2_internal_wgrad_grouped(Vsrc, DM, DU, T, Cin, Cout, 16, T * Cin, T * Cout, (long long)Cout * Cin, stream);
     if (rc != Y2_OK) return rc;
     const long long n = (long long)Cout * Cin;
     hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)y2_cdiv(n, 256)), dim3(256), 0, s, DU, dw_packed, Cout, Cin);

@@ -16,6 +16,7 @@ carry the arithmetic:
 torch only allocates, keeps the autograd tape and (in train.py's wrapper) runs the RCCL all-reduce.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -28,13 +29,16 @@ SYNC_POSITIVES = True   # data parallel: all-reduce the positive count so the cl
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.01
 LEAKY = 0.1
+_WINO_CHUNK_BYTES = int(os.environ.get('Y2_WINO_CHUNK_MB', '4096')) << 20      # csrc/wino.hip: wino_chunk_bytes()
 
 
 def _new(dev, *shape, dtype=torch.float32):
     return torch.empty(*shape, dtype=dtype, device=dev)
 
 
-def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=None, slope=1.0, stats=None, y_pool=None, ldp=0, coff=0, out_mode=0):
+def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=None, slope=1.0, stats=None, y_pool=None, ldp=0, coff=0, out_mode=0, keep_v=False):
+    """One y2_conv_fwd.  keep_v: when the Winograd algorithm is chosen, run it in a workspace of its own and return that tensor -
+    its head is the transformed input V, which the weight gradient of the same layer reuses (y2_wino_wgrad v_transformed)."""
     p = _hip.ConvParams()
     p.x, p.w = x.data_ptr(), wp.data_ptr()
     p.scale = scale.data_ptr() if scale is not None else None
@@ -48,14 +52,23 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
     # 3x3 layers: also offer the Winograd algorithm (filter transform of the packed weight: fprop and dgrad alike)
     u = _hip.wino_weight(wp, cout, cin) if (out_mode == 0 and _hip.wino_eligible(cout, cin, k)) else None
     _hip.autotune_conv(p, x.device, wino_w=u)
-    _hip.conv_workspace(p, x.device)
+    kept = None
+    if keep_v and p.algo == 1:
+        T = B * ((H + 1) // 2) * ((W + 1) // 2)
+        if 16 * T * (cin + cout) * 4 <= _WINO_CHUNK_BYTES:        # one batch chunk: V covers the whole batch
+            need = L.y2_conv_fwd_workspace_bytes(ctypes.byref(p))
+            kept = torch.empty(need // 4 + 4, dtype=torch.float32, device=x.device)
+            p.workspace, p.workspace_bytes = kept.data_ptr(), kept.numel() * 4
+    if kept is None:
+        _hip.conv_workspace(p, x.device)
     _hip.check(L.y2_conv_fwd(ctypes.byref(p), st), 'y2_conv_fwd')
+    return kept
 
 
 class _Block(object):
     """One conv block of the forward pass: geometry + saved tensors for backward."""
     __slots__ = ('mod', 'name', 'x', 'ldx', 'H', 'W', 'cin', 'cout', 'k', 'z', 'scale', 'shift', 'mean', 'invstd', 'pool',
-                 'out_full', 'out_pool', 'out_ld', 'out_off', 'out_mode', 'has_bn', 'slope', 'first')
+                 'out_full', 'out_pool', 'out_ld', 'out_off', 'out_mode', 'has_bn', 'slope', 'first', 'wino_v')
 
 
 def darknet_forward(dnn, x):
@@ -86,6 +99,7 @@ class DarknetTrainFn(torch.autograd.Function):
             cout, cin, k, _ = weight.shape
             blk.mod, blk.name, blk.x, blk.ldx, blk.H, blk.W, blk.cin, blk.cout, blk.k = mod, name, xin, ldx, h, w, cin, cout, k
             blk.pool, blk.has_bn, blk.slope, blk.first = pool, mod.bn is not None, (LEAKY if mod.has_act else 1.0), first
+            blk.wino_v = None
             z = _new(dev, B, h, w, cout)
             stats = torch.zeros(_hip.STATS_REPL * 2 * cout, dtype=torch.float64, device=dev) if blk.has_bn else None
             if first:
@@ -94,7 +108,7 @@ class DarknetTrainFn(torch.autograd.Function):
             else:
                 wp = _new(dev, weight.numel())
                 _hip.check(L.y2_pack_weight(_hip.ptr(_hip.f32c(weight)), _hip.ptr(wp), cout, cin, k, 0, st), 'y2_pack_weight')
-                _conv(L, st, xin, wp, z, B, h, w, cin, ldx, cout, k, cout, stats=stats)
+                blk.wino_v = _conv(L, st, xin, wp, z, B, h, w, cin, ldx, cout, k, cout, stats=stats, keep_v=True)
             blk.z = z
             if blk.has_bn:
                 bn = mod.bn
@@ -226,7 +240,8 @@ class DarknetTrainFn(torch.autograd.Function):
                 _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw4), cop, 4, k, st), 'y2_unpack_weight_grad')
                 ready(weight, dw4[:cout, :cin].contiguous())
             else:
-                dwp = _hip.conv_wgrad(blk.x, dz, B, h, w, cin, blk.ldx, cop, cop, k)     # direct or Winograd, by measurement
+                dwp = _hip.conv_wgrad(blk.x, dz, B, h, w, cin, blk.ldx, cop, cop, k, v=blk.wino_v)     # direct or Winograd, by measurement
+                blk.wino_v = None
                 dw = _new(dev, cop, cin, k, k)
                 _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cop, cin, k, st), 'y2_unpack_weight_grad')
                 ready(weight, dw if cop == cout else dw[:cout].contiguous())
