@@ -276,11 +276,16 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None):
     is timed once per problem shape and cached.  `v`: the layer's transformed input kept from a Winograd forward (see
     include/yolo2_hip.h, y2_wino_wgrad) - the weight gradient then skips its input transform."""
     L, st, dev = lib(), stream(), x.device
-    dwp = torch.zeros(cout * cin * k * k, dtype=torch.float32, device=dev)
+    nw = cout * cin * k * k
+    eligible = wino_eligible(cout, cin, k) and not (ldx % 4) and not (ldz % 4)
+    key = ('wgrad', B, H, W, cin, ldx, cout, ldz, v is not None, str(dev))
+    choice = _TUNE.get(key) if eligible else 0
+    # the direct kernel accumulates split partial sums into a zeroed buffer; the Winograd path overwrites (no fill needed)
+    dwp = torch.empty(nw, dtype=torch.float32, device=dev) if choice == 1 else torch.zeros(nw, dtype=torch.float32, device=dev)
 
     def direct():
         check(L.y2_conv_wgrad(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, k, st), 'y2_conv_wgrad')
-    if not wino_eligible(cout, cin, k) or (ldx % 4) or (ldz % 4):
+    if not eligible:
         direct()
         return dwp
     need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
@@ -291,8 +296,6 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None):
 
     def wino():
         check(L.y2_wino_wgrad(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, ptr(v), ptr(ws), ws.numel() * 4, st), 'y2_wino_wgrad')
-    key = ('wgrad', B, H, W, cin, ldx, cout, ldz, v is not None, str(dev))
-    choice = _TUNE.get(key)
     if choice is None:
         if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             choice = 1 if cin >= 128 else 0

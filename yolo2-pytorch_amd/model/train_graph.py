@@ -90,6 +90,15 @@ class DarknetTrainFn(torch.autograd.Function):
             raise ValueError('input size must be a multiple of 32 (got %dx%d)' % (H, W))
         dev = x.device
         b1, b2, b3 = dnn._blocks()
+        # one zero-filled arena for every layer's replicated BN-statistics accumulators (one fill kernel instead of 22)
+        couts = [m.conv.weight.shape[0] for _, m, _ in b1 + b2 + b3] + [dnn.passthrough.conv.weight.shape[0]]
+        arena = torch.zeros(_hip.STATS_REPL * 2 * sum(couts), dtype=torch.float64, device=dev)
+        arena_used = [0]
+
+        def take(n):
+            t = arena[arena_used[0]:arena_used[0] + n]
+            arena_used[0] += n
+            return t
         blocks = []
 
         def run_block(name, mod, xin, ldx, h, w, pool, out_full=None, out_ld=0, out_off=0, out_mode=0, want_full=True, first=False):
@@ -101,7 +110,7 @@ class DarknetTrainFn(torch.autograd.Function):
             blk.pool, blk.has_bn, blk.slope, blk.first = pool, mod.bn is not None, (LEAKY if mod.has_act else 1.0), first
             blk.wino_v = None
             z = _new(dev, B, h, w, cout)
-            stats = torch.zeros(_hip.STATS_REPL * 2 * cout, dtype=torch.float64, device=dev) if blk.has_bn else None
+            stats = take(_hip.STATS_REPL * 2 * cout) if blk.has_bn else None
             if first:
                 _hip.check(L.y2_conv0_fwd(_hip.ptr(xin), _hip.ptr(_hip.f32c(weight)), None, None, _hip.ptr(z), None, _hip.ptr(stats),
                                           B, h, w, cin, cout, cout, 0, 1.0, st), 'y2_conv0_fwd')
@@ -200,10 +209,13 @@ class DarknetTrainFn(torch.autograd.Function):
         i_pass = idx['passthrough']
         order = list(range(n - 1, -1, -1))
         dcat = None
+        sums_arena = torch.zeros(2 * sum(b.cout for b in blocks), dtype=torch.float64, device=dev)     # one fill for all layers
+        sums_used = 0
         for i in order:
             blk = blocks[i]
             h, w, cout, cin, k = blk.H, blk.W, blk.cout, blk.cin, blk.k
-            sums = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
+            sums = sums_arena[sums_used:sums_used + 2 * cout]
+            sums_used += 2 * cout
             # the wgrad / dgrad DMA kernels want channel counts that are multiples of 4: an unaligned Cout (the 125 / 425
             # channel head) is handled in a zero-padded channel space; unaligned Cin is an inference-only feature
             cop = (cout + 3) // 4 * 4
