@@ -102,6 +102,7 @@ typedef struct y2_conv_params {
 
 #define Y2_ALGO_DIRECT 0
 #define Y2_ALGO_WINOGRAD 1
+#define Y2_ALGO_WINOGRAD_FUSED 2   /* same transforms, but GEMM + output transform in ONE kernel (no product tensor in memory); Cin % 32 == 0 */
 
 /* Winograd F(2x2,3x3) filter transform U[p][co][ci] = (G g G^T)[p], p = 4*xi + nu, from a packed 3x3 weight
  * (y2_pack_weight mode 0 for the forward conv, mode 1 for the data gradient: [Cout][9][Cin]).  Same role as the cuDNN

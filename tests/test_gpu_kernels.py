@@ -56,7 +56,7 @@ def run_conv(x_nchw, w, scale, shift, slope, k, pool=False, both=False, tile=0, 
     if wino:
         u = torch.empty(16 * w.numel() // 9, device=d)
         _hip.check(L.y2_wino_weight(_hip.ptr(wp), _hip.ptr(u), cout, cin, _hip.stream()), 'wino_weight')
-        wp, p.algo = u, 1
+        wp, p.algo = u, int(wino)          # 1 = Winograd, 2 = Winograd with fused GEMM + output transform
     p.x, p.w = x.data_ptr(), wp.data_ptr()
     p.scale = sc.data_ptr() if sc is not None else None
     p.shift = sh.data_ptr() if sh is not None else None
@@ -134,18 +134,21 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize('algo', [1, 2])
 @pytest.mark.parametrize('B,cin,cout,H,W,tile,pool,both', WINO_CASES)
-def test_conv_fwd_winograd_matches_fp64_reference(B, cin, cout, H, W, tile, pool, both):
+def test_conv_fwd_winograd_matches_fp64_reference(B, cin, cout, H, W, tile, pool, both, algo):
     """algo = Y2_ALGO_WINOGRAD: F(2x2,3x3) input/filter/output transforms around the grouped MFMA GEMM.  Odd sizes (ragged
     last tile row/column), concat-style channel windows, negative scales before the fused pool.  The transforms cost a
     few ulps: tolerance 4x the direct kernel's (still ~1e-5 of the output rms against the fp64 truth)."""
+    if algo == 2 and cin % 32:
+        pytest.skip('the fused kernel needs Cin % 32 == 0 (the library answers Y2_ENOSUP; autotune then keeps algo 1)')
     g = torch.Generator().manual_seed(B * 1000 + cin + cout + H)
     x = torch.randn(B, cin, H, W, generator=g)
     w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
     scale = torch.randn(cout, generator=g)
     shift = torch.randn(cout, generator=g) * 0.1
     z, ref = ref_conv(x, w, scale, shift, 0.1, 3)
-    out = run_conv(x, w, scale, shift, 0.1, 3, tile=tile, pool=pool, both=both, extra=0 if pool else 4, coff=0 if pool else 8, wino=True, stats=True)
+    out = run_conv(x, w, scale, shift, 0.1, 3, tile=tile, pool=pool, both=both, extra=0 if pool else 4, coff=0 if pool else 8, wino=algo, stats=True)
     s1, s2 = z.sum((0, 2, 3)), (z * z).sum((0, 2, 3))      # training-mode BN statistics from the output transform (valid pixels only)
     np.testing.assert_allclose(out['stats'][:cout].numpy(), s1.numpy(), rtol=1e-5, atol=2e-5 * float(s2.max().sqrt()))
     np.testing.assert_allclose(out['stats'][cout:].numpy(), s2.numpy(), rtol=2e-5)
@@ -159,20 +162,21 @@ def test_conv_fwd_winograd_matches_fp64_reference(B, cin, cout, H, W, tile, pool
         assert rel_err(y[..., c0:c0 + cout].permute(0, 3, 1, 2), ref) <= 4 * CONV_TOL
 
 
+@pytest.mark.parametrize('algo', [1, 2])
 @pytest.mark.parametrize('pool', [False, True])
-def test_conv_fwd_winograd_batch_chunks(pool, monkeypatch):
+def test_conv_fwd_winograd_batch_chunks(pool, monkeypatch, algo):
     """Y2_WINO_CHUNK_MB bounds the Winograd workspace by running the three stages per batch chunk: 5 images in chunks of 2+2+1
     (ragged last chunk) must give the same output and the same BN statistics as one chunk."""
-    B, cin, cout, H, W = 5, 64, 96, 14 if pool else 13, 10 if pool else 11
+    B, cin, cout, H, W = (5 if algo == 1 else 13), 64, 96, 14 if pool else 13, 10 if pool else 11      # fused: no product tensor, smaller chunks
     g = torch.Generator().manual_seed(77)
     x = torch.randn(B, cin, H, W, generator=g)
     w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
     scale, shift = torch.randn(cout, generator=g), torch.randn(cout, generator=g) * 0.1
     z, ref = ref_conv(x, w, scale, shift, 0.1, 3)
-    per_image = 16 * ((H + 1) // 2) * ((W + 1) // 2) * (cin + cout) * 4
-    assert 2 * per_image < (1 << 20) < 3 * per_image          # 1 MB holds two images of this layer
+    per_image = 16 * ((H + 1) // 2) * ((W + 1) // 2) * (cin + (cout if algo == 1 else 0)) * 4
+    assert per_image < (1 << 20) < B * per_image              # 1 MB holds fewer than the B images of this layer
     monkeypatch.setenv('Y2_WINO_CHUNK_MB', '1')
-    out = run_conv(x, w, scale, shift, 0.1, 3, pool=pool, both=pool, wino=True, stats=True)
+    out = run_conv(x, w, scale, shift, 0.1, 3, pool=pool, both=pool, wino=algo, stats=True)
     assert rel_err(out['y'].permute(0, 3, 1, 2), ref) <= 4 * CONV_TOL
     if pool:
         assert rel_err(out['y_pool'].permute(0, 3, 1, 2), F.max_pool2d(ref, 2)) <= 4 * CONV_TOL

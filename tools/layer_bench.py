@@ -35,7 +35,7 @@ def main():
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--only', default='')
     ap.add_argument('--no-split', action='store_true')
-    ap.add_argument('--wino', action='store_true', help='3x3 layers through algo = Winograd F(2x2,3x3); TF/s stay direct-equivalent')
+    ap.add_argument('--wino', type=int, default=0, help='3x3 layers through algo 1 (Winograd F(2x2,3x3)) or 2 (fused GEMM + output transform); TF/s stay direct-equivalent')
     args = ap.parse_args()
     L = _hip.lib()
     dev = torch.device('cuda:0')
@@ -64,7 +64,7 @@ def main():
             if args.wino and k == 3:
                 u = torch.empty(16 * cout * cin, device=dev)
                 _hip.check(L.y2_wino_weight(w.data_ptr(), u.data_ptr(), cout, cin, _hip.stream()), 'wino_weight')
-                p.w, p.algo = u.data_ptr(), 1
+                p.w, p.algo = u.data_ptr(), args.wino
                 _hip.conv_workspace(p, dev)
             elif not args.no_split:
                 _hip.conv_workspace(p, dev)

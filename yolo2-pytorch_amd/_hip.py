@@ -227,7 +227,7 @@ def autotune_conv(params, dev, wino_w=None):
     def apply(choice):
         algo, tile = choice
         params.algo, params.tile = algo, tile
-        params.w = wino_w.data_ptr() if algo == 1 else w_direct
+        params.w = wino_w.data_ptr() if algo in (1, 2) else w_direct
         return choice
     hit = _TUNE.get(key)
     if hit is not None:
@@ -239,6 +239,8 @@ def autotune_conv(params, dev, wino_w=None):
     cands = [(0, t) for t in [5, 3, 2, 1] + ([6] if params.Cout <= 32 else [])]
     if wino_ok:
         cands += [(1, t) for t in (5, 3, 2, 1)]
+        if params.Cin % 32 == 0:
+            cands.append((2, 0))        # fused GEMM + output transform (no product tensor): pays on the 52x52 layers
     best, best_t = (0, 0), float('inf')
     stats_save = params.stats
     params.stats = None          # timing launches must not accumulate statistics twice

@@ -702,7 +702,8 @@ int launch_dma(const ConvArgs& a0, hipStream_t stream, float* ws, size_t ws_byte
     a.tiles_m = y2_cdiv(a.M, BM);
     a.tiles_n = y2_cdiv(a.Cout, BN);
     a.cchunks = y2_cdiv(a.Cin, 32);
-    const size_t lds = 2u * (BM + BN) * 32 * sizeof(float);
+    size_t lds = 2u * (BM + BN) * 32 * sizeof(float);
+    if (const char* pad = getenv("Y2_CONV_LDS_MIN")) { const size_t m = (size_t)atol(pad); if (lds < m) lds = m; }   // occupancy experiments only
     const bool ctail = !GEN && (a.Cin % 32) != 0;
     const int nk_all = GEN ? y2_cdiv(a.K, 32) : a.taps * a.cchunks;
     const long long tiles = (long long)a.tiles_m * a.tiles_n * (a.groups > 1 ? a.groups : 1);
@@ -1040,7 +1041,7 @@ int choose_tile(long long M, int Cout, int nk) {
 
 static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need, int groups = 1, long long gx = 0, long long gw = 0, long long gy = 0) {
     if (ws_need != nullptr) *ws_need = 0;
-    if (p != nullptr && p->algo == Y2_ALGO_WINOGRAD && groups == 1) return y2_internal_wino_conv(p, stream, ws_need);
+    if (p != nullptr && (p->algo == Y2_ALGO_WINOGRAD || p->algo == Y2_ALGO_WINOGRAD_FUSED) && groups == 1) return y2_internal_wino_conv(p, stream, ws_need);
     if (p != nullptr && p->algo != Y2_ALGO_DIRECT && groups == 1) return Y2_EINVAL;
     if (p == nullptr || p->x == nullptr || p->w == nullptr) return Y2_EINVAL;
     if (p->y == nullptr && p->y_pool == nullptr && p->stats == nullptr) return Y2_EINVAL;

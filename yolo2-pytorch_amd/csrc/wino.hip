@@ -211,6 +211,210 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     }
 }
 
+// ---- stage 2 + 3 fused (Y2_ALGO_WINOGRAD_FUSED): one workgroup owns 64 tiles x 64 output channels for ALL 16 positions, so the
+// output transform A^T M A is in-lane arithmetic on the MFMA accumulators and M never goes to memory.
+//   * 4 waves (2 x 2), wave tile 32 tiles x 32 channels = one 32x32 MFMA block per position: 16 accumulators = 256 AGPRs, one
+//     wave per SIMD (measured: the LDS-DMA pipeline keeps ~95 % of its 2-workgroup rate with one workgroup per CU).
+//   * stage = (K-slab of 32 channels, position p): A = V[p][64 tiles][32] (8 KB) + B = U[p][64 couts][32] (8 KB), fetched by
+//     LDS-DMA (same 128-B rows + XOR chunk swizzle as conv_fwd_dma_kernel) into a WF_STAGES-deep ring: WF_STAGES-1 stages in
+//     flight, counted vmcnt + one raw s_barrier per stage; 8 ds_read_b128 + 16 MFMA 32x32x2 per wave per stage.
+//   * epilogue: accumulator register r of the 16 positions belongs to the same (tile, channel): 24 adds give the 2x2 output
+//     pixels, then affine + LeakyReLU, optional 2x2 max-pool (a tile is a pooling window) and BN statistics (valid pixels only).
+constexpr int WF_POS_FLOATS = (64 + 64) * 32;      // one position's A + B slab (16 KB)
+
+struct WinoFusedArgs {
+    const float* v;       // [16][T][Cin]
+    const float* u;       // [16][Cout][Cin]
+    const float* scale; const float* shift;
+    float* y; float* y_pool; double* stats;
+    int H, W, Cin, Cout, ldy, coff, ldp, poff, th, tw, T, tiles_m, tiles_n;
+    unsigned v_bytes, u_bytes;
+    float slope;
+    y2_fastdiv d_tt, d_tw;
+};
+
+// PG = positions per pipeline stage (one barrier per stage: 16*PG MFMAs per wave between barriers), WF_STAGES = ring depth.
+template <int PG, int WF_STAGES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fused_kernel(const WinoFusedArgs a) {
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int PER = 4 * PG;                              // DMA instructions per thread per stage (2 A + 2 B per position)
+    constexpr int D = WF_STAGES - 1;                         // stages in flight ahead of the one being consumed
+    constexpr int SPK = 16 / PG;                             // stages per K-slab
+    constexpr int WF_STAGE_FLOATS = PG * WF_POS_FLOATS;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tile = y2_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
+    const int m0 = tile_m * 64, n0 = tile_n * 64;
+
+    // staging: lane -> physical 16-B slot (lane & 7) of row (t >> 3) + 32*i, fetching logical chunk slot ^ swz(row)
+    const int srow = t >> 3;
+    const int lchunk = (lane & 7) ^ ((srow >> 1) & 7);
+    unsigned a_off[2], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + srow + 32 * i, n = n0 + srow + 32 * i;
+        a_off[i] = m < a.T ? (unsigned)(((size_t)m * a.Cin + 4 * lchunk) * 4) : OOB;
+        b_off[i] = n < a.Cout ? (unsigned)(((size_t)n * a.Cin + 4 * lchunk) * 4) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.v), 0, a.v_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
+    const unsigned v_plane = (unsigned)((size_t)a.T * a.Cin * 4), u_plane = (unsigned)((size_t)a.Cout * a.Cin * 4);
+
+    auto issue = [&](int kslab, int g, int slot) {
+#pragma unroll
+        for (int pp = 0; pp < PG; ++pp) {
+            const int p = g * PG + pp;
+            float* sa = smem + slot * WF_STAGE_FLOATS + pp * WF_POS_FLOATS + wave * (8 * 32);
+            float* sb = sa + 64 * 32;
+            const unsigned sv = (unsigned)p * v_plane + (unsigned)kslab * 128u;      // uniform part of the address
+            const unsigned su = (unsigned)p * u_plane + (unsigned)kslab * 128u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(sa + i * 32 * 32), 16, (int)a_off[i], (int)sv, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(sb + i * 32 * 32), 16, (int)b_off[i], (int)su, 0, 0);
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    const int sw = (l31 >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) foff[q] = l31 * 32 + (((2 * q + half) ^ sw) << 2);
+    const int fa = wm * 32 * 32, fb = 64 * 32 + wn * 32 * 32;
+
+    // one stage: PG independent accumulator chains, interleaved so consecutive MFMAs never depend on each other
+    auto compute = [&](int slot, f32x16* c) {
+        const float* sbuf = smem + slot * WF_STAGE_FLOATS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 av[PG], bv[PG];
+#pragma unroll
+            for (int pp = 0; pp < PG; ++pp) {
+                av[pp] = *reinterpret_cast<const f32x4*>(sbuf + pp * WF_POS_FLOATS + fa + foff[q]);
+                bv[pp] = *reinterpret_cast<const f32x4*>(sbuf + pp * WF_POS_FLOATS + fb + foff[q]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int pp = 0; pp < PG; ++pp) c[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[pp][e], bv[pp][e], c[pp], 0, 0, 0);
+        }
+    };
+
+    const int nks = a.Cin / 32;
+    const int NS = nks * SPK;                                // stages, position group fastest
+    int ik = 0, ip = 0, islot = 0;                           // next stage to issue
+    auto issue_next = [&]() {
+        issue(ik, ip, islot);
+        islot = islot == WF_STAGES - 1 ? 0 : islot + 1;
+        if (++ip == SPK) { ip = 0; ++ik; }
+    };
+    for (int s = 0; s < (NS < D ? NS : D); ++s) issue_next();
+    int cur = 0;
+    // steady K-slabs: every stage has D-1 younger stages in flight behind it
+    static_assert(D - 1 <= SPK - 1 && D <= 5 && PER * (D > 1 ? D - 1 : 1) < 64, "ring deeper than a K-slab / vmcnt range");
+    for (int ks = 0; ks < nks - 1; ++ks) {
+#pragma unroll
+        for (int g = 0; g < SPK; ++g) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * (D - 1)) : "memory");
+            __builtin_amdgcn_s_barrier();            // stage landed for everyone; everyone finished reading the previous stage
+            issue_next();                            // into the slot of the previous stage (a stage D ahead always exists here)
+            compute(cur, &acc[g * PG]);
+            cur = cur == WF_STAGES - 1 ? 0 : cur + 1;
+        }
+    }
+    // last K-slab: the number of younger stages shrinks to 0 -> exact counts
+#pragma unroll
+    for (int g = 0; g < SPK; ++g) {
+        const int younger = (SPK - 1 - g) < (D - 1) ? (SPK - 1 - g) : (D - 1);
+        if (younger == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D > 4 ? PER * 4 : 0) : "memory");
+        else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D > 3 ? PER * 3 : 0) : "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D > 2 ? PER * 2 : 0) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D > 1 ? PER * 1 : 0) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (g + D < SPK) issue_next();
+        compute(cur, &acc[g * PG]);
+        cur = cur == WF_STAGES - 1 ? 0 : cur + 1;
+    }
+
+    // ---- epilogue: output transform in registers.  C layout: lane -> channel n (l31), register r -> tile row (r&3) + 8*(r>>2) + 4*half
+    const int n = n0 + wn * 32 + l31;
+    const bool nok = n < a.Cout;
+    const float sc = (a.scale != nullptr && nok) ? a.scale[n] : 1.f;
+    const float sh = (a.shift != nullptr && nok) ? a.shift[n] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int tt = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float sm[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sm[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+            sm[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+        }
+        float o[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            o[i][0] = sm[i][0] + sm[i][1] + sm[i][2];
+            o[i][1] = sm[i][1] - sm[i][2] - sm[i][3];
+        }
+        if (tt >= a.T || !nok) continue;
+        const int b = (int)y2_div((uint32_t)tt, a.d_tt);
+        const int rr = tt - b * a.th * a.tw;
+        const int ty = (int)y2_div((uint32_t)rr, a.d_tw);
+        const int tx = rr - ty * a.tw;
+        const bool y1 = 2 * ty + 1 < a.H, x1 = 2 * tx + 1 < a.W;
+        if (a.stats != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if ((i == 1 && !y1) || (j == 1 && !x1)) continue;
+                    s1 += o[i][j];
+                    s2 += o[i][j] * o[i][j];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float uu = o[i][j] * sc + sh;
+                o[i][j] = uu > 0.f ? uu : uu * a.slope;
+            }
+        if (a.y != nullptr) {
+            float* dst = a.y + ((size_t)(b * a.H + 2 * ty) * a.W + 2 * tx) * a.ldy + a.coff + n;
+            dst[0] = o[0][0];
+            if (x1) dst[a.ldy] = o[0][1];
+            if (y1) {
+                dst[(size_t)a.W * a.ldy] = o[1][0];
+                if (x1) dst[(size_t)(a.W + 1) * a.ldy] = o[1][1];
+            }
+        }
+        if (a.y_pool != nullptr)
+            a.y_pool[((size_t)(b * a.th + ty) * a.tw + tx) * a.ldp + a.poff + n] = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1]));
+    }
+    if (a.stats != nullptr) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (half == 0 && nok) {
+            double* st = a.stats + (size_t)(tile_m % Y2_STATS_REPL) * 2 * a.Cout;
+            atomicAdd(st + n, (double)s1);
+            atomicAdd(st + a.Cout + n, (double)s2);
+        }
+    }
+}
+
 // ---- weight gradient:  dU[p][co][ci] = sum_t dM[p][t][co] * V[p][t][ci],   dM = A dz A^T (4x4 from the 2x2 gradient tile),
 //      dg = G^T dU G.  16 reductions over T tiles instead of 9 shifted reductions over 4T pixels (2.25x fewer MACs).
 struct WinoDzArgs {
@@ -321,9 +525,11 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     if (p->y_pool != nullptr && ((p->H & 1) || (p->W & 1) || p->ldp < p->poff + p->Cout)) return Y2_EINVAL;
     if (p->y_pool != nullptr && ((p->ldp % 4) != 0 || (p->poff % 4) != 0 || !y2_aligned16(p->y_pool))) return Y2_ENOSUP;
     if ((p->scale != nullptr && !y2_aligned16(p->scale)) || (p->shift != nullptr && !y2_aligned16(p->shift))) return Y2_ENOSUP;
+    const bool fused = p->algo == Y2_ALGO_WINOGRAD_FUSED;
+    if (fused && (p->Cin % 32) != 0) return Y2_ENOSUP;
     const int th = (p->H + 1) / 2, tw = (p->W + 1) / 2;
     // Batch chunks bound the workspace (V = 4x the input, M = 4x the output of a chunk); see wino_chunk_bytes().
-    const size_t img_bytes = (size_t)16 * th * tw * ((size_t)p->Cin + p->Cout) * sizeof(float);
+    const size_t img_bytes = (size_t)16 * th * tw * ((size_t)p->Cin + (fused ? 0 : p->Cout)) * sizeof(float);
     int cb = (int)(wino_chunk_bytes() / (img_bytes > 0 ? img_bytes : 1));
     if (cb < 1) cb = 1;
     if (cb > p->B) cb = p->B;
@@ -332,7 +538,8 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     const long long T = (long long)cb * th * tw;    // tiles of a full chunk
     if (T * (p->Cin / 4) >= 0xffffffffLL || T * (p->Cout / 4) >= 0xffffffffLL || T > 0x7fffffff) return Y2_ENOSUP;
     const size_t vbytes = align256((size_t)16 * T * p->Cin * sizeof(float));
-    const size_t mbytes = align256((size_t)16 * T * p->Cout * sizeof(float));
+    const size_t mbytes = fused ? 0 : align256((size_t)16 * T * p->Cout * sizeof(float));
+    if (fused && (vbytes >= 0x7fffffffull || (size_t)16 * p->Cout * p->Cin * 4 >= 0x7fffffffull)) return Y2_ENOSUP;
 
     // stage 2 as a grouped 1x1 "convolution" over an image of 1 x T pixels
     y2_conv_params q = {};
@@ -342,8 +549,10 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
         float* const dummy = reinterpret_cast<float*>(256);
         q.x = dummy; q.w = dummy; q.y = dummy;
         size_t inner = 0;
-        const int rc = y2_internal_conv_grouped(&q, 16, T * p->Cin, (long long)p->Cout * p->Cin, T * p->Cout, stream, &inner);
-        if (rc != Y2_OK) return rc;
+        if (!fused) {
+            const int rc = y2_internal_conv_grouped(&q, 16, T * p->Cin, (long long)p->Cout * p->Cin, T * p->Cout, stream, &inner);
+            if (rc != Y2_OK) return rc;
+        }
         *ws_need = vbytes + mbytes + inner;
         return Y2_OK;
     }
@@ -364,6 +573,35 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
         ia.d_c4 = y2_make_fastdiv((uint32_t)ia.c4n); ia.d_tt = d_tt; ia.d_tw = d_tw;
         hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)y2_cdiv(Tc * ia.c4n, 256)), dim3(256), 0, s, ia);
 
+        if (fused) {
+            WinoFusedArgs fa;
+            fa.v = V; fa.u = p->w; fa.scale = p->scale; fa.shift = p->shift; fa.stats = p->stats;
+            fa.y = p->y != nullptr ? p->y + in_off * p->ldy : nullptr;
+            fa.y_pool = p->y_pool != nullptr ? p->y_pool + (size_t)b0 * th * tw * p->ldp : nullptr;
+            fa.H = p->H; fa.W = p->W; fa.Cin = p->Cin; fa.Cout = p->Cout; fa.ldy = p->ldy; fa.coff = p->coff; fa.ldp = p->ldp; fa.poff = p->poff;
+            fa.th = th; fa.tw = tw; fa.T = (int)Tc; fa.tiles_m = y2_cdiv(Tc, 64); fa.tiles_n = y2_cdiv(p->Cout, 64);
+            fa.v_bytes = (unsigned)((size_t)16 * Tc * p->Cin * 4); fa.u_bytes = (unsigned)((size_t)16 * p->Cout * p->Cin * 4);
+            fa.slope = p->slope; fa.d_tt = d_tt; fa.d_tw = d_tw;
+            const long long grid = (long long)fa.tiles_m * fa.tiles_n;
+            if (grid > 0x7fffffffLL) return Y2_EINVAL;
+#define Y2_WF_LAUNCH(PG_, NST_)                                                                                                    \
+            do {                                                                                                                   \
+                auto kern = wino_fused_kernel<PG_, NST_>;                                                                          \
+                const size_t lds = (size_t)NST_ * PG_ * WF_POS_FLOATS * sizeof(float);                                             \
+                static bool attr = false;                                                                                          \
+                if (!attr) {                                                                                                       \
+                    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                    if (e != hipSuccess) return -(1000 + (int)e);                                                                  \
+                    attr = true;                                                                                                   \
+                }                                                                                                                  \
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, fa);                                             \
+            } while (0)
+            // measured on the 52x52 / 26x26 / 13x13 layers (B=32): 4 positions per stage + 2-deep ring (64 MFMAs per wave between
+            // barriers) 0.341 / 0.283 / 0.330 ms; 2 positions x 4-deep 0.357 / 0.289 / 0.336; 1 position x 6-deep 0.373 / 0.315 / 0.369
+            Y2_WF_LAUNCH(4, 2);
+#undef Y2_WF_LAUNCH
+            continue;
+        }
         q.W = (int)Tc;
         q.x = V; q.w = p->w; q.y = M;
         q.workspace = M + mbytes / sizeof(float);

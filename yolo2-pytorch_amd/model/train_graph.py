@@ -53,7 +53,7 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
     u = _hip.wino_weight(wp, cout, cin) if (out_mode == 0 and _hip.wino_eligible(cout, cin, k)) else None
     _hip.autotune_conv(p, x.device, wino_w=u)
     kept = None
-    if keep_v and p.algo == 1:
+    if keep_v and p.algo in (1, 2):
         T = B * ((H + 1) // 2) * ((W + 1) // 2)
         if 16 * T * (cin + cout) * 4 <= _WINO_CHUNK_BYTES:        # one batch chunk: V covers the whole batch
             need = L.y2_conv_fwd_workspace_bytes(ctypes.byref(p))
