@@ -248,20 +248,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
-    const int tile = y2_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
-    const int m0 = tile_m * 64, n0 = tile_n * 64;
+    // Persistent workgroups (one per CU): XCD x owns the contiguous chunk [x*per_xcd, (x+1)*per_xcd) of the tile list (tile_n
+    // fastest, so the workgroups of one XCD share V rows / the filter panel in that L2) and its workgroups stride through it.
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int xcd = blockIdx.x % Y2_NUM_XCD, wg_in_xcd = blockIdx.x / Y2_NUM_XCD;
+    const int wgs_per_xcd = gridDim.x / Y2_NUM_XCD;                    // host: gridDim.x is a multiple of 8
+    const int per_xcd = (ntiles + Y2_NUM_XCD - 1) / Y2_NUM_XCD;
+    const int xcd_end = min(ntiles, (xcd + 1) * per_xcd);
+    int tile = xcd * per_xcd + wg_in_xcd;
+    if (tile >= xcd_end) return;
 
     // staging: lane -> physical 16-B slot (lane & 7) of row (t >> 3) + 32*i, fetching logical chunk slot ^ swz(row)
     const int srow = t >> 3;
     const int lchunk = (lane & 7) ^ ((srow >> 1) & 7);
     unsigned a_off[2], b_off[2];
+    int m0 = 0, n0 = 0;
+    auto place = [&](int tl) {          // operand row offsets of tile tl
+        m0 = (tl / a.tiles_n) * 64;
+        n0 = (tl % a.tiles_n) * 64;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + srow + 32 * i, n = n0 + srow + 32 * i;
-        a_off[i] = m < a.T ? (unsigned)(((size_t)m * a.Cin + 4 * lchunk) * 4) : OOB;
-        b_off[i] = n < a.Cout ? (unsigned)(((size_t)n * a.Cin + 4 * lchunk) * 4) : OOB;
-    }
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + srow + 32 * i, n = n0 + srow + 32 * i;
+            a_off[i] = m < a.T ? (unsigned)(((size_t)m * a.Cin + 4 * lchunk) * 4) : OOB;
+            b_off[i] = n < a.Cout ? (unsigned)(((size_t)n * a.Cin + 4 * lchunk) * 4) : OOB;
+        }
+    };
+    place(tile);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.v), 0, a.v_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
     const unsigned v_plane = (unsigned)((size_t)a.T * a.Cin * 4), u_plane = (unsigned)((size_t)a.Cout * a.Cin * 4);
@@ -282,11 +294,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     f32x16 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-
     const int sw = (l31 >> 1) & 7;
     int foff[4];
 #pragma unroll
@@ -319,10 +326,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         islot = islot == WF_STAGES - 1 ? 0 : islot + 1;
         if (++ip == SPK) { ip = 0; ++ik; }
     };
-    for (int s = 0; s < (NS < D ? NS : D); ++s) issue_next();
+    for (int s = 0; s < (NS < D ? NS : D); ++s) issue_next();      // prologue of the first tile
     int cur = 0;
+    for (;;) {
+    const int em0 = m0, en0 = n0;                                  // this tile's origin (place() moves m0 / n0 to the next tile)
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
     // steady K-slabs: every stage has D-1 younger stages in flight behind it
     static_assert(D - 1 <= SPK - 1 && D <= 5 && PER * (D > 1 ? D - 1 : 1) < 64, "ring deeper than a K-slab / vmcnt range");
+    static_assert(D == 1, "persistent loop: with D > 1 the epilogue stores sit between DMA stages in the vmcnt order - re-derive the counts first");
     for (int ks = 0; ks < nks - 1; ++ks) {
 #pragma unroll
         for (int g = 0; g < SPK; ++g) {
@@ -347,16 +361,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         compute(cur, &acc[g * PG]);
         cur = cur == WF_STAGES - 1 ? 0 : cur + 1;
     }
+    // the next tile's first D stages go out BEFORE the epilogue: their DMA latency hides behind the output transform.  They
+    // land in the slots of stages NS-2 ... NS-D-1 (never the one just consumed), which every wave left before the last barrier.
+    // (The epilogue's stores also count in vmcnt; the ring in use is one stage deep, so the next wait is vmcnt(0) anyway.)
+    tile += wgs_per_xcd;
+    const bool more = tile < xcd_end;
+    if (more) {
+        place(tile);
+        ik = 0; ip = 0;
+        for (int s = 0; s < (NS < D ? NS : D); ++s) issue_next();
+    }
 
     // ---- epilogue: output transform in registers.  C layout: lane -> channel n (l31), register r -> tile row (r&3) + 8*(r>>2) + 4*half
-    const int n = n0 + wn * 32 + l31;
+    const int n = en0 + wn * 32 + l31;
     const bool nok = n < a.Cout;
     const float sc = (a.scale != nullptr && nok) ? a.scale[n] : 1.f;
     const float sh = (a.shift != nullptr && nok) ? a.shift[n] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int tt = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int tt = em0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         float sm[2][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -408,11 +432,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
         if (half == 0 && nok) {
-            double* st = a.stats + (size_t)(tile_m % Y2_STATS_REPL) * 2 * a.Cout;
+            double* st = a.stats + (size_t)((em0 >> 6) % Y2_STATS_REPL) * 2 * a.Cout;
             atomicAdd(st + n, (double)s1);
             atomicAdd(st + a.Cout + n, (double)s2);
         }
     }
+    if (!more) break;
+    }   // persistent tile loop
 }
 
 // ---- weight gradient:  dU[p][co][ci] = sum_t dM[p][t][co] * V[p][t][ci],   dM = A dz A^T (4x4 from the 2x2 gradient tile),
@@ -582,8 +608,9 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
             fa.th = th; fa.tw = tw; fa.T = (int)Tc; fa.tiles_m = y2_cdiv(Tc, 64); fa.tiles_n = y2_cdiv(p->Cout, 64);
             fa.v_bytes = (unsigned)((size_t)16 * Tc * p->Cin * 4); fa.u_bytes = (unsigned)((size_t)16 * p->Cout * p->Cin * 4);
             fa.slope = p->slope; fa.d_tt = d_tt; fa.d_tw = d_tw;
-            const long long grid = (long long)fa.tiles_m * fa.tiles_n;
-            if (grid > 0x7fffffffLL) return Y2_EINVAL;
+            const long long ntiles = (long long)fa.tiles_m * fa.tiles_n;
+            if (ntiles > 0x7fffffffLL) return Y2_EINVAL;
+            const long long grid = ntiles < Y2_NUM_CU ? ((ntiles + Y2_NUM_XCD - 1) / Y2_NUM_XCD) * Y2_NUM_XCD : Y2_NUM_CU;   // persistent: one per CU
 #define Y2_WF_LAUNCH(PG_, NST_)                                                                                                    \
             do {                                                                                                                   \
                 auto kern = wino_fused_kernel<PG_, NST_>;                                                                          \
