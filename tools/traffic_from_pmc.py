@@ -10,7 +10,7 @@ import json
 import re
 import sys
 
-FAMILY = re.compile(r'conv_fwd_dma_kernel|conv_splitk_fixup_kernel|wino_(input|output)_kernel')
+FAMILY = re.compile(r'conv_fwd_dma_kernel|conv_splitk_fixup_kernel|wino_(input|output|fused)_kernel')
 rows = []
 for line in open(sys.argv[1]):
     m = re.match(r'(\S+)\s+(\S+)\s+dispatches=\s*(\d+)\s+mean_per_dispatch=([0-9.eE+-]+)', line)
