@@ -132,7 +132,7 @@ WINO_CASES = [
     (2, 128, 64, 7, 9, 5, False, False), (2, 256, 512, 26, 26, 1, False, False), (2, 32, 48, 12, 20, 2, True, False),
     (2, 64, 32, 8, 8, 0, True, True), (1, 16, 20, 5, 3, 0, False, False), (2, 1280, 1024, 13, 13, 0, False, False),
     (4, 32, 320, 64, 64, 0, False, False),      # 320 output tiles of 64x64 > 256 CUs: persistent workgroups of the fused kernel take 2 tiles
-    (3, 64, 192, 50, 38, 0, True, True),        # 713 tiles x 3 channel tiles, ragged last tile, pool + full output
+    (3, 64, 192, 50, 38, 0, True, True),        # ragged last row tile (1425 tiles of 2x2) x 3 channel tiles, pool + full output
 ]
 
 
