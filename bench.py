@@ -246,7 +246,7 @@ def main():
     # second leg, reported beside the metric: the same step with the Winograd algorithm disabled = pure implicit-GEMM
     # convolutions (executed == algorithmic multiply-adds), the conv-MFMA roofline fraction north_star asks for
     direct_leg = None
-    if n_wino > 0 and not args.no_direct_leg:
+    if _hip.WINOGRAD and args.model == 'darknet' and not args.no_direct_leg:      # rank-independent condition: every rank runs the same barriers
         _hip.WINOGRAD = False
         dnn._plan_cache = None
         try:
