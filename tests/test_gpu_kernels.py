@@ -105,6 +105,7 @@ CASES = [
     # B, Cin, Cout, H, W, k, tile
     (2, 32, 64, 16, 24, 3, 1), (2, 32, 64, 16, 24, 3, 2), (2, 32, 64, 16, 24, 3, 3), (2, 32, 64, 16, 24, 3, 4), (2, 32, 64, 16, 24, 3, 5),
     (1, 64, 128, 13, 13, 3, 0), (2, 32, 64, 16, 24, 3, 7), (3, 512, 256, 13, 13, 3, 7), (2, 64, 125, 9, 7, 1, 7), (2, 16, 48, 10, 6, 3, 7), (3, 128, 64, 13, 13, 1, 0), (2, 96, 125, 7, 9, 1, 0), (2, 40, 72, 10, 6, 3, 1),
+    (2, 64, 160, 20, 24, 3, 8), (2, 96, 288, 13, 13, 3, 9), (3, 128, 128, 16, 16, 1, 8), (2, 40, 72, 10, 6, 3, 9),
     (2, 6, 20, 8, 8, 3, 0), (2, 64, 32, 16, 24, 3, 6), (3, 512, 256, 13, 13, 3, 5), (2, 1024, 125, 13, 13, 1, 3), (2, 64, 24, 16, 24, 3, 0), (1, 13, 33, 5, 7, 1, 2), (2, 256, 512, 13, 13, 3, 0),
 ]
 
@@ -186,7 +187,7 @@ def test_conv_fwd_winograd_batch_chunks(pool, monkeypatch, algo):
     np.testing.assert_allclose(out['stats'][cout:].numpy(), (z * z).sum((0, 2, 3)).numpy(), rtol=2e-5)
 
 
-@pytest.mark.parametrize('tile', [1, 2, 3, 5, 7])
+@pytest.mark.parametrize('tile', [1, 2, 3, 5, 7, 8, 9])
 @pytest.mark.parametrize('both', [False, True])
 def test_conv_fwd_fused_maxpool(tile, both):
     g = torch.Generator().manual_seed(5)

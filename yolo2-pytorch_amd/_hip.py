@@ -236,7 +236,9 @@ def autotune_conv(params, dev, wino_w=None):
         return apply((0, 0))
     L = lib()
     st = stream()
-    cands = [(0, t) for t in [5, 3, 2, 1] + ([6] if params.Cout <= 32 else [])]
+    big = params.B * params.H * params.W >= 65536 and params.Cout >= 128 and params.ksize in (1, 3) and params.stride in (0, 1) \
+        and params.pad_plus1 in (0, (params.ksize - 1) // 2 + 1) and not params.transposed and not params.residual
+    cands = [(0, t) for t in [5, 3, 2, 1] + ([6] if params.Cout <= 32 else []) + ([8, 9] if big else [])]      # 8, 9: 512-thread 256x128 / 128x256 tiles
     if wino_ok:
         cands += [(1, t) for t in (5, 3, 2, 1)]
         if params.Cin % 32 == 0:

@@ -348,13 +348,14 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvArgs a) {
 //   * 2-deep ring: iteration s = {vmcnt(0); barrier; issue DMA of slab s+1; 16 ds_read_b128 + 64 MFMA on slab s}.
 // Requirements (host checks, else the register-staged kernel runs): Cin, ldx multiples of 4, 16-B aligned bases,
 // tensors < 2^31 bytes.
-template <int BM, int BN, int WAVES_M, bool POOLORD, bool CTAIL, int STAGES = 2, bool GEN = false>
-__global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
+template <int BM, int BN, int WAVES_M, bool POOLORD, bool CTAIL, int STAGES = 2, bool GEN = false, int NTH = NT>
+__global__ __launch_bounds__(NTH) void conv_fwd_dma_kernel(const ConvArgs a) {
     constexpr int BK = 32;
-    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WAVES_N = (NTH / 64) / WAVES_M;
+    constexpr int RPP = NTH / 8;                  // rows staged per DMA pass (8 lanes per 128-B row)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MB = WM / 32, NB = WN / 32;
-    constexpr int AR = BM / 32, BR = BN / 32;     // DMA instructions per thread per slab (A rows, B rows)
+    constexpr int AR = BM / RPP, BR = BN / RPP;     // DMA instructions per thread per slab (A rows, B rows)
     constexpr int STAGE = (BM + BN) * BK;          // floats per LDS stage
     constexpr unsigned OOB = 0x80000000u;          // beyond num_records of any supported tensor -> zeros
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
     const int ktot = GEN ? a.K : a.taps * a.Cin;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int m = m0 + srow + 32 * i;
+        const int m = m0 + srow + RPP * i;
         if (GEN) {
             a_mask[i] = 0;
             if (m < a.M) {
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
     unsigned b_base[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-        const int n = n0 + srow + 32 * i;
+        const int n = n0 + srow + RPP * i;
         b_base[i] = n < a.Cout ? (unsigned)(((size_t)n * ktot + (GEN ? 0 : 4 * lchunk)) * 4) : OOB;
     }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gx_ptr), 0, a.x_bytes, 0x00020000);
@@ -467,20 +468,20 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
                     const unsigned yq = y2_div((unsigned)yu, a.d_ts), xq = y2_div((unsigned)xu, a.d_ts);
                     const bool ok = kok && yu >= 0 && xu >= 0 && (int)yq * a.tstride == yu && (int)xq * a.tstride == xu && yq < (unsigned)a.H && xq < (unsigned)a.W;
                     const unsigned voff = ok ? (unsigned)(((size_t)(a_mask[i] + yq * a.W + xq) * a.ldx + c) * 4) : OOB;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 32 * BK), 16, (int)voff, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * RPP * BK), 16, (int)voff, 0, 0, 0);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < AR; ++i) {
                     const bool ok = kok && (unsigned)(a_yb[i] + ky) < (unsigned)a.H && (unsigned)(a_xb[i] + kx) < (unsigned)a.W;
                     const unsigned voff = ok ? a_base[i] + toff : OOB;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 32 * BK), 16, (int)voff, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * RPP * BK), 16, (int)voff, 0, 0, 0);
                 }
             }
 #pragma unroll
             for (int i = 0; i < BR; ++i) {
                 const unsigned voff = (kok && b_base[i] != OOB) ? b_base[i] + (unsigned)kq * 4u : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sb + i * 32 * BK), 16, (int)voff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sb + i * RPP * BK), 16, (int)voff, 0, 0, 0);
             }
             return;
         }
@@ -493,13 +494,13 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
         for (int i = 0; i < AR; ++i) {
             const bool ok = (a_mask[i] & tbit) != 0 && cok;
             const unsigned voff = ok ? a_base[i] + toff : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 32 * BK), 16, (int)voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * RPP * BK), 16, (int)voff, 0, 0, 0);
         }
         const unsigned woff = (unsigned)((tap * a.Cin + c0) * 4);
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
             const unsigned voff = (CTAIL && !cok) ? OOB : b_base[i];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sb + i * 32 * BK), 16, (int)voff, (int)woff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sb + i * RPP * BK), 16, (int)voff, (int)woff, 0, 0);
         }
     };
 
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_dma_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(dst + (((i * NB + j) * 4 + g) * NT + t) * 4) = v;
+                    *reinterpret_cast<f32x4*>(dst + (((i * NB + j) * 4 + g) * NTH + t) * 4) = v;
                 }
         return;
     }
@@ -696,7 +697,7 @@ inline void plan_split(long long tiles, int nk, long long tile_elems, size_t ws_
     full_tiles = (int)(tiles - rem); ksplit = bs;
 }
 
-template <int BM, int BN, int WAVES_M, bool POOLORD, bool GEN = false>
+template <int BM, int BN, int WAVES_M, bool POOLORD, bool GEN = false, int NTH = NT>
 int launch_dma(const ConvArgs& a0, hipStream_t stream, float* ws, size_t ws_bytes, size_t* ws_need) {
     ConvArgs a = a0;
     a.tiles_m = y2_cdiv(a.M, BM);
@@ -728,15 +729,15 @@ int launch_dma(const ConvArgs& a0, hipStream_t stream, float* ws, size_t ws_byte
             if (e != hipSuccess) return -(1000 + (int)e);                                                                   \
             attr_set[SLOT] = true;                                                                                          \
         }                                                                                                                   \
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), LDSB, stream, a);                                          \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTH), LDSB, stream, a);                                         \
     } while (0)
-    if (GEN) Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, false, false, 2, true>), 3, lds);
-    else if (stages3 && !ctail) Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, false, 3>), 2, lds / 2 * 3);
-    else if (ctail) Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, true>), 1, lds);
-    else Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, false>), 0, lds);
+    if (GEN) Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, false, false, 2, true, NTH>), 3, lds);
+    else if (stages3 && !ctail) Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, false, 3, false, NTH>), 2, lds / 2 * 3);
+    else if (ctail) Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, true, 2, false, NTH>), 1, lds);
+    else Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, false, 2, false, NTH>), 0, lds);
 #undef Y2_DMA_LAUNCH
     if (a.ksplit > 1)
-        hipLaunchKernelGGL((conv_splitk_fixup_kernel<BM, BN, WAVES_M, (POOLORD && !GEN)>), dim3((unsigned)(tiles - a.full_tiles)), dim3(NT), 0, stream, a);
+        hipLaunchKernelGGL((conv_splitk_fixup_kernel<BM, BN, WAVES_M, (POOLORD && !GEN), NTH>), dim3((unsigned)(tiles - a.full_tiles)), dim3(NTH), 0, stream, a);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -985,6 +986,8 @@ int dispatch_dma(const ConvArgs& a, int tile, hipStream_t s, float* ws, size_t w
         case 3: return launch_dma<64, 64, 2, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);
         case 5: return launch_dma<64, 128, 2, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);
         case 6: return launch_dma<128, 32, 4, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);
+        case 8: if (!GEN) return launch_dma<256, 128, 4, POOLORD, false, 512>(a, s, ws, ws_bytes, ws_need); return Y2_ENOSUP;   // 8 waves: 2 per SIMD, 96 KB LDS, 6 B/clk operand DMA
+        case 9: if (!GEN) return launch_dma<128, 256, 2, POOLORD, false, 512>(a, s, ws, ws_bytes, ws_need); return Y2_ENOSUP;
         case 7: if (!GEN) return launch_wave<POOLORD>(a, s, ws, ws_bytes, ws_need); return Y2_ENOSUP;   // barrier-free wave-private 64x64 tiles   // narrow outputs (Cout <= 32: dgrad into the first layers)
         default: return Y2_ENOSUP;
     }
@@ -1109,9 +1112,9 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
     // variants and small Cin (K handled as one linear axis) use the GEN instantiation of the DMA kernel.
     const unsigned long long xb = (unsigned long long)Min * p->ldx * 4ull, wb = (unsigned long long)p->Cout * a.taps * p->Cin * 4ull;
     if (tile == 7 && (!standard || (p->Cin % 16) != 0 || groups > 1)) tile = 3;      // the wave-private kernel covers the standard convolutions only
-    const bool dma_tile = (tile == 1 || tile == 2 || tile == 3 || tile == 5 || tile == 6 || tile == 7);
+    const bool dma_tile = (tile == 1 || tile == 2 || tile == 3 || tile == 5 || tile == 6 || tile == 7 || tile == 8 || tile == 9);
     const bool dma_ok = vec && xb < 0x7fffffffull && wb < 0x7fffffffull && dma_tile;
-    const bool gen = !standard || (groups == 1 && dma_ok && tile != 7 && p->Cin < 32 && !pool && p->out_mode == 0);
+    const bool gen = !standard || (groups == 1 && dma_ok && tile != 7 && tile != 8 && tile != 9 && p->Cin < 32 && !pool && p->out_mode == 0);
     if (groups > 1 && (!dma_ok || gen || pool || p->out_mode != 0 || p->stats != nullptr || p->residual != nullptr)) return Y2_ENOSUP;
     float* ws = p->workspace;
     const size_t wsb = (ws != nullptr && y2_aligned16(ws)) ? (size_t)p->workspace_bytes : 0;
