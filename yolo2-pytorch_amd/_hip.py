@@ -234,10 +234,15 @@ def autotune_conv(params, dev, wino_w=None):
         return apply(tuple(hit) if isinstance(hit, (list, tuple)) else (0, hit))
     if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
         # no measurement possible: the choices the measurements converge to on MI355X (profiles/r01_detect_b32_layer_table.txt)
+        prefer = []
         if wino_ok and params.Cin % 32 == 0 and params.H * params.W >= 26 * 26:
-            return apply((2, 0))        # fused Winograd on the 104x104 ... 26x26 layers
+            prefer.append((2, 0))       # fused Winograd on the 104x104 ... 26x26 layers
         if wino_ok and params.Cin >= 128:
-            return apply((1, 5))        # three-kernel Winograd, 64x128 GEMM tiles, on the 13x13 layers
+            prefer.append((1, 5))       # three-kernel Winograd, 64x128 GEMM tiles, on the 13x13 layers
+        for choice in prefer:
+            apply(choice)
+            if lib().y2_conv_fwd_workspace_bytes(ctypes.byref(params)) >= 0:      # the library accepts this problem (sizes, alignment)
+                return choice
         return apply((0, 0))
     L = lib()
     st = stream()
