@@ -559,6 +559,8 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     int cb = (int)(wino_chunk_bytes() / (img_bytes > 0 ? img_bytes : 1));
     if (cb < 1) cb = 1;
     if (cb > p->B) cb = p->B;
+    // the fused kernel addresses V through one 32-bit buffer descriptor: keep a chunk's V below 2 GB
+    while (fused && cb > 1 && (size_t)16 * cb * th * tw * p->Cin * sizeof(float) >= 0x7fffffffull) cb = (cb + 1) / 2;
     const int nchunks = y2_cdiv(p->B, cb);
     cb = y2_cdiv(p->B, nchunks);                     // equal chunks
     const long long T = (long long)cb * th * tw;    // tiles of a full chunk

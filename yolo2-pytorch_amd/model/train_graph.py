@@ -55,7 +55,7 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
     kept = None
     if keep_v and p.algo in (1, 2):
         T = B * ((H + 1) // 2) * ((W + 1) // 2)
-        if 16 * T * (cin + cout) * 4 <= _WINO_CHUNK_BYTES:        # one batch chunk: V covers the whole batch
+        if 16 * T * (cin + cout) * 4 <= _WINO_CHUNK_BYTES and 16 * T * cin * 4 < 0x7fffffff:        # one batch chunk: V covers the whole batch
             need = L.y2_conv_fwd_workspace_bytes(ctypes.byref(p))
             kept = torch.empty(need // 4 + 4, dtype=torch.float32, device=x.device)
             p.workspace, p.workspace_bytes = kept.data_ptr(), kept.numel() * 4
