@@ -151,6 +151,7 @@ def main():
     ap.add_argument('--no-direct-leg', action='store_true', help='skip the extra Winograd-off measurement (roofline.direct_only)')
     ap.add_argument('--no-graph', action='store_true', help='launch the detect step eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--train-steps', type=int, default=6, help='extra leg: timed training steps (fwd + region loss + bwd + SGD), 0 = skip')
+    ap.add_argument('--settle', type=float, default=2.0, help='seconds of idle between the inference legs and the training leg (outside every timed region)')
     ap.add_argument('--train-batch', type=int, default=64, help='per-GPU batch of the training leg (BASELINE configs[2])')
     ap.add_argument('--cpu-sample', type=int, default=192, help='images for the CPU baseline (0 = skip)')
     args = ap.parse_args()
@@ -261,6 +262,8 @@ def main():
 
     train_out = None
     if args.train_steps > 0:
+        torch.cuda.synchronize()
+        time.sleep(args.settle)          # untimed pause between the inference legs and the training leg
         train_out = train_leg(args, dev, world, rank, barrier)
     traffic = None
     try:   # HBM-side bytes per step of the same kernel family from the committed rocprofv3 PMC passes (separate runs)
