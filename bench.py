@@ -256,6 +256,10 @@ def main():
             direct_leg = {'images_per_sec': round(args.batch * min(args.steps, 10) * world / ddt, 2), 'achieved': round(dex, 2),
                           'frac': round(dex / PEAK_FP32_MFMA_TFLOPS, 4), 'conv_chain_ms_per_step': round(dchain, 4),
                           'note': 'Y2_WINOGRAD=0: every 3x3 layer through the implicit-GEMM MFMA kernel'}
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            direct_leg = {'error': '%s: %s' % (type(e).__name__, e)}
         finally:
             _hip.WINOGRAD = True
             dnn._plan_cache = None
@@ -264,7 +268,12 @@ def main():
     if args.train_steps > 0:
         torch.cuda.synchronize()
         time.sleep(args.settle)          # untimed pause between the inference legs and the training leg
-        train_out = train_leg(args, dev, world, rank, barrier)
+        try:
+            train_out = train_leg(args, dev, world, rank, barrier)
+        except Exception as e:           # the extra leg must not take the headline metric down with it
+            import traceback
+            traceback.print_exc()
+            train_out = {'error': '%s: %s' % (type(e).__name__, e)}
     traffic = None
     try:   # HBM-side bytes per step of the same kernel family from the committed rocprofv3 PMC passes (separate runs)
         import glob
@@ -272,7 +281,7 @@ def main():
         if tf and args.batch == 32 and args.size == 416 and args.model == 'darknet':
             traffic = json.load(open(tf[-1]))['traffic_bytes_per_step']
         tfd = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_direct_detect_b32_traffic.json')))
-        if direct_leg is not None and tfd and args.batch == 32 and args.size == 416 and args.model == 'darknet':
+        if direct_leg is not None and 'error' not in direct_leg and tfd and args.batch == 32 and args.size == 416 and args.model == 'darknet':
             direct_leg['traffic'] = json.load(open(tfd[-1]))['traffic_bytes_per_step']
     except Exception:
         traffic = None
@@ -302,7 +311,10 @@ def main():
         if train_out is not None:
             out['train'] = train_out
         if world == 1 and args.cpu_sample > 0:
-            out['cpu_baseline'] = cpu_baseline(sd, anchors, args.size, args.cpu_sample)
+            try:
+                out['cpu_baseline'] = cpu_baseline(sd, anchors, args.size, args.cpu_sample)
+            except Exception as e:
+                out['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
