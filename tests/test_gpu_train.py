@@ -525,3 +525,26 @@ def test_fused_clip_grad_norm():
         np.testing.assert_allclose(norm.item(), total.item(), rtol=1e-6)
         for p, w in zip(ps, want):
             np.testing.assert_allclose(p.grad.cpu().numpy(), (w * coef).cpu().numpy(), rtol=2e-6, atol=1e-12)
+
+
+def test_multi_scale_training_steps_with_fused_adam_and_clip():
+    """train.py:338-362 over the reference's multi-scale schedule (config.ini sizes 320...608): consecutive steps at different input
+    sizes through one model / optimizer (utils.optim.Adam, the ini's default optimizer, + gradient clipping): kernels take H, W at run
+    time, per-shape tuning caches coexist, the loss stays finite and decreases on a repeated batch."""
+    import train as y2train
+    import utils
+    widths = dict(NARROW)
+    widths['layers1.5'] = 8   # training needs channel counts that are multiples of 4
+    inf, anchors = build(odark.init_state_dict(5, 20, seed=0, channels=widths, head_scale=1 / 8.0))
+    inf.train()
+    opt = utils.optim.Adam(inf.parameters(), 1e-3, betas=(0.9, 0.999), eps=1e-8)
+    seen = {}
+    for it, S in enumerate((320, 416, 352, 320, 416, 352, 320, 416, 352)):
+        data = {k: v.to(dev()) for k, v in synth.labels(2, S, 20, seed=7).items()}
+        data['tensor'] = synth.images(2, S, seed=8).to(dev())
+        r = y2train.iterate(inf, opt, data, oloss.HPARAM, 0.6, anchors, clip=5.0)
+        lt = float(r['loss_total'])
+        assert np.isfinite(lt), (it, S)
+        seen.setdefault(S, []).append(lt)
+    for S, ls in seen.items():
+        assert ls[-1] < ls[0], (S, ls)              # the same batch at the same size: three Adam steps apart the loss went down

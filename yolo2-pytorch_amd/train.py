@@ -175,6 +175,6 @@ def iterate(inference, optimizer, data, loss_hparam, threshold, anchors, clip=No
     optimizer.zero_grad()
     loss_total.backward()
     if clip is not None:
-        nn.utils.clip_grad_norm_(inference.parameters(), clip)
+        utils.optim.clip_grad_norm_(inference.parameters(), clip)     # fused form of nn.utils.clip_grad_norm (train.py:352-354)
     optimizer.step()
     return dict(pred=pred, loss=loss, loss_total=loss_total, debug=debug)
