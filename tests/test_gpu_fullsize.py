@@ -77,8 +77,9 @@ def test_batch_composition_independence_and_permutation(net, batch):
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(5))
     with torch.no_grad():
         fp = inf.dnn.forward_nhwc(x[perm].to(dev())).clone()
-    # same shape, same kernels: only the split-K remainder tiles may sum in another order
-    assert rel(fp, feat[perm.to(dev())]) <= 1e-5
+    # same shape, same kernels: only the rows that fall into split-K remainder tiles sum in another order, and 23 layers amplify
+    # that rounding (measured 0-2.5e-5 of the rms, depending on which algorithm each layer picked)
+    assert rel(fp, feat[perm.to(dev())]) <= 5e-5
 
 
 def test_decode_invariants_and_nms_properties_at_full_size(net, batch):
