@@ -187,6 +187,50 @@ def test_conv_fwd_winograd_batch_chunks(pool, monkeypatch, algo):
     np.testing.assert_allclose(out['stats'][cout:].numpy(), (z * z).sum((0, 2, 3)).numpy(), rtol=2e-5)
 
 
+def _random_conv_cases(n, seed=2024):
+    rng = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < n:
+        k = int(rng.choice([1, 3, 3]))
+        cin = int(rng.choice([4, 8, 12, 20, 32, 36, 64, 96, 100, 128, 160, 256]))
+        cout = int(rng.choice([4, 12, 20, 32, 48, 64, 100, 125, 128, 192, 320]))
+        H, W = int(rng.randint(1, 30)), int(rng.randint(1, 30))
+        B = int(rng.randint(1, 5))
+        pool = bool(rng.rand() < 0.3)
+        if pool:
+            H, W = 2 * max(1, H // 2), 2 * max(1, W // 2)
+        algos = [0]
+        if k == 3 and cin % 4 == 0 and cout % 4 == 0:
+            algos.append(1)
+            if cin % 32 == 0:
+                algos.append(2)
+        algo = int(rng.choice(algos))
+        tile = int(rng.choice([0, 1, 2, 3, 5])) if algo != 2 else 0
+        cases.append((B, cin, cout, H, W, k, tile, algo, pool))
+    return cases
+
+
+@pytest.mark.parametrize('B,cin,cout,H,W,k,tile,algo,pool', _random_conv_cases(48))
+def test_conv_fwd_random_shapes(B, cin, cout, H, W, k, tile, algo, pool):
+    """Seeded random problem shapes (1x1 ... 29x29 maps, channel counts that are not multiples of the tile sizes, every tile
+    configuration, direct / Winograd / fused Winograd, with and without the fused pool) against the fp64 reference: output,
+    pooled output and the BN statistics."""
+    g = torch.Generator().manual_seed(B * 7919 + cin * 31 + cout * 17 + H * 5 + W + k)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    scale = torch.randn(cout, generator=g)
+    shift = torch.randn(cout, generator=g) * 0.1
+    z, ref = ref_conv(x, w, scale, shift, 0.1, k)
+    out = run_conv(x, w, scale, shift, 0.1, k, tile=tile, pool=pool, both=pool, wino=algo, stats=True)
+    tol = CONV_TOL * (4 if algo else 1)
+    assert rel_err(out['y'].permute(0, 3, 1, 2), ref) <= tol
+    if pool:
+        assert rel_err(out['y_pool'].permute(0, 3, 1, 2), F.max_pool2d(ref, 2)) <= tol
+    s1, s2 = z.sum((0, 2, 3)), (z * z).sum((0, 2, 3))
+    np.testing.assert_allclose(out['stats'][:cout].numpy(), s1.numpy(), rtol=1e-5, atol=2e-5 * float(s2.max().sqrt()))
+    np.testing.assert_allclose(out['stats'][cout:].numpy(), s2.numpy(), rtol=2e-5)
+
+
 @pytest.mark.parametrize('tile', [1, 2, 3, 5, 7, 8, 9])
 @pytest.mark.parametrize('both', [False, True])
 def test_conv_fwd_fused_maxpool(tile, both):

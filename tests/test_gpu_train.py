@@ -107,6 +107,55 @@ def test_winograd_wgrad_and_dgrad(B, cin, cout, H, W):
     assert rel(dx.permute(0, 3, 1, 2), x.grad) <= 4 * TOL
 
 
+def _random_wgrad_cases(n, seed=77):
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        k = int(rng.choice([1, 3, 3]))
+        out.append((int(rng.randint(1, 5)), int(rng.choice([4, 8, 20, 32, 64, 100, 128, 192])), int(rng.choice([4, 12, 32, 64, 100, 128, 256])),
+                    int(rng.randint(1, 28)), int(rng.randint(1, 28)), k))
+    return out
+
+
+@pytest.mark.parametrize('B,cin,cout,H,W,k', _random_wgrad_cases(28))
+def test_conv_wgrad_dgrad_random_shapes(B, cin, cout, H, W, k):
+    """Seeded random shapes: direct weight gradient, Winograd weight gradient (3x3) and the data gradient (direct kernel on the
+    rotated filter; Winograd where the library accepts it) against fp64 autograd."""
+    import _hip
+    L = _hip.lib()
+    g = torch.Generator().manual_seed(B * 131 + cin * 7 + cout * 3 + H + W + k)
+    x = torch.randn(B, cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(cout, cin, k, k, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    dz = torch.randn(B, cout, H, W, generator=g, dtype=torch.float64)
+    F.conv2d(x, w, padding=(k - 1) // 2).backward(dz)
+    d = dev()
+    xd, dzd = nhwc(x.detach().float()).to(d), nhwc(dz.float()).to(d)
+    dwp = torch.zeros(w.numel(), device=d)
+    _hip.check(L.y2_conv_wgrad(_hip.ptr(xd), _hip.ptr(dzd), _hip.ptr(dwp), B, H, W, cin, cin, cout, cout, k, _hip.stream()), 'wgrad')
+    dw = torch.empty(cout, cin, k, k, device=d)
+    _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cout, cin, k, _hip.stream()), 'unpack')
+    assert rel(dw, w.grad) <= TOL
+    if k == 3:
+        ws = torch.empty(L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout) // 4 + 4, device=d)
+        dwp2 = torch.full((w.numel(),), 9.0, device=d)
+        _hip.check(L.y2_wino_wgrad(_hip.ptr(xd), _hip.ptr(dzd), _hip.ptr(dwp2), B, H, W, cin, cin, cout, cout, None, _hip.ptr(ws), ws.numel() * 4, _hip.stream()), 'wino_wgrad')
+        _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp2), _hip.ptr(dw), cout, cin, k, _hip.stream()), 'unpack')
+        assert rel(dw, w.grad) <= 4 * TOL
+    wd = torch.empty(w.numel(), device=d)
+    wdev = w.detach().float().to(d).contiguous()
+    _hip.check(L.y2_pack_weight(_hip.ptr(wdev), _hip.ptr(wd), cout, cin, k, 1, _hip.stream()), 'pack1')
+    for algo in ((0, 1, 2) if k == 3 else (0,)):
+        dx = torch.full((B, H, W, cin), 3.0, device=d)
+        p = _hip.ConvParams()
+        src = wd if algo == 0 else _hip.wino_weight(wd, cin, cout)
+        p.x, p.w, p.y, p.algo = dzd.data_ptr(), src.data_ptr(), dx.data_ptr(), algo
+        p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize, p.ldy, p.slope = B, H, W, cout, cout, cin, k, cin, 1.0
+        if _hip.conv_workspace(p, d) < 0:
+            continue            # e.g. the fused kernel wants Cin % 32 == 0
+        _hip.check(L.y2_conv_fwd(ctypes.byref(p), _hip.stream()), 'dgrad algo %d' % algo)
+        assert rel(dx.permute(0, 3, 1, 2), x.grad) <= (4 if algo else 1) * TOL, algo
+
+
 @pytest.mark.parametrize('B,cin,cout,H,W', [(2, 3, 32, 16, 32), (1, 3, 40, 9, 13), (2, 1, 8, 6, 6)])
 def test_conv0_wgrad(B, cin, cout, H, W):
     import _hip
