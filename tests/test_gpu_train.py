@@ -328,6 +328,35 @@ def test_region_loss_coco_and_single_class_vs_oracle():
         np.testing.assert_allclose(f.grad.cpu().numpy(), gr, rtol=5e-4, atol=2e-6 * np.abs(gr).max())
 
 
+@pytest.mark.parametrize('rows,B,nmax,C,seed', [(10, 1, 1, 20, 1), (13, 3, 30, 20, 2), (19, 5, 8, 20, 3), (13, 2, 50, 80, 4), (10, 4, 3, 3, 5), (19, 1, 20, 0, 6)])
+def test_region_loss_random_configurations_vs_oracle(rows, B, nmax, C, seed):
+    """Grid sizes of the reference's multi-scale schedule, 1 ... 50 ground-truth boxes per image (more boxes than cells share
+    anchors -> collisions), 0 / 3 / 20 / 80 classes: loss terms and d(loss)/d(feature) against the oracle's fp64 autograd."""
+    import model
+    A = 5
+    S = rows * 32
+    gen = torch.Generator().manual_seed(100 + seed)
+    feat = 0.5 * torch.randn(B, A * (5 + C), rows, rows, generator=gen)
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    data = synth.norm_data(synth.labels(B, S, max(C, 1), nmax=nmax, seed=seed), S, S, rows, rows)
+    fo = feat.clone().double().requires_grad_(True)
+    lo, _ = oloss.loss(anchors.double(), {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}, ohead.decode(fo, anchors.double()), 0.6)
+    oloss.total(lo).backward()
+
+    class Id(torch.nn.Module):
+        def forward(self, t):
+            return t
+    f = feat.to(dev()).requires_grad_(True)
+    pred = model._inference(model.Inference(None, Id(), anchors), f)
+    l, _ = model.loss(anchors, data, pred, 0.6)
+    sum(l[k] * oloss.HPARAM[k] for k in l).backward()
+    assert set(l.keys()) == set(lo.keys())
+    for k in l:
+        np.testing.assert_allclose(l[k].item(), lo[k].item(), rtol=5e-5)
+    gr = fo.grad.numpy()
+    np.testing.assert_allclose(f.grad.cpu().numpy(), gr, rtol=5e-4, atol=2e-6 * np.abs(gr).max())
+
+
 def build(sd, num_cls=20, bn=True):
     import model
     import model.yolo2
