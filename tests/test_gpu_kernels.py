@@ -495,6 +495,34 @@ def test_detect_batch_nothing_visible_and_everything_visible(golden, threshold):
                 np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize('rows,cols,C,B,fix,thr,overlap,limit,seed', [
+    (10, 10, 20, 3, False, 0.3, 0.45, 200, 1), (13, 13, 80, 2, True, 0.005, 0.45, 200, 2), (19, 19, 20, 2, False, 0.5, 0.3, 50, 3),
+    (13, 13, 0, 4, False, 0.2, 0.6, 200, 4), (19, 19, 80, 1, True, 0.02, 0.45, 1000, 5), (7, 12, 3, 2, False, 0.1, 0.5, 10, 6)])
+def test_detect_batch_random_configurations_vs_oracle(rows, cols, C, B, fix, thr, overlap, limit, seed):
+    """decode -> filter -> NMS -> gather over grid sizes (incl. a non-square one), class counts (0 = single class), both filter
+    modes, thresholds, overlaps and keep limits: survivors bit-exact against the oracle run on the GPU-decoded values."""
+    import detect
+    A = 5
+    g = torch.Generator().manual_seed(500 + seed)
+    ch = A * (5 + C)
+    feat = (torch.randn(B, rows, cols, ch, generator=g) * 1.5).to(dev())
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    kw = dict(threshold_cls=thr) if fix else dict(threshold=thr)
+    d = detect.detect_batch(feat, anchors, fix=fix, overlap=overlap, limit=limit, **kw)
+    res = detect.postprocess_batch(d, fix=fix, **(dict(threshold_cls=thr) if fix else {}))
+    n = rows * cols * A
+    iou = d['iou'].view(B, n).cpu().numpy()
+    mn, mx = d['yx_min'].view(B, n, 2).cpu().numpy(), d['yx_max'].view(B, n, 2).cpu().numpy()
+    prob = d['prob'].view(B, n, -1).cpu().numpy()
+    for b in range(B):
+        ref = odet.postprocess(iou[b], mn[b], mx[b], prob[b], fix=fix, overlap=overlap, limit=limit,
+                               **(dict(threshold_cls=thr) if fix else dict(threshold=thr)))
+        assert (ref is None) == (res[b] is None)
+        if ref is not None:
+            for got, want in zip(res[b], ref[:5]):
+                np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
 # ------------------------------------------------------------------ general convolution (ResNet plugin: model/resnet.py)
 GEN_CASES = [
     # B, Cin, Cout, H, W, k, stride, pad, residual, tile
