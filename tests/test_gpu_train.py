@@ -621,7 +621,7 @@ def test_multi_scale_training_steps_with_fused_adam_and_clip():
         data = {k: v.to(dev()) for k, v in synth.labels(2, S, 20, seed=7).items()}
         data['tensor'] = synth.images(2, S, seed=8).to(dev())
         r = y2train.iterate(inf, opt, data, oloss.HPARAM, 0.6, anchors, clip=5.0)
-        lt = float(r['loss_total'])
+        lt = float(r['loss_total'].detach())
         assert np.isfinite(lt), (it, S)
         seen.setdefault(S, []).append(lt)
     for S, ls in seen.items():
