@@ -131,7 +131,7 @@ def train_leg(args, dev, world, rank, barrier):
     out = {'metric': 'images/sec (%dx%d) train, %s YOLOv2 %d classes' % (S, S, 'Darknet-19' if args.model == 'darknet' else args.model, args.classes), 'value': round(B * args.train_steps * world / dt, 2), 'unit': 'images/sec',
            'ms_per_step': round(dt / args.train_steps * 1e3, 3), 'steps': args.train_steps, 'per_gpu_batch': B, 'global_batch': B * world,
            'parallelism': 'dp%d (RCCL all-reduce, bucketed, overlapped with backward)' % world if world > 1 else 'single GPU',
-           'optimizer': 'utils.optim.SGD(lr=1e-3, momentum=0.9): fused multi-tensor HIP kernel, torch.optim.SGD semantics', 'loss_total': float(r['loss_total']),
+           'optimizer': 'utils.optim.SGD(lr=1e-3, momentum=0.9): fused multi-tensor HIP kernel, torch.optim.SGD semantics', 'loss_total': float(r['loss_total'].detach()),
            'conv_tflops': round(flops / dt / 1e12 / world, 2), 'conv_frac_of_fp32_mfma_peak': round(flops / dt / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4)}
     del wrapped, opt, inf
     torch.cuda.empty_cache()
