@@ -197,6 +197,27 @@ int y2_iou_pair(const float* yx_min1, const float* yx_max1, const float* yx_min2
 int y2_nms(const float* score, const float* yx_min, const float* yx_max, const int32_t* cand, const int32_t* n, int B, int stride,
            float overlap, int limit, int32_t* order_ws, int32_t* keep, int32_t* keep_count, y2_stream_t stream);
 
+/* HOST-memory forms of the same algorithms (all pointers are HOST pointers, no stream, no HIP call: safe in a forked child).
+ * utils.postprocess.nms is called on CPU tensors by the reference's summary worker (train.py:209) and the utils.iou.torch unit
+ * tests run on CPU tensors (utils/iou/torch.py:64-113).  Same ordering rule (score descending, ties -> lower index, NaN last),
+ * same fp32 IoU operation sequence: keep lists and IoU values are bit-identical to the device entry points. */
+int y2_nms_host(const float* score, const float* yx_min, const float* yx_max, const int32_t* cand, const int32_t* n, int B, int stride,
+                float overlap, int limit, int32_t* keep, int32_t* keep_count);
+int y2_iou_matrix_host(const float* yx_min1, const float* yx_max1, const float* yx_min2, const float* yx_max2,
+                       int Bt, int N1, int N2, float min_union, int mode, float* out);
+int y2_iou_pair_host(const float* yx_min1, const float* yx_max1, const float* yx_min2, const float* yx_max2,
+                     int n, float min_union, float* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py, tools/): y2_prof_enable(1) clears the record table and starts bracketing EVERY kernel launch of
+ * this library with a HIP event pair on the launch stream; y2_prof_enable(0) stops.  Record i = (kernel name, milliseconds
+ * between its two events, multiply-add FLOPs the launch executes: 2*M*N*K of the GEMM it runs, 0 for non-GEMM kernels).
+ * y2_prof_get synchronises that record's end event.  Not for use during hipGraph capture.  Process-global tooling state
+ * (the only host state of the library besides per-device attribute caches); one process per GPU.
+ * ------------------------------------------------------------------------------------------------ */
+int y2_prof_enable(int on);
+int y2_prof_count(void);
+int y2_prof_get(int i, char* name, int name_cap, float* ms, double* flops);
 
 /* ------------------------------------------------------------------------------------------------
  * Training path.  The reference trains through torch autograd (train.py:344-357): conv / BN / LeakyReLU /

@@ -47,14 +47,24 @@ def test_conv_params_struct_layout():
     assert ctypes.sizeof(_hip.ConvParams) == 168
 
 
-def test_no_cpu_fallback():
-    import utils.iou.torch as iou
-    import utils.postprocess as post
-    a = torch.zeros(2, 2)
+def test_no_cpu_fallback_on_the_gpu_path():
+    """The convolution / decode / loss path refuses CPU tensors (only nms and the IoU helpers have host entry points, because
+    the reference calls those on CPU tensors: train.py:209, utils/iou/torch.py:64-113)."""
+    import configparser
+
+    import detect
+    import model
+    import model.yolo2
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1'}})
+    anchors = torch.ones(5, 2)
+    dnn = model.yolo2.Darknet(model.ConfigChannels(cfg), anchors, 20).eval()
     with pytest.raises(RuntimeError, match='no CPU fallback'):
-        iou.iou_matrix(a, a + 1, a, a + 1)
+        dnn(torch.zeros(1, 3, 32, 32))
     with pytest.raises(RuntimeError, match='no CPU fallback'):
-        post.nms(torch.ones(2), a, a + 1)
+        model.decode(torch.zeros(1, 1, 1, 125), anchors, 5)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        detect.filter_visible_batch(torch.zeros(1, 5), torch.zeros(1, 5), True, 0.005)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -82,6 +82,12 @@ SIGNATURES = {
     'y2_region_loss_fwd': [c_void_p] * 11 + [c_int] * 6 + [c_float] + [c_void_p] * 5 + [c_void_p],
     'y2_region_loss_finalize': [c_void_p, ctypes.c_double, c_int, c_void_p, c_void_p],
     'y2_region_loss_bwd': [c_void_p] * 9 + [c_int] * 6 + [c_float] + [c_void_p] * 5 + [c_void_p] * 4 + [c_void_p],
+    'y2_nms_host': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
+    'y2_iou_matrix_host': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p],
+    'y2_iou_pair_host': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p],
+    'y2_prof_enable': [c_int],
+    'y2_prof_count': [],
+    'y2_prof_get': [c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_float), ctypes.POINTER(ctypes.c_double)],
     'y2_nms': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
 }
 

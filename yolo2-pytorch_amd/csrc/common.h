@@ -24,6 +24,44 @@ __attribute__((visibility("hidden"))) int y2_internal_wgrad_grouped(const float*
                                                                      long long gx, long long gz, long long gw, y2_stream_t stream);
 __attribute__((visibility("hidden"))) int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need);
 
+// ---- per-device host-side caches (a process may touch several GPUs; symbol addresses and function attributes are per device)
+constexpr int Y2_MAX_DEVICES = 64;
+static inline int y2_current_device() {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= Y2_MAX_DEVICES) return -1;
+    return d;
+}
+// "this kernel may use the whole 160 KB LDS of a gfx950 CU", set once per (kernel instantiation, device)
+struct Y2LdsAttr {
+    bool done[Y2_MAX_DEVICES] = {};
+    int ensure(const void* kern) {
+        const int d = y2_current_device();
+        if (d < 0) return Y2_EINVAL;
+        if (!done[d]) {
+            const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return -(1000 + (int)e);
+            done[d] = true;
+        }
+        return 0;
+    }
+};
+
+// ---- measurement hooks (prof.hip; include/yolo2_hip.h: y2_prof_*): when recording is on, every kernel launch of the library is
+// bracketed by a HIP event pair on ITS launch stream and tagged with the multiply-add work it executes.
+__attribute__((visibility("hidden"))) extern int y2_prof_on;
+__attribute__((visibility("hidden"))) void y2_prof_begin(const char* name, hipStream_t s, double flops);
+__attribute__((visibility("hidden"))) void y2_prof_end(hipStream_t s);
+struct Y2ProfScope {
+    hipStream_t s; bool on;
+    Y2ProfScope(const char* name, hipStream_t s_, double flops) : s(s_), on(y2_prof_on != 0) { if (on) y2_prof_begin(name, s, flops); }
+    ~Y2ProfScope() { if (on) y2_prof_end(s); }
+};
+#define Y2_LAUNCH(NAME, FLOPS, KERN, GRID, BLOCK, LDS, STREAM, ...)              \
+    do {                                                                         \
+        Y2ProfScope y2_prof_scope_(NAME, STREAM, FLOPS);                         \
+        hipLaunchKernelGGL(KERN, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);         \
+    } while (0)
+
 constexpr int Y2_NUM_CU = 256;   // MI355X: 8 XCD x 32 CU
 constexpr int Y2_NUM_XCD = 8;
 

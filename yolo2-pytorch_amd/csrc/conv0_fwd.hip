@@ -157,8 +157,8 @@ template <int CIN>
 int launch0(const Conv0Args& a, hipStream_t s) {
     const long long grid = (long long)a.B * a.tiles_y * a.tiles_x;
     if (grid <= 0 || grid > 0x7fffffffLL) return Y2_EINVAL;
-    if (a.Cout <= 32) hipLaunchKernelGGL((conv0_kernel<CIN, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv0_kernel<CIN, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    if (a.Cout <= 32) Y2_LAUNCH("conv0_kernel", 2.0 * (double)a.B * a.H * a.W * 9 * CIN * a.Cout, (conv0_kernel<CIN, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else Y2_LAUNCH("conv0_kernel", 2.0 * (double)a.B * a.H * a.W * 9 * CIN * a.Cout, (conv0_kernel<CIN, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

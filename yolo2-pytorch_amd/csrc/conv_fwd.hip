@@ -665,15 +665,11 @@ int launch(const ConvArgs& a0, hipStream_t stream) {
     if (const char* pad = getenv("Y2_CONV_LDS_MIN")) { const size_t m = (size_t)atol(pad); if (lds < m) lds = m; }   // occupancy experiments only
     a.cchunks = y2_cdiv(a.Cin, BK);
     auto kern = conv_fwd_kernel<BM, BN, WAVES_M, BK, POOLORD, VEC, ABLATE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return -(1000 + (int)e);
-        attr_set = true;
-    }
+    static Y2LdsAttr attr_set;
+    if (const int rc = attr_set.ensure(reinterpret_cast<const void*>(kern))) return rc;
     const long long grid = (long long)a.tiles_m * a.tiles_n;
     if (grid <= 0 || grid > 0x7fffffffLL) return Y2_EINVAL;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
+    Y2_LAUNCH("conv_fwd_kernel", 2.0 * (double)a.M * a.Cout * (a.K > 0 ? a.K : a.taps * a.Cin) * (a.groups > 1 ? a.groups : 1), kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -718,18 +714,14 @@ int launch_dma(const ConvArgs& a0, hipStream_t stream, float* ws, size_t ws_byte
     plan_split(tiles, nk_all, (long long)BM * BN, ws != nullptr ? ws_bytes : 0, a.full_tiles, a.ksplit);
     a.partial = ws;
     const long long grid = a.full_tiles + (tiles - a.full_tiles) * a.ksplit;
-    static bool attr_set[4] = {false, false, false, false};
+    static Y2LdsAttr attr_set[4];
     static int stages3 = -1;
     if (stages3 < 0) { const char* e = getenv("Y2_CONV_STAGES"); stages3 = (e != nullptr && atoi(e) == 3) ? 1 : 0; }
 #define Y2_DMA_LAUNCH(KERN, SLOT, LDSB)                                                                                     \
     do {                                                                                                                    \
         auto kern = KERN;                                                                                                   \
-        if (!attr_set[SLOT]) {                                                                                              \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            if (e != hipSuccess) return -(1000 + (int)e);                                                                   \
-            attr_set[SLOT] = true;                                                                                          \
-        }                                                                                                                   \
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTH), LDSB, stream, a);                                         \
+        if (const int rc_ = attr_set[SLOT].ensure(reinterpret_cast<const void*>(kern))) return rc_;                        \
+        Y2_LAUNCH(a.groups > 1 ? "conv_fwd_dma_kernel[grouped]" : "conv_fwd_dma_kernel", 2.0 * (double)a.M * a.Cout * (a.K > 0 ? a.K : a.taps * a.Cin) * (a.groups > 1 ? a.groups : 1), kern, dim3((unsigned)grid), dim3(NTH), LDSB, stream, a);                                         \
     } while (0)
     if (GEN) Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, false, false, 2, true, NTH>), 3, lds);
     else if (stages3 && !ctail) Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, false, 3, false, NTH>), 2, lds / 2 * 3);
@@ -737,7 +729,7 @@ int launch_dma(const ConvArgs& a0, hipStream_t stream, float* ws, size_t ws_byte
     else Y2_DMA_LAUNCH((conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, false, 2, false, NTH>), 0, lds);
 #undef Y2_DMA_LAUNCH
     if (a.ksplit > 1)
-        hipLaunchKernelGGL((conv_splitk_fixup_kernel<BM, BN, WAVES_M, (POOLORD && !GEN), NTH>), dim3((unsigned)(tiles - a.full_tiles)), dim3(NTH), 0, stream, a);
+        Y2_LAUNCH("conv_splitk_fixup_kernel", 0.0, (conv_splitk_fixup_kernel<BM, BN, WAVES_M, (POOLORD && !GEN), NTH>), dim3((unsigned)(tiles - a.full_tiles)), dim3(NTH), 0, stream, a);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -966,14 +958,14 @@ int launch_wave(const ConvArgs& a0, hipStream_t stream, float* ws, size_t ws_byt
     do {                                                                                                                          \
         auto kern = conv_fwd_wave_kernel<POOLORD, ST, BKV>;                                                                       \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, stream, a);                                                 \
+        Y2_LAUNCH("conv_fwd_wave_kernel", 2.0 * (double)a.M * a.Cout * (a.K > 0 ? a.K : a.taps * a.Cin) * (a.groups > 1 ? a.groups : 1), kern, dim3((unsigned)grid), dim3(64), lds, stream, a);                                                 \
     } while (0)
     (void)attr;
     if (bk == 32) { if (stages == 2) Y2_WAVE(2, 32); else if (stages == 3) Y2_WAVE(3, 32); else Y2_WAVE(4, 32); }
     else { if (stages == 2) Y2_WAVE(2, 16); else if (stages == 3) Y2_WAVE(3, 16); else Y2_WAVE(4, 16); }
 #undef Y2_WAVE
     if (a.ksplit > 1)
-        hipLaunchKernelGGL((conv_splitk_fixup_kernel<64, 64, 1, POOLORD, 64>), dim3((unsigned)(tiles - a.full_tiles)), dim3(64), 0, stream, a);
+        Y2_LAUNCH("conv_splitk_fixup_kernel", 0.0, (conv_splitk_fixup_kernel<64, 64, 1, POOLORD, 64>), dim3((unsigned)(tiles - a.full_tiles)), dim3(64), 0, stream, a);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -1094,12 +1086,19 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
     a.res = p->residual; a.ldr = p->ldr;
     a.d_cin = y2_make_fastdiv((uint32_t)p->Cin); a.d_kw = y2_make_fastdiv((uint32_t)p->ksize);
     a.d_howo = y2_make_fastdiv((uint32_t)(Ho * Wo)); a.d_wo = y2_make_fastdiv((uint32_t)Wo);
-    static const float* zeros = nullptr;
-    if (zeros == nullptr && ws_need == nullptr) {
-        void* zp = nullptr;
-        hipError_t e = hipGetSymbolAddress(&zp, HIP_SYMBOL(y2_zero16_storage));
-        if (e != hipSuccess) return -(1000 + (int)e);
-        zeros = static_cast<const float*>(zp);
+    // per-DEVICE cache: a __device__ symbol has one address per GPU (a process may touch more than one device)
+    static const float* zeros_dev[Y2_MAX_DEVICES] = {};
+    const float* zeros = nullptr;
+    if (ws_need == nullptr) {
+        const int dev = y2_current_device();
+        if (dev < 0) return Y2_EINVAL;
+        zeros = zeros_dev[dev];
+        if (zeros == nullptr) {
+            void* zp = nullptr;
+            hipError_t e = hipGetSymbolAddress(&zp, HIP_SYMBOL(y2_zero16_storage));
+            if (e != hipSuccess) return -(1000 + (int)e);
+            zeros = zeros_dev[dev] = static_cast<const float*>(zp);
+        }
     }
     a.zeros = zeros;
 

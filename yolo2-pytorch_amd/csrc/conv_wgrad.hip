@@ -231,13 +231,9 @@ static int wgrad_impl(const float* x, const float* dz, float* dw, int B, int Hi,
     const size_t lds = 2u * (size_t)(KS * TI + KS * TJ) * sizeof(float);
 #define Y2_WGRAD_LAUNCH(TI_, WI_)                                                                                         \
     do {                                                                                                                  \
-        static bool attr = false;                                                                                         \
-        if (!attr) {                                                                                                      \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<TI_, WI_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            if (e != hipSuccess) return -(1000 + (int)e);                                                                 \
-            attr = true;                                                                                                  \
-        }                                                                                                                 \
-        hipLaunchKernelGGL((conv_wgrad_kernel<TI_, WI_>), dim3((unsigned)grid), dim3(NT), lds, s, a);                      \
+        static Y2LdsAttr attr;                                                                                            \
+        if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<TI_, WI_>))) return rc_;          \
+        Y2_LAUNCH(a.groups > 1 ? "conv_wgrad_kernel[grouped]" : "conv_wgrad_kernel", 2.0 * (double)a.M * a.Cout * a.taps * a.Cin * (a.groups > 1 ? a.groups : 1), (conv_wgrad_kernel<TI_, WI_>), dim3((unsigned)grid), dim3(NT), lds, s, a);                      \
     } while (0)
     if (TI == 32) Y2_WGRAD_LAUNCH(32, 1);
     else if (TI == 64) Y2_WGRAD_LAUNCH(64, 1);
@@ -329,8 +325,8 @@ extern "C" int y2_conv0_wgrad(const float* x_nchw, const float* dz, float* dw, i
     W0Args a;
     a.x = x_nchw; a.dz = dz; a.dw = dw; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldz = ldz; a.rows_total = B * H;
     const int grid = a.rows_total < 4 * 4 * Y2_NUM_CU ? y2_cdiv(a.rows_total, 4) : 4 * Y2_NUM_CU;
-    if (Cout <= 32) hipLaunchKernelGGL((conv0_wgrad_kernel<1>), dim3(grid), dim3(256), 0, y2_s(stream), a);
-    else hipLaunchKernelGGL((conv0_wgrad_kernel<2>), dim3(grid), dim3(256), 0, y2_s(stream), a);
+    if (Cout <= 32) Y2_LAUNCH("conv0_wgrad_kernel", 2.0 * (double)B * H * W * 9 * Cin * Cout, (conv0_wgrad_kernel<1>), dim3(grid), dim3(256), 0, y2_s(stream), a);
+    else Y2_LAUNCH("conv0_wgrad_kernel", 2.0 * (double)B * H * W * 9 * Cin * Cout, (conv0_wgrad_kernel<2>), dim3(grid), dim3(256), 0, y2_s(stream), a);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

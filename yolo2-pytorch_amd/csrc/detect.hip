@@ -161,6 +161,10 @@ __global__ void iou_pair_kernel(const float* __restrict__ mn1, const float* __re
 // Stage 1 — utils/postprocess.py:37-38 `score.sort(descending=True)[:limit]` without a sort: the rank of
 // candidate i is #{j : s_j > s_i or (s_j == s_i and j < i)} (ties -> lower index first, a total order), computed
 // by all threads against LDS-staged score tiles; candidates with rank < limit scatter themselves to order[rank].
+// A NaN score has no place in an ordering: it ranks as -inf (after every number; among themselves lower index first), so the
+// ranks stay a permutation of 0..n-1 and every order[] slot below min(n, limit) is written.
+__device__ __forceinline__ float nms_key(float s) { return s != s ? -__builtin_inff() : s; }
+
 __global__ __launch_bounds__(256) void nms_rank_kernel(const float* __restrict__ score, const int32_t* __restrict__ cand, const int32_t* __restrict__ n_per, int stride, int limit, int32_t* order) {
     __shared__ float tile[1024];
     const int b = blockIdx.y;
@@ -169,12 +173,12 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const float* __restrict__
     const float* s = score + (size_t)b * stride;
     const int32_t* cd = cand ? cand + (size_t)b * stride : nullptr;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const float si = i < n ? s[cd ? cd[i] : i] : 0.f;
+    const float si = i < n ? nms_key(s[cd ? cd[i] : i]) : 0.f;
     int rank = 0;
     for (int j0 = 0; j0 < n; j0 += 1024) {
         const int cnt = min(1024, n - j0);
         __syncthreads();
-        for (int j = threadIdx.x; j < cnt; j += 256) tile[j] = s[cd ? cd[j0 + j] : j0 + j];
+        for (int j = threadIdx.x; j < cnt; j += 256) tile[j] = nms_key(s[cd ? cd[j0 + j] : j0 + j]);
         __syncthreads();
         for (int j = 0; j < cnt; ++j) {
             const float sj = tile[j];
@@ -263,7 +267,7 @@ extern "C" int y2_decode(const float* feature, const float* anchors, int B, int 
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return -(1000 + (int)e);
     }
-    hipLaunchKernelGGL(decode_kernel, dim3(y2_cdiv(total, 64)), dim3(64), lds, y2_s(stream), a);
+    Y2_LAUNCH("decode_kernel", 0.0, decode_kernel, dim3(y2_cdiv(total, 64)), dim3(64), lds, y2_s(stream), a);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -275,12 +279,12 @@ extern "C" int y2_filter_visible(const float* iou, const float* prob, int B, int
     if (prob != nullptr) {
         if (!prob_cls || !cls || C < 1) return Y2_EINVAL;
         const long long rows = (long long)B * n;
-        hipLaunchKernelGGL(rowmax_kernel, dim3(y2_cdiv(rows, 4)), dim3(256), 0, y2_s(stream), prob, (int)rows, C, prob_cls, cls);
+        Y2_LAUNCH("rowmax_kernel", 0.0, rowmax_kernel, dim3(y2_cdiv(rows, 4)), dim3(256), 0, y2_s(stream), prob, (int)rows, C, prob_cls, cls);
         Y2_LAUNCH_CHECK();
     } else if (fix && !prob_cls) {
         return Y2_EINVAL;
     }
-    hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(256), 0, y2_s(stream), iou, prob_cls, n, fix, thr, count, index);
+    Y2_LAUNCH("compact_kernel", 0.0, compact_kernel, dim3(B), dim3(256), 0, y2_s(stream), iou, prob_cls, n, fix, thr, count, index);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -291,7 +295,7 @@ extern "C" int y2_iou_matrix(const float* yx_min1, const float* yx_max1, const f
     const long long total = (long long)Bt * N1 * N2;
     if (total == 0) return Y2_OK;
     if (!yx_min1 || !yx_max1 || !yx_min2 || !yx_max2 || !out) return Y2_EINVAL;
-    hipLaunchKernelGGL(iou_matrix_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), yx_min1, yx_max1, yx_min2, yx_max2, N1, N2, min_union, mode, out, total);
+    Y2_LAUNCH("iou_matrix_kernel", 0.0, iou_matrix_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), yx_min1, yx_max1, yx_min2, yx_max2, N1, N2, min_union, mode, out, total);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -301,7 +305,7 @@ extern "C" int y2_iou_pair(const float* yx_min1, const float* yx_max1, const flo
     if (n < 0) return Y2_EINVAL;
     if (n == 0) return Y2_OK;
     if (!yx_min1 || !yx_max1 || !yx_min2 || !yx_max2 || !out) return Y2_EINVAL;
-    hipLaunchKernelGGL(iou_pair_kernel, dim3(y2_cdiv(n, 256)), dim3(256), 0, y2_s(stream), yx_min1, yx_max1, yx_min2, yx_max2, n, min_union, out);
+    Y2_LAUNCH("iou_pair_kernel", 0.0, iou_pair_kernel, dim3(y2_cdiv(n, 256)), dim3(256), 0, y2_s(stream), yx_min1, yx_max1, yx_min2, yx_max2, n, min_union, out);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -311,17 +315,21 @@ extern "C" int y2_nms(const float* score, const float* yx_min, const float* yx_m
     if (!score || !yx_min || !yx_max || !n || !order_ws || !keep || !keep_count) return Y2_EINVAL;
     if (B <= 0 || stride <= 0 || limit <= 0 || limit > 1024) return Y2_EINVAL;
     hipStream_t s = y2_s(stream);
-    hipLaunchKernelGGL(nms_rank_kernel, dim3(y2_cdiv(stride, 256), B), dim3(256), 0, s, score, cand, n, stride, limit, order_ws);
+    Y2_LAUNCH("nms_rank_kernel", 0.0, nms_rank_kernel, dim3(y2_cdiv(stride, 256), B), dim3(256), 0, s, score, cand, n, stride, limit, order_ws);
     Y2_LAUNCH_CHECK();
     const int words = (limit + 63) / 64;
     const size_t lds = (((size_t)limit * 20 + 15) & ~(size_t)15) + (size_t)limit * words * 8;
-    static size_t attr_lds = 0;
-    if (lds > 64 * 1024 && lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(1000 + (int)e);
-        attr_lds = lds;
+    static size_t attr_lds[Y2_MAX_DEVICES] = {};       // high-water mark per device (function attributes are per device)
+    if (lds > 64 * 1024) {
+        const int dev = y2_current_device();
+        if (dev < 0) return Y2_EINVAL;
+        if (lds > attr_lds[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return -(1000 + (int)e);
+            attr_lds[dev] = lds;
+        }
     }
-    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(256), lds, s, yx_min, yx_max, cand, n, stride, overlap, limit, order_ws, keep, keep_count);
+    Y2_LAUNCH("nms_kernel", 0.0, nms_kernel, dim3(B), dim3(256), lds, s, yx_min, yx_max, cand, n, stride, overlap, limit, order_ws, keep, keep_count);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

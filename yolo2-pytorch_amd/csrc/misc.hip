@@ -132,7 +132,7 @@ extern "C" const char* y2_build_info(void) { return "libyolo2_hip gfx950 fp32-mf
 extern "C" int y2_pack_weight(const float* w, float* dst, int Cout, int Cin, int ksize, int mode, y2_stream_t stream) {
     if (w == nullptr || dst == nullptr || Cout <= 0 || Cin <= 0 || ksize <= 0 || (mode != 0 && mode != 1)) return Y2_EINVAL;
     const long long total = (long long)Cout * Cin * ksize * ksize;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), w, dst, Cout, Cin, ksize * ksize, mode, total);
+    Y2_LAUNCH("pack_weight_kernel", 0.0, pack_weight_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), w, dst, Cout, Cin, ksize * ksize, mode, total);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -140,7 +140,7 @@ extern "C" int y2_pack_weight(const float* w, float* dst, int Cout, int Cin, int
 extern "C" int y2_unpack_weight_grad(const float* src, float* dst, int Cout, int Cin, int ksize, y2_stream_t stream) {
     if (src == nullptr || dst == nullptr || Cout <= 0 || Cin <= 0 || ksize <= 0) return Y2_EINVAL;
     const long long total = (long long)Cout * Cin * ksize * ksize;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), src, dst, Cout, Cin, ksize * ksize, 2, total);
+    Y2_LAUNCH("pack_weight_kernel", 0.0, pack_weight_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), src, dst, Cout, Cin, ksize * ksize, 2, total);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -148,7 +148,7 @@ extern "C" int y2_unpack_weight_grad(const float* src, float* dst, int Cout, int
 extern "C" int y2_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                           float* scale, float* shift, int C, y2_stream_t stream) {
     if (!gamma || !beta || !mean || !var || !scale || !shift || C <= 0) return Y2_EINVAL;
-    hipLaunchKernelGGL(bn_fold_kernel, dim3(y2_cdiv(C, 256)), dim3(256), 0, y2_s(stream), gamma, beta, mean, var, eps, scale, shift, C);
+    Y2_LAUNCH("bn_fold_kernel", 0.0, bn_fold_kernel, dim3(y2_cdiv(C, 256)), dim3(256), 0, y2_s(stream), gamma, beta, mean, var, eps, scale, shift, C);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -158,12 +158,12 @@ extern "C" int y2_maxpool2_fwd(const float* x, float* y, int B, int H, int W, in
     if ((H & 1) || (W & 1) || ldx < C || ldy < C) return Y2_EINVAL;
     if ((C & 3) || (ldx & 3) || (ldy & 3) || !y2_aligned16(x) || !y2_aligned16(y)) {
         const long long tot = (long long)B * (H / 2) * (W / 2) * C;
-        hipLaunchKernelGGL(maxpool2_scalar_kernel, dim3(stream_grid(tot, 256)), dim3(256), 0, y2_s(stream), x, y, H / 2, W / 2, C, ldx, ldy, tot);
+        Y2_LAUNCH("maxpool2_scalar_kernel", 0.0, maxpool2_scalar_kernel, dim3(stream_grid(tot, 256)), dim3(256), 0, y2_s(stream), x, y, H / 2, W / 2, C, ldx, ldy, tot);
         Y2_LAUNCH_CHECK();
         return Y2_OK;
     }
     const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool2_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, y, H / 2, W / 2, C / 4, ldx, ldy, total);
+    Y2_LAUNCH("maxpool2_kernel", 0.0, maxpool2_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, y, H / 2, W / 2, C / 4, ldx, ldy, total);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -174,8 +174,8 @@ extern "C" int y2_maxpool_fwd(const float* x, float* y, int B, int H, int W, int
     if (Ho <= 0 || Wo <= 0) return Y2_EINVAL;
     const bool vec = !(C & 3) && !(ldx & 3) && !(ldy & 3) && y2_aligned16(x) && y2_aligned16(y);
     const long long total = (long long)B * Ho * Wo * (vec ? C / 4 : C);
-    if (vec) hipLaunchKernelGGL((maxpool_gen_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, y, H, W, Ho, Wo, C, ldx, ldy, ksize, stride, pad, total);
-    else hipLaunchKernelGGL((maxpool_gen_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, y, H, W, Ho, Wo, C, ldx, ldy, ksize, stride, pad, total);
+    if (vec) Y2_LAUNCH("maxpool_gen_kernel", 0.0, (maxpool_gen_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, y, H, W, Ho, Wo, C, ldx, ldy, ksize, stride, pad, total);
+    else Y2_LAUNCH("maxpool_gen_kernel", 0.0, (maxpool_gen_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, y, H, W, Ho, Wo, C, ldx, ldy, ksize, stride, pad, total);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -183,7 +183,7 @@ extern "C" int y2_maxpool_fwd(const float* x, float* y, int B, int H, int W, int
 extern "C" int y2_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int ld, y2_stream_t stream) {
     if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ld < C) return Y2_EINVAL;
     const long long total = (long long)B * H * W * ld;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, y, C, H * W, ld, total);
+    Y2_LAUNCH("nchw_to_nhwc_kernel", 0.0, nchw_to_nhwc_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, y, C, H * W, ld, total);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

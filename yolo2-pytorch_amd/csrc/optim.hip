@@ -204,7 +204,7 @@ extern "C" int y2_opt_sgd(const y2_opt_tensor* tensors, int32_t count, float lr,
     if (momentum == 0.f)
         for (int i = 0; i < Y2_OPT_MAX_TENSORS; ++i) tb.m[i] = nullptr;
     SgdHyper h = {lr, momentum, dampening, weight_decay, nesterov, first_step};
-    hipLaunchKernelGGL(opt_sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, y2_s(stream), tb, h);
+    Y2_LAUNCH("opt_sgd_kernel", 0.0, opt_sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, y2_s(stream), tb, h);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -219,7 +219,7 @@ extern "C" int y2_opt_adam(const y2_opt_tensor* tensors, int32_t count, float lr
     // bias corrections in double on the host, as torch.optim.Adam does with Python floats
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     AdamHyper h = {lr, beta1, beta2, eps, weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2)};
-    hipLaunchKernelGGL(opt_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, y2_s(stream), tb, h);
+    Y2_LAUNCH("opt_adam_kernel", 0.0, opt_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, y2_s(stream), tb, h);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -230,7 +230,7 @@ extern "C" int y2_opt_grad_sumsq(const y2_opt_tensor* tensors, int32_t count, do
     long long blocks;
     const int rc = fill_table(tb, tensors, count, false, false, blocks);
     if (rc != Y2_OK) return rc;
-    hipLaunchKernelGGL(opt_sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, y2_s(stream), tb, sumsq);
+    Y2_LAUNCH("opt_sumsq_kernel", 0.0, opt_sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, y2_s(stream), tb, sumsq);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -241,7 +241,7 @@ extern "C" int y2_opt_clip_grads(const y2_opt_tensor* tensors, int32_t count, co
     long long blocks;
     const int rc = fill_table(tb, tensors, count, false, false, blocks);
     if (rc != Y2_OK) return rc;
-    hipLaunchKernelGGL(opt_clip_kernel, dim3((unsigned)blocks), dim3(256), 0, y2_s(stream), tb, sumsq, max_norm);
+    Y2_LAUNCH("opt_clip_kernel", 0.0, opt_clip_kernel, dim3((unsigned)blocks), dim3(256), 0, y2_s(stream), tb, sumsq, max_norm);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

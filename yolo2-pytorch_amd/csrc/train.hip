@@ -561,7 +561,7 @@ extern "C" int y2_bn_finalize(const double* stats, double count, const float* ga
                               float* running_mean, float* running_var, float momentum, float eps,
                               float* scale, float* shift, float* mean, float* invstd, int C, y2_stream_t stream) {
     if (!stats || !gamma || !beta || !scale || !shift || !mean || !invstd || C <= 0 || count <= 0) return Y2_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(y2_cdiv(C, 256)), dim3(256), 0, y2_s(stream), stats, count, gamma, beta, running_mean, running_var,
+    Y2_LAUNCH("bn_finalize_kernel", 0.0, bn_finalize_kernel, dim3(y2_cdiv(C, 256)), dim3(256), 0, y2_s(stream), stats, count, gamma, beta, running_mean, running_var,
                        momentum, eps, scale, shift, mean, invstd, C);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
@@ -584,8 +584,8 @@ extern "C" int y2_bn_act_fwd_ex(const float* z, const float* scale, const float*
     const int grid = act_grid(total, vec ? C / 4 : C);
     a.d_wo = y2_make_fastdiv((uint32_t)(pool ? W / 2 : W)); a.d_ho = y2_make_fastdiv((uint32_t)(pool ? H / 2 : H));
     hipStream_t s = y2_s(stream);
-    if (pool) { if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<true, 4>), dim3(grid), dim3(256), 0, s, a, total); else hipLaunchKernelGGL((bn_act_fwd_kernel<true, 1>), dim3(grid), dim3(256), 0, s, a, total); }
-    else { if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<false, 4>), dim3(grid), dim3(256), 0, s, a, total); else hipLaunchKernelGGL((bn_act_fwd_kernel<false, 1>), dim3(grid), dim3(256), 0, s, a, total); }
+    if (pool) { if (vec) Y2_LAUNCH("bn_act_fwd_kernel", 0.0, (bn_act_fwd_kernel<true, 4>), dim3(grid), dim3(256), 0, s, a, total); else Y2_LAUNCH("bn_act_fwd_kernel", 0.0, (bn_act_fwd_kernel<true, 1>), dim3(grid), dim3(256), 0, s, a, total); }
+    else { if (vec) Y2_LAUNCH("bn_act_fwd_kernel", 0.0, (bn_act_fwd_kernel<false, 4>), dim3(grid), dim3(256), 0, s, a, total); else Y2_LAUNCH("bn_act_fwd_kernel", 0.0, (bn_act_fwd_kernel<false, 1>), dim3(grid), dim3(256), 0, s, a, total); }
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -617,8 +617,8 @@ extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float*
     hipStream_t s = y2_s(stream);
 #define Y2_BWD(POOL, CV)                                                                                             \
     do {                                                                                                             \
-        hipLaunchKernelGGL((bn_act_bwd_kernel<POOL, CV, false>), dim3(grid), dim3(256), lds, s, a, total);            \
-        hipLaunchKernelGGL((bn_act_bwd_kernel<POOL, CV, true>), dim3(grid), dim3(256), 0, s, a, total);               \
+        Y2_LAUNCH("bn_act_bwd_kernel", 0.0, (bn_act_bwd_kernel<POOL, CV, false>), dim3(grid), dim3(256), lds, s, a, total);            \
+        Y2_LAUNCH("bn_act_bwd_kernel", 0.0, (bn_act_bwd_kernel<POOL, CV, true>), dim3(grid), dim3(256), 0, s, a, total);               \
     } while (0)
     if (pool) { if (vec) Y2_BWD(true, 4); else Y2_BWD(true, 1); }
     else { if (vec) Y2_BWD(false, 4); else Y2_BWD(false, 1); }
@@ -650,14 +650,14 @@ extern "C" int y2_colsum(const float* x, long long M, int C, int ld, double* out
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     const int grid = (int)(((want + unit - 1) / unit) * unit);
-    hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), (size_t)C * sizeof(float), y2_s(stream), x, M, C, ld, out);
+    Y2_LAUNCH("colsum_kernel", 0.0, colsum_kernel, dim3(grid), dim3(256), (size_t)C * sizeof(float), y2_s(stream), x, M, C, ld, out);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
 
 extern "C" int y2_f64_to_f32(const double* src, float* dst, int n, double mul, y2_stream_t stream) {
     if (!src || !dst || n <= 0) return Y2_EINVAL;
-    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(y2_cdiv(n, 256)), dim3(256), 0, y2_s(stream), src, dst, n, mul);
+    Y2_LAUNCH("f64_to_f32_kernel", 0.0, f64_to_f32_kernel, dim3(y2_cdiv(n, 256)), dim3(256), 0, y2_s(stream), src, dst, n, mul);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -666,7 +666,7 @@ extern "C" int y2_decode_bwd(const float* iou, const float* center_offset, const
                              const float* d_logits, float* d_feature, int boxes, int C, y2_stream_t stream) {
     if (!iou || !center_offset || !d_feature || boxes <= 0 || C < 0) return Y2_EINVAL;
     const long long total = (long long)boxes * (5 + C);
-    hipLaunchKernelGGL(decode_bwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), iou, center_offset, d_iou, d_center_offset, d_size_norm, d_logits,
+    Y2_LAUNCH("decode_bwd_kernel", 0.0, decode_bwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), iou, center_offset, d_iou, d_center_offset, d_size_norm, d_logits,
                        d_feature, boxes, C);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
@@ -687,14 +687,14 @@ extern "C" int y2_region_loss_fwd(const float* iou, const float* center_offset, 
     if (e != hipSuccess) return -(1000 + (int)e);
     e = hipMemsetAsync(sums, 0, 6 * sizeof(double), s);
     if (e != hipSuccess) return -(1000 + (int)e);
-    hipLaunchKernelGGL(loss_match_kernel, dim3(y2_cdiv(n, 256), B), dim3(256), 0, s, yx_min, yx_max, gt_yx_min, gt_yx_max, n, N, best_iou, best_idx);
-    hipLaunchKernelGGL(loss_positive_kernel, dim3(y2_cdiv((long long)B * N, 256)), dim3(256), 0, s, gt_yx_min, gt_yx_max, anchors, B, N, rows, cols, A, positive);
+    Y2_LAUNCH("loss_match_kernel", 0.0, loss_match_kernel, dim3(y2_cdiv(n, 256), B), dim3(256), 0, s, yx_min, yx_max, gt_yx_min, gt_yx_max, n, N, best_iou, best_idx);
+    Y2_LAUNCH("loss_positive_kernel", 0.0, loss_positive_kernel, dim3(y2_cdiv((long long)B * N, 256)), dim3(256), 0, s, gt_yx_min, gt_yx_max, anchors, B, N, rows, cols, A, positive);
     LossArgs a;
     a.iou = iou; a.co = center_offset; a.sn = size_norm; a.logits = logits; a.best_iou = best_iou; a.best_idx = best_idx; a.positive = positive;
     a.gt_min = gt_yx_min; a.gt_max = gt_yx_max; a.gt_cls = gt_cls; a.gt_onehot = gt_onehot; a.anchors = anchors;
     a.B = B; a.n = n; a.N = N; a.A = A; a.C = C; a.threshold = threshold;
-    hipLaunchKernelGGL(loss_fwd_kernel, dim3(y2_cdiv(n, 256), B), dim3(256), 0, s, a, sums);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, sums, (double)B * n, gt_cls != nullptr ? 1 : 0, loss_out);
+    Y2_LAUNCH("loss_fwd_kernel", 0.0, loss_fwd_kernel, dim3(y2_cdiv(n, 256), B), dim3(256), 0, s, a, sums);
+    Y2_LAUNCH("loss_finalize_kernel", 0.0, loss_finalize_kernel, dim3(1), dim3(64), 0, s, sums, (double)B * n, gt_cls != nullptr ? 1 : 0, loss_out);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -711,7 +711,7 @@ extern "C" int y2_region_loss_bwd(const float* iou, const float* center_offset, 
     a.iou = iou; a.co = center_offset; a.sn = size_norm; a.logits = logits; a.best_iou = best_iou; a.best_idx = best_idx; a.positive = positive;
     a.gt_min = gt_yx_min; a.gt_max = gt_yx_max; a.gt_cls = gt_cls; a.gt_onehot = gt_onehot; a.anchors = anchors;
     a.B = B; a.n = n; a.N = N; a.A = A; a.C = C; a.threshold = threshold;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(y2_cdiv(n, 256), B), dim3(256), 0, y2_s(stream), a, sums, (double)B * n, weights, d_iou, d_center_offset, d_size_norm, d_logits);
+    Y2_LAUNCH("loss_bwd_kernel", 0.0, loss_bwd_kernel, dim3(y2_cdiv(n, 256), B), dim3(256), 0, y2_s(stream), a, sums, (double)B * n, weights, d_iou, d_center_offset, d_size_norm, d_logits);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -719,7 +719,7 @@ extern "C" int y2_region_loss_bwd(const float* iou, const float* center_offset, 
 // Re-run the finalisation after the number of positives (sums[5]) has been all-reduced across data-parallel ranks.
 extern "C" int y2_region_loss_finalize(const double* sums, double cnt, int cross_entropy, float* loss_out, y2_stream_t stream) {
     if (!sums || !loss_out || cnt <= 0) return Y2_EINVAL;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, y2_s(stream), sums, cnt, cross_entropy, loss_out);
+    Y2_LAUNCH("loss_finalize_kernel", 0.0, loss_finalize_kernel, dim3(1), dim3(64), 0, y2_s(stream), sums, cnt, cross_entropy, loss_out);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -730,7 +730,7 @@ extern "C" int y2_maxpool_bwd(const float* x, const float* dy, const float* dy2,
     const int Ho = (H + pad + pad_end - ksize) / stride + 1, Wo = (W + pad + pad_end - ksize) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return Y2_EINVAL;
     const long long total = (long long)B * H * W * C;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, dy, dy2, dx, H, W, Ho, Wo, C, ldx, ldy, lddx, ksize, stride, pad, total);
+    Y2_LAUNCH("maxpool_bwd_kernel", 0.0, maxpool_bwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, dy, dy2, dx, H, W, Ho, Wo, C, ldx, ldy, lddx, ksize, stride, pad, total);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

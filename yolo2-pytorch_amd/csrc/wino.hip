@@ -530,7 +530,7 @@ inline size_t wino_chunk_bytes() {
 extern "C" int y2_wino_weight(const float* w_packed, float* u, int32_t Cout, int32_t Cin, y2_stream_t stream) {
     if (w_packed == nullptr || u == nullptr || Cout <= 0 || Cin <= 0) return Y2_EINVAL;
     const long long n = (long long)Cout * Cin;
-    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)y2_cdiv(n, 256)), dim3(256), 0, y2_s(stream), w_packed, u, Cout, Cin);
+    Y2_LAUNCH("wino_weight_kernel", 0.0, wino_weight_kernel, dim3((unsigned)y2_cdiv(n, 256)), dim3(256), 0, y2_s(stream), w_packed, u, Cout, Cin);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -599,7 +599,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
         ia.x = p->x + in_off * p->ldx; ia.v = V; ia.B = nb; ia.H = p->H; ia.W = p->W; ia.Cin = p->Cin; ia.ldx = p->ldx; ia.th = th; ia.tw = tw;
         ia.T = (int)Tc; ia.c4n = p->Cin / 4;
         ia.d_c4 = y2_make_fastdiv((uint32_t)ia.c4n); ia.d_tt = d_tt; ia.d_tw = d_tw;
-        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)y2_cdiv(Tc * ia.c4n, 256)), dim3(256), 0, s, ia);
+        Y2_LAUNCH("wino_input_kernel", 0.0, wino_input_kernel, dim3((unsigned)y2_cdiv(Tc * ia.c4n, 256)), dim3(256), 0, s, ia);
 
         if (fused) {
             WinoFusedArgs fa;
@@ -617,13 +617,9 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
             do {                                                                                                                   \
                 auto kern = wino_fused_kernel<PG_, NST_>;                                                                          \
                 const size_t lds = (size_t)NST_ * PG_ * WF_POS_FLOATS * sizeof(float);                                             \
-                static bool attr = false;                                                                                          \
-                if (!attr) {                                                                                                       \
-                    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                    if (e != hipSuccess) return -(1000 + (int)e);                                                                  \
-                    attr = true;                                                                                                   \
-                }                                                                                                                  \
-                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, fa);                                             \
+                static Y2LdsAttr attr;                                                                                             \
+                if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(kern))) return rc_;                                  \
+                Y2_LAUNCH("wino_fused_kernel", 2.0 * 16.0 * (double)fa.T * fa.Cout * fa.Cin, kern, dim3((unsigned)grid), dim3(256), lds, s, fa);                                             \
             } while (0)
             // measured on the 52x52 / 26x26 / 13x13 layers (B=32): 4 positions per stage + 2-deep ring (64 MFMAs per wave between
             // barriers) 0.341 / 0.283 / 0.330 ms; 2 positions x 4-deep 0.357 / 0.289 / 0.336; 1 position x 6-deep 0.373 / 0.315 / 0.369
@@ -650,8 +646,8 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
         const int ny = 256 / nx;
         oa.loop = p->stats != nullptr ? 8 : 1;
         const dim3 grid((unsigned)y2_cdiv(Tc, (long long)ny * oa.loop), (unsigned)y2_cdiv(oa.n4n, nx));
-        if (p->stats != nullptr) hipLaunchKernelGGL(wino_output_kernel<true>, grid, dim3(nx, ny), 0, s, oa);
-        else hipLaunchKernelGGL(wino_output_kernel<false>, grid, dim3(nx, ny), 0, s, oa);
+        if (p->stats != nullptr) Y2_LAUNCH("wino_output_kernel", 0.0, wino_output_kernel<true>, grid, dim3(nx, ny), 0, s, oa);
+        else Y2_LAUNCH("wino_output_kernel", 0.0, wino_output_kernel<false>, grid, dim3(nx, ny), 0, s, oa);
     }
     Y2_LAUNCH_CHECK();
     return Y2_OK;
@@ -686,18 +682,18 @@ extern "C" int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, 
     WinoInArgs ia;
     ia.x = x; ia.v = V; ia.B = B; ia.H = H; ia.W = W; ia.Cin = Cin; ia.ldx = ldx; ia.th = th; ia.tw = tw; ia.T = (int)T; ia.c4n = Cin / 4;
     ia.d_c4 = y2_make_fastdiv((uint32_t)ia.c4n); ia.d_tt = y2_make_fastdiv((uint32_t)(th * tw)); ia.d_tw = y2_make_fastdiv((uint32_t)tw);
-    if (v_transformed == nullptr) hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)y2_cdiv(T * ia.c4n, 256)), dim3(256), 0, s, ia);
+    if (v_transformed == nullptr) Y2_LAUNCH("wino_input_kernel", 0.0, wino_input_kernel, dim3((unsigned)y2_cdiv(T * ia.c4n, 256)), dim3(256), 0, s, ia);
     const float* Vsrc = v_transformed != nullptr ? v_transformed : V;
 
     WinoDzArgs za;
     za.dz = dz; za.dm = DM; za.B = B; za.H = H; za.W = W; za.Cout = Cout; za.ldz = ldz; za.th = th; za.tw = tw; za.T = (int)T; za.c4n = Cout / 4;
     za.d_c4 = y2_make_fastdiv((uint32_t)za.c4n); za.d_tt = ia.d_tt; za.d_tw = ia.d_tw;
-    hipLaunchKernelGGL(wino_dz_kernel, dim3((unsigned)y2_cdiv(T * za.c4n, 256)), dim3(256), 0, s, za);
+    Y2_LAUNCH("wino_dz_kernel", 0.0, wino_dz_kernel, dim3((unsigned)y2_cdiv(T * za.c4n, 256)), dim3(256), 0, s, za);
 
     const int rc = y2_internal_wgrad_grouped(Vsrc, DM, DU, T, Cin, Cout, 16, T * Cin, T * Cout, (long long)Cout * Cin, stream);
     if (rc != Y2_OK) return rc;
     const long long n = (long long)Cout * Cin;
-    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)y2_cdiv(n, 256)), dim3(256), 0, s, DU, dw_packed, Cout, Cin);
+    Y2_LAUNCH("wino_dw_kernel", 0.0, wino_dw_kernel, dim3((unsigned)y2_cdiv(n, 256)), dim3(256), 0, s, DU, dw_packed, Cout, Cin);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

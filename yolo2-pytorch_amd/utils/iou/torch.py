@@ -2,6 +2,7 @@
 
 Same function names and argument meaning as the reference; the arithmetic runs in y2_iou_matrix / y2_iou_pair
 (one fused kernel, no `repeat`-materialised temporaries) and is bit-identical to the reference's fp32 sequence.
+CPU tensors (the reference's unit tests run on them) go to the library's host entry points y2_iou_*_host.
 """
 import numpy as np
 import torch
@@ -11,15 +12,26 @@ import _hip
 EPS = float(np.finfo(np.float32).eps)
 
 
+def _host(ts):
+    return [t.detach().to(torch.float32).contiguous() for t in ts]
+
+
 def _run(yx_min1, yx_max1, yx_min2, yx_max2, batched, min, mode):
-    _hip.require_gpu(yx_min1, yx_max1, yx_min2, yx_max2)
-    a1, b1, a2, b2 = (_hip.f32c(t) for t in (yx_min1, yx_max1, yx_min2, yx_max2))
+    cpu = not yx_min1.is_cuda
+    if cpu:      # CPU tensors (the reference's own unit tests, utils/iou/torch.py:64-113): the library's host implementation
+        a1, b1, a2, b2 = _host((yx_min1, yx_max1, yx_min2, yx_max2))
+    else:
+        _hip.require_gpu(yx_min1, yx_max1, yx_min2, yx_max2)
+        a1, b1, a2, b2 = (_hip.f32c(t) for t in (yx_min1, yx_max1, yx_min2, yx_max2))
     if batched:
         Bt, N1, N2 = a1.size(0), a1.size(1), a2.size(1)
         out = torch.empty(Bt, N1, N2, dtype=torch.float32, device=a1.device)
     else:
         Bt, N1, N2 = 1, a1.size(0), a2.size(0)
         out = torch.empty(N1, N2, dtype=torch.float32, device=a1.device)
+    if cpu:
+        _hip.check(_hip.lib().y2_iou_matrix_host(a1.data_ptr(), b1.data_ptr(), a2.data_ptr(), b2.data_ptr(), Bt, N1, N2, min, mode, out.data_ptr()), 'y2_iou_matrix_host')
+        return out
     _hip.check(_hip.lib().y2_iou_matrix(_hip.ptr(a1), _hip.ptr(b1), _hip.ptr(a2), _hip.ptr(b2), Bt, N1, N2, min, mode,
                                         _hip.ptr(out), _hip.stream()), 'y2_iou_matrix')
     return out
@@ -42,6 +54,11 @@ def batch_iou_matrix(yx_min1, yx_max1, yx_min2, yx_max2, min=EPS):
 
 
 def batch_iou_pair(yx_min1, yx_max1, yx_min2, yx_max2, min=EPS):
+    if not yx_min1.is_cuda:
+        a1, b1, a2, b2 = _host((yx_min1, yx_max1, yx_min2, yx_max2))
+        out = torch.empty(a1.shape[:-1], dtype=torch.float32)
+        _hip.check(_hip.lib().y2_iou_pair_host(a1.data_ptr(), b1.data_ptr(), a2.data_ptr(), b2.data_ptr(), out.numel(), min, out.data_ptr()), 'y2_iou_pair_host')
+        return out
     _hip.require_gpu(yx_min1, yx_max1, yx_min2, yx_max2)
     a1, b1, a2, b2 = (_hip.f32c(t) for t in (yx_min1, yx_max1, yx_min2, yx_max2))
     out = torch.empty(a1.shape[:-1], dtype=torch.float32, device=a1.device)

@@ -1,6 +1,7 @@
 """`utils.postprocess` — greedy NMS, MI355X-native (utils/postprocess.py:23-49).
 
-`nms` keeps the reference signature and returns a Python list of indices (descending score).  `nms_batch` is
+`nms` keeps the reference signature and returns a Python list of indices (descending score); it accepts GPU tensors
+(y2_nms) and CPU tensors (y2_nms_host: the reference's summary worker calls it on CPU tensors, train.py:209).  `nms_batch` is
 the device-resident form used by detect.postprocess_batch: all images of a batch in one launch pair, no host
 round trip.
 """
@@ -26,11 +27,26 @@ def nms_batch(score, yx_min, yx_max, n, overlap=0.5, limit=200, cand=None):
     return keep, cnt
 
 
+def _nms_host(score, yx_min, yx_max, overlap, limit):
+    """CPU tensors (the reference's summary worker, train.py:209): y2_nms_host, the library's host implementation of the same
+    rank + greedy algorithm as the device kernels (bit-identical keep lists; no HIP call, safe in a forked child)."""
+    score, yx_min, yx_max = (t.detach().to(torch.float32).contiguous() for t in (score.reshape(-1), yx_min.reshape(-1, 2), yx_max.reshape(-1, 2)))
+    n = torch.tensor([score.numel()], dtype=torch.int32)
+    keep = torch.empty(limit, dtype=torch.int32)
+    cnt = torch.empty(1, dtype=torch.int32)
+    _hip.check(_hip.lib().y2_nms_host(score.data_ptr(), yx_min.data_ptr(), yx_max.data_ptr(), None, n.data_ptr(), 1, score.numel(), overlap, limit,
+                                      keep.data_ptr(), cnt.data_ptr()), 'y2_nms_host')
+    return keep[:int(cnt[0])].tolist()
+
+
 def nms(score, yx_min, yx_max, overlap=0.5, limit=200):
-    """utils/postprocess.py:23-49: indices of the selected boxes, in descending-score order."""
+    """utils/postprocess.py:23-49: indices of the selected boxes, in descending-score order.  GPU tensors run y2_nms, CPU
+    tensors y2_nms_host (same library, same algorithm)."""
     keep = []
     if score.numel() == 0:
         return keep
+    if not score.is_cuda:
+        return _nms_host(score, yx_min, yx_max, overlap, limit)
     n = torch.tensor([score.numel()], dtype=torch.int32, device=score.device)
     k, c = nms_batch(score.reshape(1, -1), yx_min.reshape(1, -1, 2), yx_max.reshape(1, -1, 2), n, overlap, limit)
     return k[0, :int(c.item())].tolist()
