@@ -91,6 +91,89 @@ def worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
+class Gated(nn.Module):
+    """Two branches + one parameter nobody uses: which branch runs is decided per call (per rank in the test)."""
+
+    def __init__(self):
+        nn.Module.__init__(self)
+        self.a, self.b, self.unused = nn.Linear(4, 4), nn.Linear(4, 4), nn.Linear(4, 4)
+        self.out = nn.Linear(4, 2)
+
+    def forward(self, x, use_b):
+        h = self.a(x)
+        if use_b:
+            h = h + self.b(x)
+        return self.out(torch.tanh(h))
+
+
+def uneven_worker(rank, world, port, tmp):
+    """Robustness of the bucket protocol: a parameter that only ONE rank produced a gradient for, a parameter nobody used, and a
+    backward that raised half-way must neither desynchronise the collectives nor poison the next step."""
+    for p in (ROOT, APP):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import train
+    train.init_distributed()
+    torch.manual_seed(3)
+    m = Gated()
+    dp = train.DataParallelRCCL(m, bucket_bytes=64)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 4, generator=g)
+    # (1) `b` runs on rank 1 only
+    dp(x[rank * 2:rank * 2 + 2], use_b=(rank == 1)).pow(2).sum().backward()
+    ref = Gated()
+    ref.load_state_dict(m.state_dict())
+    l0 = ref(x[0:2], False).pow(2).sum()
+    l1 = ref(x[2:4], True).pow(2).sum()
+    ((l0 + l1) / 2).backward()
+    for (n, a), b in zip(m.named_parameters(), ref.parameters()):
+        if n.startswith('unused'):
+            assert a.grad is None, n                     # nobody produced a gradient: stays None on every rank
+        else:
+            assert a.grad is not None, (n, rank)         # rank 0 receives b's averaged gradient although it never ran b
+            assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6), (n, rank)
+    # (2) a backward that raises leaves no stale state behind
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, gr):
+            raise RuntimeError('boom')
+    for q in m.parameters():
+        q.grad = None
+    try:
+        Boom.apply(dp(x[rank * 2:rank * 2 + 2], use_b=False)).sum().backward()
+        raised = False
+    except RuntimeError:
+        raised = True
+    assert raised
+    for q in m.parameters():
+        q.grad = None
+    dp(x[rank * 2:rank * 2 + 2], use_b=False).pow(2).sum().backward()
+    for q in ref.parameters():
+        q.grad = None
+    ((ref(x[0:2], False).pow(2).sum() + ref(x[2:4], False).pow(2).sum()) / 2).backward()
+    for (n, a), b in zip(m.named_parameters(), ref.parameters()):
+        if n.startswith('unused') or n.startswith('b.'):
+            assert a.grad is None, n
+        else:
+            assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6), (n, rank)
+    if rank == 0:
+        open(os.path.join(tmp, 'ok'), 'w').write('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_dp_uneven_gradients_and_failed_backward_gloo_world2(tmp_path):
+    port = free_port()
+    mp.spawn(uneven_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / 'ok').exists()
+
+
 @pytest.mark.timeout(180)
 def test_dp_wrapper_gloo_world2(tmp_path):
     port = free_port()

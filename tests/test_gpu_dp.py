@@ -60,3 +60,169 @@ def test_dp_wrapper_rccl_world1_equals_plain_backward():
             assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-9, k
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ world_size 2 on the real path
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+DP_S, DP_B, DP_LABEL_SEED = 96, 4, 2
+
+
+def _dp_inputs():
+    widths = dict(NARROW)
+    widths['layers1.5'] = 8
+    sd = odark.init_state_dict(5, 20, seed=0, channels=widths, head_scale=1 / 8.0)
+    x = synth.images(DP_B, DP_S, seed=1)
+    data = synth.norm_data(synth.labels(DP_B, DP_S, 20, seed=DP_LABEL_SEED), DP_S, DP_S, DP_S // 32, DP_S // 32)
+    return sd, x, data
+
+
+def _dp_rank(rank, world, port, tmp, sync):
+    """One data-parallel rank: Darknet (narrow) + model.loss on its shard through train.ensure_model -> DataParallelRCCL.
+    Both ranks share cuda:0 (the test box has one GPU), so the process group is gloo with host-staged buffers; everything
+    else - the grad_ready_hook bucket protocol, the positive-count all-reduce, the HIP kernels - is the product path."""
+    import sys
+    from conftest import APP, ROOT
+    for p in (ROOT, APP):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', Y2_DIST_BACKEND='gloo')
+    import model
+    import train
+    from model import train_graph
+    train_graph.SYNC_POSITIVES = sync
+    assert train.init_distributed() == world
+    sd, x, data = _dp_inputs()
+    if rank != 0:       # replicas must end up with rank 0's weights (the wrapper broadcasts them)
+        sd = {k: (v + 0.01 if v.is_floating_point() else v) for k, v in sd.items()}
+    inf, anchors = build(sd)
+    m = train.ensure_model(inf)
+    assert isinstance(m, train.DataParallelRCCL) and inf.dnn.grad_ready_hook is not None
+    per = DP_B // world
+    sl = slice(rank * per, (rank + 1) * per)
+    pred = model._inference(m, x[sl].cuda())
+    loss, debug = model.loss(anchors, {k: v[sl] for k, v in data.items()}, pred, 0.6)
+    sum(loss[k] * oloss.HPARAM[k] for k in loss).backward()
+    torch.cuda.synchronize()
+    torch.save({'loss': {k: v.item() for k, v in loss.items()}, 'positives': int(debug['positive'].sum().item()),
+                'grads': {k: p.grad.cpu() for k, p in inf.named_parameters()},
+                'buffers': {k: b.cpu() for k, b in inf.dnn.named_buffers()}}, os.path.join(tmp, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _oracle_concatenated_batch(world):
+    """The reference's semantics for the global batch (train.py:65-71, 296-309; model/__init__.py:159-166): BatchNorm statistics
+    per replica shard, ONE loss over the concatenated batch (cnt = B_total*cells*A, cls = mean over ALL positives), fp64 autograd."""
+    from oracle import head as ohead
+    sd, x, data = _dp_inputs()
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    per = DP_B // world
+    stats0 = {}
+    feats = [odark.forward(x[r * per:(r + 1) * per].double(), sd64, training=True, stats=(stats0 if r == 0 else {})) for r in range(world)]
+    lo, dbg = oloss.loss(anchors.double(), {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()},
+                         ohead.decode(torch.cat(feats, 0), anchors.double()), 0.6)
+    oloss.total(lo).backward()
+    return sd64, lo, dbg, stats0
+
+
+def _rel(got, ref):
+    rms = ref.double().pow(2).mean().sqrt().item()
+    return (got.double() - ref.double()).abs().max().item() / max(rms, 1e-30)
+
+
+@pytest.mark.timeout(600)
+def test_dp_world2_darknet_region_loss_equals_concatenated_batch(tmp_path):
+    """two ranks x B/2 on Darknet + region loss == one process on the concatenated batch (per-shard BN), including
+    the positive-count all-reduce that makes the mean-over-positives cls term global (model/__init__.py:162)."""
+    import torch.multiprocessing as mp
+    world = 2
+    sd64, lo, dbg, stats0 = _oracle_concatenated_batch(world)
+    per = DP_B // world
+    pos = dbg['positive'].view(DP_B, -1).sum(1)
+    assert pos[:per].sum().item() != pos[per:].sum().item(), 'the shards must hold different numbers of positives for this test to bite'
+    out = {}
+    for sync in (True, False):
+        d = tmp_path / ('sync%d' % sync)
+        d.mkdir()
+        mp.spawn(_dp_rank, args=(world, _free_port(), str(d), sync), nprocs=world, join=True)
+        out[sync] = [torch.load(str(d / ('rank%d.pt' % r)), weights_only=False) for r in range(world)]
+    r0, r1 = out[True]
+    assert r0['positives'] + r1['positives'] == int(pos.sum().item()) and r0['positives'] != r1['positives']
+    # averaged gradients are identical on both ranks and equal the single-process gradient on the concatenated batch
+    for k, v in sd64.items():
+        if not v.requires_grad:
+            continue
+        assert torch.equal(r0['grads'][k], r1['grads'][k]), k
+        e = _rel(r0['grads'][k], v.grad)
+        assert e <= 2e-3, (k, e)          # same tolerance as the single-process training-step test (23 batch-stat BN layers in fp32)
+    # loss terms: every rank divides by its LOCAL cnt, so the mean over ranks is the global term; cls uses the GLOBAL positive count
+    for k in lo:
+        got = 0.5 * (r0['loss'][k] + r1['loss'][k])
+        assert abs(got - lo[k].item()) <= 1e-4 * abs(lo[k].item()), (k, got, lo[k].item())
+    # rank 0's running statistics are those of shard 0 (only replica 0's buffers persist in nn.DataParallel)
+    for prefix, (rm, rv) in stats0.items():
+        assert _rel(r0['buffers'][prefix + '.bn.running_mean'], rm) <= 1e-4, prefix
+        assert _rel(r0['buffers'][prefix + '.bn.running_var'], rv) <= 1e-4, prefix
+    # without the positive-count all-reduce the cls term (and with it the head gradient) is visibly wrong
+    n0, n1 = out[False]
+    wrong = 0.5 * (n0['loss']['cls'] + n1['loss']['cls'])
+    assert abs(wrong - lo['cls'].item()) > 1e-3 * abs(lo['cls'].item())
+    for k in ('foreground', 'background', 'center', 'size'):
+        assert abs(0.5 * (n0['loss'][k] + n1['loss'][k]) - lo[k].item()) <= 1e-4 * abs(lo[k].item()), k
+    head = 'layers3.1.conv.weight'
+    assert _rel(n0['grads'][head], sd64[head].grad) > 10 * _rel(r0['grads'][head], sd64[head].grad)
+
+
+def test_wrapped_model_survives_cpu_cuda_round_trip():
+    """train.py:423-432: Train.eval moves the (wrapped) inference module to the CPU and back between training steps.  The plan /
+    packed-weight caches are keyed on data pointers and the wrapper's flat buckets live on the old device: after the round trip a
+    training step and an eval forward must still be right (fresh model on the same weights as the witness)."""
+    import model
+    import train
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    os.environ.pop('Y2_DIST_BACKEND', None)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+    try:
+        widths = dict(NARROW)
+        widths['layers1.5'] = 8
+        sd = odark.init_state_dict(5, 20, seed=0, channels=widths, head_scale=1 / 8.0)
+        x = synth.images(2, 96, seed=1).cuda()
+        data = synth.norm_data(synth.labels(2, 96, 20, seed=2), 96, 96, 3, 3)
+
+        def step(m, anchors):
+            for p in m.parameters():
+                p.grad = None
+            pred = model._inference(m, x)
+            loss, _ = model.loss(anchors, data, pred, 0.6)
+            sum(loss[k] * oloss.HPARAM[k] for k in loss).backward()
+            torch.cuda.synchronize()
+
+        inf, anchors = build(sd)
+        m = train.DataParallelRCCL(inf, bucket_bytes=4096)
+        step(m, anchors)                                   # buckets and caches now live on cuda:0
+        inf.eval()
+        with torch.no_grad():
+            before = model._inference(m, x)['feature'].clone()
+        m.cpu()                                            # train.py:424
+        assert all(not p.is_cuda for p in inf.parameters())
+        m.cuda()                                           # train.py:432
+        with torch.no_grad():
+            after = model._inference(m, x)['feature']
+        assert torch.equal(before, after)                  # same weights, re-packed from the new allocations
+        inf.train()
+        step(m, anchors)
+        witness, anchors2 = build({k: v.clone() for k, v in inf.dnn.state_dict().items()})
+        # train-mode gradients do not depend on the running statistics, so a fresh model on the same weights is an exact witness
+        step(witness, anchors2)
+        for (k, a), (_, b) in zip(inf.named_parameters(), witness.named_parameters()):
+            assert (a.grad - b.grad).abs().max().item() <= 1e-5 * b.grad.abs().max().item() + 1e-9, k
+    finally:
+        dist.destroy_process_group()

@@ -152,6 +152,20 @@ def require_gpu(*tensors):
             raise RuntimeError('yolo2-hip: this operator runs only on an MI355X GPU tensor (got device %s); there is no CPU fallback' % t.device)
 
 
+# Memory written through raw pointers (the fused optimizers, y2_bn_finalize's running statistics) does not bump torch's
+# `_version` counters, so caches of packed / folded / transformed weights also key on this epoch: every writer of parameter
+# or buffer memory outside torch calls `mutated()`.
+_EPOCH = [0]
+
+
+def mutated():
+    _EPOCH[0] += 1
+
+
+def epoch():
+    return _EPOCH[0]
+
+
 _WS = {}
 
 

@@ -117,7 +117,8 @@ class ResNet(nn.Module):
 
     # ------------------------------------------------------------------ preparation: packed weights + folded BN
     def _versions(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        # torch version counters + the library's mutation epoch (raw-pointer writers: utils.optim, y2_bn_finalize)
+        return (_hip.epoch(),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def _prepare(self, dev):
         ver = (dev, self._versions())
@@ -258,7 +259,7 @@ class ResNet(nn.Module):
         return out
 
     def forward(self, x):
-        if self.training and torch.is_grad_enabled():
+        if self.training:        # BN semantics follow self.training alone (see model.yolo2.Darknet.forward)
             from model import train_graph
             return train_graph.resnet_forward(self, x)
         with torch.no_grad():
@@ -273,8 +274,9 @@ def _make(block, layers):
             pretrained = config_channels.config.getboolean('model', 'pretrained')
         except Exception:
             pretrained = False
-        if pretrained:   # model/resnet.py:164-171 downloads torchvision weights: there is no network here
-            logging.warning('model.resnet: [model] pretrained=1 ignored (no network / torchvision model zoo in this environment)')
+        if pretrained:   # model/resnet.py:164-171 loads the torchvision model-zoo weights by URL
+            raise RuntimeError('model.resnet: [model] pretrained=1 cannot be honoured (no torchvision model zoo / network here); '
+                               'set pretrained=0 and load a checkpoint with load_state_dict (same keys as torchvision.models.resnet)')
         return net
     return ctor
 

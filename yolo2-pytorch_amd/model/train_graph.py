@@ -26,6 +26,26 @@ import _hip
 
 SYNC_POSITIVES = True   # data parallel: all-reduce the positive count so the cls mean is over the global batch
 
+# Set by train.DataParallelRCCL: callable(tensor) summing a small tensor over the wrapper's process group, in place (it knows
+# the group and how to reach it: RCCL directly on device memory, or host staging under the gloo test backend).
+# None: the default group is used when torch.distributed is initialised with more than one rank.
+DP_ALL_REDUCE = None
+
+
+def _sum_over_ranks(t):
+    """True when `t` was summed over more than one rank."""
+    if DP_ALL_REDUCE is not None:
+        return DP_ALL_REDUCE(t)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if t.is_cuda and dist.get_backend() == 'gloo':
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return True
+    return False
+
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.01
 LEAKY = 0.1
@@ -125,6 +145,7 @@ class DarknetTrainFn(torch.autograd.Function):
                 _hip.check(L.y2_bn_finalize(_hip.ptr(stats), float(B * h * w), _hip.ptr(bn.weight.detach()), _hip.ptr(bn.bias.detach()),
                                             _hip.ptr(bn.running_mean), _hip.ptr(bn.running_var), BN_MOMENTUM, BN_EPS,
                                             _hip.ptr(blk.scale), _hip.ptr(blk.shift), _hip.ptr(blk.mean), _hip.ptr(blk.invstd), cout, st), 'y2_bn_finalize')
+                _hip.mutated()      # running statistics were written through raw pointers
                 if bn.num_batches_tracked is not None:
                     bn.num_batches_tracked += 1
             else:
@@ -366,10 +387,11 @@ class RegionLossFn(torch.autograd.Function):
                                         _hip.ptr(gt_min), _hip.ptr(gt_max), _hip.ptr(cls_i), _hip.ptr(cls_oh), _hip.ptr(anchors_dev),
                                         B, rows, cols, A, C, N, float(threshold), _hip.ptr(best_iou), _hip.ptr(best_idx), _hip.ptr(positive),
                                         _hip.ptr(sums), _hip.ptr(out), _hip.stream()), 'y2_region_loss_fwd')
-        if SYNC_POSITIVES and cls_i is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if SYNC_POSITIVES and cls_i is not None:
             # exact data-parallel parity of the cls term (mean over positives, model/__init__.py:162): global positive count
-            dist.all_reduce(sums[5:6], op=dist.ReduceOp.SUM)
-            _hip.check(L.y2_region_loss_finalize(_hip.ptr(sums), float(B * n), 1, _hip.ptr(out), _hip.stream()), 'y2_region_loss_finalize')
+            npos = sums[5:6]
+            if _sum_over_ranks(npos):
+                _hip.check(L.y2_region_loss_finalize(_hip.ptr(sums), float(B * n), 1, _hip.ptr(out), _hip.stream()), 'y2_region_loss_finalize')
         ctx.saved = (iou, co, sn, lg, gt_min, gt_max, cls_i, cls_oh, anchors_dev, best_iou, best_idx, positive, sums)
         ctx.geom = (B, rows, cols, A, C, N, float(threshold))
         ctx.mark_non_differentiable(best_iou, best_idx, positive)
@@ -502,6 +524,7 @@ class ResNetTrainFn(torch.autograd.Function):
                 _hip.check(L.y2_bn_finalize(_hip.ptr(stats), float(B * ho * wo), _hip.ptr(bn.weight.detach()), _hip.ptr(bn.bias.detach()),
                                             _hip.ptr(bn.running_mean), _hip.ptr(bn.running_var), ResNetTrainFn.MOMENTUM if momentum is None else momentum, BN_EPS,
                                             _hip.ptr(op.scale), _hip.ptr(op.shift), _hip.ptr(op.mean), _hip.ptr(op.invstd), cout, st), 'y2_bn_finalize')
+                _hip.mutated()
                 if bn.num_batches_tracked is not None:
                     bn.num_batches_tracked += 1
             else:

@@ -136,7 +136,9 @@ class Darknet(nn.Module):
         return self.layers1[0]
 
     def _versions(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        """Cache key of everything derived from the parameters: torch's version counters plus the library's mutation epoch
+        (raw-pointer writers - utils.optim, y2_bn_finalize - are invisible to `_version`)."""
+        return (_hip.epoch(),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def _prepare_eval(self, device):
         """Pack weights to [Cout][tap][Cin] and fold BN once per parameter version (y2_pack_weight / y2_bn_fold)."""
@@ -305,7 +307,10 @@ class Darknet(nn.Module):
         return out
 
     def forward(self, x):
-        if self.training and torch.is_grad_enabled():
+        # BN semantics follow self.training alone, like nn.BatchNorm2d (model/yolo2.py:58): train() mode normalises with batch
+        # statistics and updates the running ones whether or not autograd is recording (under no_grad the graph is simply
+        # not taped); eval() mode runs the folded-BN inference chain, which is not differentiable (it returns no grad_fn).
+        if self.training:
             from model import train_graph  # training graph (autograd.Function over the HIP kernels)
             return train_graph.darknet_forward(self, x)
         with torch.no_grad():
@@ -408,7 +413,7 @@ class Tiny(Darknet):
         return cur
 
     def forward(self, x):
-        if self.training and torch.is_grad_enabled():
+        if self.training:
             from model import train_graph
             return train_graph.tiny_forward(self, x)
         with torch.no_grad():

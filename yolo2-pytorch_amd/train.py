@@ -37,6 +37,19 @@ def norm_data(data, height, width, rows, cols, keys='yx_min, yx_max'):
     return _data
 
 
+class _HostStagedWork(object):
+    """all-reduce of a GPU tensor under a backend that only moves host memory (the gloo backend of the CPU / single-GPU tests):
+    copy to the host, reduce there, copy back on wait().  RCCL (backend "nccl") never takes this path."""
+
+    def __init__(self, t, group):
+        self.t, self.h = t, t.cpu()
+        self.work = dist.all_reduce(self.h, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+    def wait(self):
+        self.work.wait()
+        self.t.copy_(self.h)
+
+
 class DataParallelRCCL(nn.Module):
     """Gradient-averaging data parallelism over torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" on CPU)."""
 
@@ -46,10 +59,16 @@ class DataParallelRCCL(nn.Module):
         self.pg = process_group
         self.world = dist.get_world_size(self.pg)
         self.bucket_bytes = bucket_bytes
+        self._staged = dist.get_backend(self.pg) == 'gloo'
         # identical replicas: rank 0's parameters and buffers win (the reference broadcasts GPU0's every step)
         with torch.no_grad():
             for t in list(module.parameters()) + list(module.buffers()):
-                dist.broadcast(t, 0, group=self.pg)
+                if t.is_cuda and self._staged:
+                    h = t.detach().cpu()
+                    dist.broadcast(h, 0, group=self.pg)
+                    t.copy_(h)
+                else:
+                    dist.broadcast(t, 0, group=self.pg)
         self._build_buckets()
         self._pending = False
         for p in self._params:
@@ -58,8 +77,24 @@ class DataParallelRCCL(nn.Module):
         for m in module.modules():
             if hasattr(m, 'grad_ready_hook'):
                 m.grad_ready_hook = self._early_hook
+        # the region loss sums its positive count over THIS group (model/__init__.py:162: mean over the positives of the global batch)
+        from model import train_graph
+        train_graph.DP_ALL_REDUCE = self._sum_small
 
-    # ---- bucketing: reverse registration order ~ the order in which backward produces gradients
+    def _all_reduce(self, t):
+        if t.is_cuda and self._staged:
+            return _HostStagedWork(t, self.pg)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _sum_small(self, t):
+        if self.world <= 1:
+            return False
+        self._all_reduce(t).wait()
+        return True
+
+    # ---- bucketing: reverse registration order ~ the order in which backward produces gradients.  Every flat bucket ends
+    # with one flag per parameter ("this rank produced a gradient for it"): after the sum a parameter nobody touched keeps
+    # grad None on every rank, and a parameter only SOME ranks touched gets the averaged gradient on all of them.
     def _build_buckets(self):
         self._params = [p for p in self.module.parameters() if p.requires_grad]
         self._where = {}
@@ -79,28 +114,47 @@ class DataParallelRCCL(nn.Module):
             for p in bucket:
                 self._where[id(p)] = (bi, off)
                 off += p.numel()
-            self._flat.append(torch.zeros(off, dtype=bucket[0].dtype, device=bucket[0].device))
+            self._flat.append(torch.zeros(off + len(bucket), dtype=bucket[0].dtype, device=bucket[0].device))
         self._reset()
 
     def _reset(self):
         self._ready = [0] * len(self._buckets)
         self._done = set()
         self._works = [None] * len(self._buckets)
+        self._next = 0          # buckets are launched strictly in index order: every rank issues the SAME collective sequence
 
     def _start(self):
         if not self._pending:
             self._pending = True
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
 
+    def _launch_bucket(self, bi):
+        """Zero the slots (and flags) of parameters without a gradient this step, then start the bucket's all-reduce.  EVERY
+        rank launches EVERY bucket exactly once per backward, so the collective sequences of the ranks always match."""
+        flat, bucket = self._flat[bi], self._buckets[bi]
+        base = flat.numel() - len(bucket)
+        if self._ready[bi] == len(bucket):           # the common case: one fill kernel for all flags
+            flat[base:].fill_(1.0)
+        else:
+            for k, p in enumerate(bucket):
+                if id(p) in self._done:
+                    flat[base + k] = 1.0
+                else:
+                    _, off = self._where[id(p)]
+                    flat[off:off + p.numel()].zero_()
+                    flat[base + k] = 0.0
+        self._works[bi] = self._all_reduce(flat)
+
     def _fill(self, p, g):
         bi, off = self._where[id(p)]
-        if self._flat[bi].device != g.device:
+        if self._flat[bi].device != g.device:       # the module moved (train.py:423-432: .cpu() for evaluation, .cuda() to resume)
             self._flat[bi] = self._flat[bi].to(g.device)
         self._flat[bi][off:off + p.numel()].copy_(g.reshape(-1))
         self._done.add(id(p))
         self._ready[bi] += 1
-        if self._ready[bi] == len(self._buckets[bi]):
-            self._works[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        while self._next < len(self._buckets) and self._ready[self._next] == len(self._buckets[self._next]):
+            self._launch_bucket(self._next)        # a complete bucket waits for its incomplete predecessors (launched by _finalize)
+            self._next += 1
 
     def _early_hook(self, p, g):
         """Called from inside a module's backward with the finished gradient of parameter p."""
@@ -117,26 +171,36 @@ class DataParallelRCCL(nn.Module):
 
     def _finalize(self):
         inv = 1.0 / self.world
-        for bi, bucket in enumerate(self._buckets):
-            if self._works[bi] is None:   # bucket with parameters that got no gradient this step
-                if self._ready[bi] == 0:
-                    continue
-                for p in bucket:
-                    if id(p) not in self._done:
-                        bo, off = self._where[id(p)]
-                        self._flat[bi][off:off + p.numel()].zero_()
-                self._works[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            self._works[bi].wait()
-            flat = self._flat[bi]
-            flat.mul_(inv)
-            for p in bucket:
-                bo, off = self._where[id(p)]
-                if p.grad is not None:
-                    p.grad.copy_(flat[off:off + p.numel()].view_as(p))
-        self._pending = False
-        self._reset()
+        try:
+            for bi in range(self._next, len(self._buckets)):
+                # some parameters of this bucket (or of an earlier one) got no gradient on this rank: reduce it anyway, in order
+                bucket = self._buckets[bi]
+                dev = next((p.grad.device for p in bucket if p.grad is not None), self._flat[bi].device)
+                if self._flat[bi].device != dev:
+                    self._flat[bi] = self._flat[bi].to(dev)
+                self._launch_bucket(bi)
+            self._next = len(self._buckets)
+            for bi, bucket in enumerate(self._buckets):
+                self._works[bi].wait()
+                flat = self._flat[bi]
+                base = flat.numel() - len(bucket)
+                flags = flat[base:].tolist() if any(id(p) not in self._done for p in bucket) else None
+                flat[:base].mul_(inv)
+                for k, p in enumerate(bucket):
+                    _, off = self._where[id(p)]
+                    avg = flat[off:off + p.numel()].view_as(p)
+                    if p.grad is not None:
+                        p.grad.copy_(avg)
+                    elif flags is not None and flags[k] > 0:      # another rank produced a gradient for it
+                        p.grad = avg.clone()
+        finally:
+            self._pending = False
+            self._reset()
 
     def forward(self, *args, **kwargs):
+        # a backward that raised leaves the bookkeeping half-filled: start every step from a clean slate
+        self._pending = False
+        self._reset()
         return self.module(*args, **kwargs)
 
 
@@ -145,12 +209,16 @@ def init_distributed():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = os.environ.get('Y2_DIST_BACKEND')      # tests: "gloo" with GPU tensors staged through the host (two ranks on ONE GPU)
         if torch.cuda.is_available():
             local = int(os.environ.get('LOCAL_RANK', '0'))
             torch.cuda.set_device(local)
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+            if backend in (None, '', 'nccl'):
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local))       # "nccl" IS RCCL on ROCm
+            else:
+                dist.init_process_group(backend)
         else:
-            dist.init_process_group('gloo')
+            dist.init_process_group(backend or 'gloo')
     return world
 
 

@@ -85,6 +85,7 @@ class SGD(torch.optim.Optimizer):
                 if rows:
                     _launch(L.y2_opt_sgd, rows, group['lr'], group['momentum'], group['dampening'], group['weight_decay'],
                             int(group['nesterov']), first)
+        _hip.mutated()      # parameters were written through raw pointers: packed-weight caches must not survive
         return loss
 
 
@@ -121,6 +122,7 @@ class Adam(torch.optim.Optimizer):
             b1, b2 = group['betas']
             for step, rows in by_step.items():
                 _launch(L.y2_opt_adam, rows, group['lr'], b1, b2, group['eps'], group['weight_decay'], step)
+        _hip.mutated()
         return loss
 
 
