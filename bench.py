@@ -1,23 +1,35 @@
 #!/usr/bin/env python
-"""bench.py — images/sec of the Darknet-19 YOLOv2 hot path on MI355X (BASELINE.json metric).
+"""bench.py — images/sec of the Darknet-19 YOLOv2 hot path on MI355X (BASELINE.json metric: train + detect at 1/2/4/8 GPUs).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size S] [--mode detect|forward]
+    python bench.py [--gpus N] [--steps K] [--warmup W]        # N > 1: re-launches itself as N ranks (one process per GPU)
 
-N = 1 workload = BASELINE.json configs[1]: Darknet-19 YOLOv2 416x416 batch-32 inference (conv stack + decode +
-visibility filter + NMS), synthetic images, random-init weights (seeded), inputs resident in HBM before the timed
-region.  For N > 1 (launched by torch.distributed.run, one process per GPU) inference is "replicas only": every rank
-runs the same per-GPU batch, no data-path collective; the barrier and max-over-ranks timing stay.
+Launch.  With WORLD_SIZE unset and --gpus N > 1 the script re-executes itself under `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`; launched by the driver through torch.distributed.run it reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  `ranks_seen` in the output is an RCCL all-reduce of ones.
 
-Prints ONE JSON line on rank 0 with the contract fields plus:
-  roofline     — conv_fwd_dma_kernel family (the dominant kernel: 99% of the FLOPs): algorithmic conv FLOPs of its 22
-                 launches per step / their duration, measured live with one HIP event pair per step on the launch stream
-                 inside the timed region; peak = 157.3 TFLOP/s (fp32-input MFMA, MI355X_MICROARCH.md).
-  cpu_baseline — the CPU oracle (port of the reference path: torch-CPU conv stack + numpy decode/filter/NMS) timed on
-                 this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+Legs (every timed region: W untimed warm-up steps, barrier + synchronize, EXACTLY K steps, barrier + synchronize, MAX over ranks):
+  detect   BASELINE configs[1]: 416x416 batch-32 inference per GPU = conv stack + decode + visibility filter + NMS, inputs
+           resident in HBM, K hipGraph replays rotating over 4 different resident batches.  N > 1: replicas only (no collective).
+  train    BASELINE configs[2]: VOC-20 batch-64 per GPU: forward (batch-stat BN) + region loss + backward + fused SGD
+           (lr 1e-3, momentum 0.9; quick_start.sh:71).  N > 1: data parallel through train.ensure_model (bucketed RCCL
+           all-reduce overlapped with backward, positive-count all-reduce), weak scaling; the same step WITHOUT the wrapper is
+           timed beside it on every rank (`train.single_gpu_images_per_sec`: the denominator of the DP scaling efficiency).
+  Headline `value`: detect at N = 1 (BASELINE configs[1]); the data-parallel train step at N > 1 (north_star: ">= 6x DP
+           scaling 1 -> 8"), with the other leg reported beside it (`detect` / `train` objects).  --headline overrides.
+
+Roofline (N = 1, measured in this run with the library's per-kernel HIP-event hooks, y2_prof_*, on the launch stream):
+  roofline         dominant kernel of the detect step: executed multiply-add FLOPs per launch / average launch duration against
+                   the fp32-input MFMA peak (157.3 TFLOP/s) -> frac <= 1 by construction; `top_kernels` lists every kernel
+                   with >= 1 % of the step; `conv_chain` gives the whole 23-conv chain (executed and direct-equivalent rates).
+  conv3x3_b64      north_star's target quantity: the 3x3 convolutions at batch 64, per-layer event pairs, Winograd on and off.
+  train.roofline   the same per-kernel table for the training step (executed FLOPs of fprop / dgrad / wgrad kernels).
+  cpu_baseline     the CPU oracle (port of the reference path) on this box's host cores, bounded sample, rank 0 at N = 1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,61 +39,406 @@ for p in (ROOT, APP):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-PEAK_FP32_MFMA_TFLOPS = 157.3
-
-
-def build_model(num_cls, dev, arch='darknet'):
-    import configparser
-
-    import model
-    import model.yolo2
-    from oracle import darknet as odark
-    from oracle import synth
-    cfg = configparser.ConfigParser()
-    cfg.read_dict({'batch_norm': {'enable': '1'}})
-    anchors = torch.from_numpy(synth.ANCHORS_VOC)
-    # SURVEY.md 8d weights: seed 0, kaiming conv, randomised BN buffers; head scaled so exp(size_norm) stays finite
-    if arch != 'darknet':
-        import model.resnet
-        from oracle import resnet as ores
-        cfg.read_dict({'model': {'pretrained': '0'}})
-        sd = ores.init_state_dict(arch, 5, num_cls, seed=0, head_scale=0.25)
-        dnn = getattr(model.resnet, arch)(model.ConfigChannels(cfg, sd), anchors, num_cls)
-        dnn.load_state_dict(sd, strict=False)
-        return model.Inference(cfg, dnn, anchors).to(dev).eval(), anchors, sd
-    sd = odark.init_state_dict(5, num_cls, seed=0, head_scale=1 / 40.0)
-    dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, num_cls)
-    dnn.load_state_dict(sd, strict=False)
-    inf = model.Inference(cfg, dnn, anchors).to(dev).eval()
-    return inf, anchors, sd
+PEAK_FP32_MFMA_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32, dense, MI355X_MICROARCH.md
+FLOPS_FWD_PER_IMG = 29.360e9           # sum over the 23 convs of 2*Cin*Cout*k*k*H*W at 416x416, VOC-20
+FLOPS_TRAIN_PER_IMG = 87.78e9          # fwd + wgrad + dgrad (all but the first conv)
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch of the detect leg (BASELINE configs[1])')
+    ap.add_argument('--size', type=int, default=416)
+    ap.add_argument('--classes', type=int, default=20)
+    ap.add_argument('--model', default='darknet', help='darknet (BASELINE configs[1-3]), tiny, or a model.resnet plugin name (configs[4]: --model resnet50 --size 608 --classes 80)')
+    ap.add_argument('--headline', default='auto', choices=['auto', 'detect', 'train'], help='auto: detect at N = 1, data-parallel train at N > 1')
+    ap.add_argument('--train-steps', type=int, default=0, help='timed training steps (0 = min(--steps, 12))')
+    ap.add_argument('--train-batch', type=int, default=64, help='per-GPU batch of the train leg (BASELINE configs[2])')
+    ap.add_argument('--rotate', type=int, default=4, help='number of different resident input batches the timed steps rotate over')
+    ap.add_argument('--no-graph', action='store_true', help='launch the detect step eagerly instead of replaying captured hipGraphs')
+    ap.add_argument('--no-train', action='store_true')
+    ap.add_argument('--no-detect', action='store_true')
+    ap.add_argument('--no-direct-leg', action='store_true', help='skip the Winograd-off measurements')
+    ap.add_argument('--no-conv3', action='store_true', help='skip the batch-64 conv3x3 leg')
+    ap.add_argument('--settle', type=float, default=2.0, help='idle seconds between the inference legs and the train leg (outside timed regions)')
+    ap.add_argument('--cpu-sample', type=int, default=192, help='images for the CPU baseline (0 = skip)')
+    ap.add_argument('--dry-run', action='store_true', help='no GPU: exercise launch / rendezvous / DP wrapper / timing protocol with a stand-in CPU workload (gloo); the numbers mean nothing')
+    return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """--gpus N without a launcher: become `torch.distributed.run` with N ranks on this node (one process per GPU)."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL needs it on this driver)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------- measurement helpers
+class Ctx(object):
+    """Process-wide run context: ranks, device, barrier, max-over-ranks."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local = int(os.environ.get('LOCAL_RANK', '0'))
+        self.gpu = torch.cuda.is_available() and not args.dry_run
+        if self.gpu:
+            torch.cuda.set_device(self.local)
+            self.dev = torch.device('cuda', self.local)
+        else:
+            self.dev = torch.device('cpu')
+        if self.world > 1:
+            import train as y2train
+            if not self.gpu:
+                os.environ.setdefault('Y2_DIST_BACKEND', 'gloo')
+            y2train.init_distributed()                      # backend "nccl" == RCCL on ROCm, one process per GPU
+        ones = torch.ones(1, device=self.dev)
+        if self.world > 1:
+            dist.all_reduce(ones)
+        self.ranks_seen = int(ones.item())
+
+    def sync(self):
+        if self.gpu:
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.sync()
+
+    def max_over_ranks(self, seconds):
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.dev)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.item()
+
+    def timed(self, fn, steps):
+        """barrier + synchronize | EXACTLY `steps` calls | barrier + synchronize; MAX over ranks.  Returns (seconds, host seconds)."""
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(i)
+        host = time.perf_counter() - t0
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0), host
+
+
+def kernel_table(fn, steps):
+    """Run fn(i) `steps` times with the library's per-kernel event hooks on (include/yolo2_hip.h: y2_prof_*): every kernel launch
+    is bracketed by a HIP event pair on its launch stream.  Returns {kernel: dict(launches, ms, flops)} per STEP (averages)."""
+    import ctypes
+
+    import torch
+
+    import _hip
+    L = _hip.lib()
+    torch.cuda.synchronize()
+    L.y2_prof_enable(1)
+    try:
+        for i in range(steps):
+            fn(i)
+        torch.cuda.synchronize()
+    finally:
+        L.y2_prof_enable(0)
+    name = ctypes.create_string_buffer(96)
+    ms, fl = ctypes.c_float(), ctypes.c_double()
+    table = {}
+    for i in range(L.y2_prof_count()):
+        if L.y2_prof_get(i, name, 96, ctypes.byref(ms), ctypes.byref(fl)) != 0:
+            continue
+        e = table.setdefault(name.value.decode(), dict(launches=0, ms=0.0, flops=0.0))
+        e['launches'] += 1
+        e['ms'] += ms.value
+        e['flops'] += fl.value
+    for e in table.values():
+        e['launches'] /= float(steps)
+        e['ms'] /= steps
+        e['flops'] /= steps
+    return table
+
+
+def top_kernels(table, min_share=0.01):
+    total = sum(e['ms'] for e in table.values()) or 1.0
+    rows = []
+    for k, e in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
+        if e['ms'] / total < min_share:
+            continue
+        tf = e['flops'] / (e['ms'] * 1e-3) / 1e12 if e['flops'] > 0 and e['ms'] > 0 else None
+        rows.append({'kernel': k, 'launches_per_step': round(e['launches'], 2), 'ms_per_step': round(e['ms'], 4), 'share': round(e['ms'] / total, 4),
+                     'avg_launch_us': round(e['ms'] / max(e['launches'], 1e-9) * 1e3, 2),
+                     'executed_tflops': None if tf is None else round(tf, 2), 'frac': None if tf is None else round(tf / PEAK_FP32_MFMA_TFLOPS, 4)})
+    return rows, total
+
+
+def roofline_from(table, what):
+    """`roofline` object for the dominant MFMA kernel of `table` + the per-kernel list."""
+    rows, total_ms = top_kernels(table)
+    mfma = [r for r in rows if r['executed_tflops'] is not None]
+    dom = max(mfma, key=lambda r: r['ms_per_step']) if mfma else None
+    gemm_ms = sum(e['ms'] for e in table.values() if e['flops'] > 0)
+    gemm_fl = sum(e['flops'] for e in table.values())
+    out = {'bound': 'mfma', 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'what': what,
+           'definition': 'executed multiply-add FLOPs of the kernel (2*M*N*K of the GEMM each launch runs; Winograd layers execute 16/36 of the direct count) / its '
+                         'launch durations, HIP event pair per launch on the launch stream, measured in this run',
+           'kernel': dom['kernel'] if dom else None, 'achieved': dom['executed_tflops'] if dom else None, 'frac': dom['frac'] if dom else None,
+           'kernel_share_of_step': dom['share'] if dom else None, 'avg_launch_us': dom['avg_launch_us'] if dom else None,
+           'all_mfma_kernels': {'executed_tflops': round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else None,
+                                'frac': round(gemm_fl / (gemm_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if gemm_ms > 0 else None,
+                                'ms_per_step': round(gemm_ms, 4), 'executed_flops_per_step': gemm_fl},
+           'kernel_ms_per_step': round(total_ms, 4), 'top_kernels': rows}
+    return out
+
+
+def static_traffic(tag):
+    """HBM-side bytes per step from the committed rocprofv3 PMC passes (separate profiling runs, tools/gpu_profile.sh): NOT measured
+    in this run, so it is reported with its source, never as a live number."""
+    import glob
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_%s_traffic.json' % tag)))
+    if not files:
+        return None, None
+    try:
+        return json.load(open(files[-1]))['traffic_bytes_per_step'], 'static: ' + os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
+# ---------------------------------------------------------------------------------------------------- detect leg
+def detect_leg(args, ctx):
+    import torch
+
+    import _hip
+    import bench_data
+    import detect
+    inf, anchors = bench_data.build_model(args.classes, ctx.dev, args.model)
+    dnn = inf.dnn
+    kw = dict(fix=True, threshold_cls=0.005, overlap=0.45, limit=200)
+    xs = [bench_data.images(args.batch, args.size, seed=1 + ctx.rank * 16 + i).to(ctx.dev) for i in range(max(1, args.rotate))]   # resident in HBM
+
+    def eager(i):
+        with torch.no_grad():
+            return detect.detect_batch(dnn.forward_nhwc(xs[i % len(xs)]), anchors, **kw)
+
+    def measure(steps, warmup, want_table):
+        for i in range(warmup):
+            eager(i)
+        ctx.sync()
+        table = kernel_table(eager, min(steps, 8)) if want_table else None
+        runs = None
+        if not args.no_graph:
+            try:      # one captured graph per resident batch (they share the plan's intermediate buffers; replays are serial)
+                runs = [detect.GraphedDetector(dnn, anchors, x, static_input=True, **kw) for x in xs]
+            except Exception as e:
+                print('hipGraph capture failed (%s); eager launches' % e, file=sys.stderr)
+                runs = None
+        fn = (lambda i: runs[i % len(runs)].run()) if runs is not None else eager
+        for i in range(2 * len(xs)):
+            fn(i)
+        dt, host = ctx.timed(fn, steps)
+        return dt, host, table, runs is not None
+
+    dt, host, table, graphed = measure(args.steps, args.warmup, ctx.world == 1)
+    images = args.batch * args.steps * ctx.world
+    out = {'images_per_sec': round(images / dt, 2), 'ms_per_step': round(dt / args.steps * 1e3, 4), 'steps': args.steps,
+           'host_ms_per_step': round(host / args.steps * 1e3, 4), 'launch': 'hipGraph replay' if graphed else 'eager',
+           'resident_batches_rotated': len(xs), 'per_gpu_batch': args.batch,
+           'parallelism': 'replicas x%d (no collective)' % ctx.world if ctx.world > 1 else 'single GPU'}
+    roof = None
+    if table is not None:
+        roof = roofline_from(table, 'detect step, batch %d (eager launches of the same kernels the timed hipGraph replays)' % args.batch)
+        plan = dnn._plan_cache[1] if dnn._plan_cache else None
+        if plan is not None and 'flops_executed' in plan:
+            conv_ms = sum(e['ms'] for k, e in table.items() if k.startswith(('conv', 'wino')))
+            alg = plan['flops'] + plan['flops0']
+            exe = plan['flops_executed'] + plan['flops0']
+            roof['conv_chain'] = {'ms_per_step': round(conv_ms, 4), 'executed_tflops': round(exe / conv_ms / 1e9, 2), 'frac': round(exe / conv_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                  'direct_equiv_tflops': round(alg / conv_ms / 1e9, 2),
+                                  'direct_equiv_note': 'ALGORITHMIC conv FLOPs (SURVEY.md 8d, 2*Cin*Cout*k*k*H*W) / kernel time: what a direct convolution would have to sustain; not a roofline fraction',
+                                  'winograd_layers': int(sum(plan['algos'])), 'flops_per_step': alg, 'executed_flops_per_step': exe}
+        tr, src = static_traffic('detect_b32') if (args.batch == 32 and args.size == 416 and args.model == 'darknet') else (None, None)
+        roof['traffic'], roof['traffic_source'] = tr, src
+        if _hip.WINOGRAD and args.model == 'darknet' and not args.no_direct_leg:
+            _hip.WINOGRAD = False
+            dnn._plan_cache = None
+            try:
+                ddt, _, dtable, _ = measure(min(args.steps, 20), 2, True)
+                droof = roofline_from(dtable, 'the same step with every 3x3 layer on the implicit-GEMM kernel (Winograd off): executed == algorithmic FLOPs')
+                roof['direct_only'] = {'images_per_sec': round(args.batch * min(args.steps, 20) / ddt, 2), 'kernel': droof['kernel'], 'achieved': droof['achieved'],
+                                       'frac': droof['frac'], 'all_mfma_kernels': droof['all_mfma_kernels']}
+            except Exception as e:
+                roof['direct_only'] = {'error': '%s: %s' % (type(e).__name__, e)}
+            finally:
+                _hip.WINOGRAD = True
+                dnn._plan_cache = None
+    state = {k: v.detach().cpu() for k, v in dnn.state_dict().items()} if (ctx.world == 1 and args.cpu_sample > 0 and args.model == 'darknet') else None
+    del inf, dnn
+    torch.cuda.empty_cache()
+    return out, roof, state, anchors
+
+
+def conv3x3_leg(args, ctx):
+    """north_star target quantity: MFMA utilisation of the 3x3 convolutions at 416x416 batch 64 (17 layers, 28.21 GFLOP/img).
+    Per-layer HIP event pairs around each y2_conv_fwd of the inference plan (layers1.0 through its own y2_conv0_fwd)."""
+    import ctypes
+
+    import torch
+
+    import _hip
+    import bench_data
+    B, S = 64, args.size
+    inf, anchors = bench_data.build_model(args.classes, ctx.dev, 'darknet')
+    dnn = inf.dnn
+    x = bench_data.images(B, S, seed=5).to(ctx.dev)
+    L, st = _hip.lib(), _hip.stream()
+
+    def run(reps=5):
+        with torch.no_grad():
+            for _ in range(2):
+                dnn.forward_nhwc(x)
+        plan = dnn._plan_cache[1]
+        alg = exe = ms = 0.0
+        layers = 0
+        # layers1.0 (K = 27) is one y2_conv0_fwd launch: time it through the kernel hooks
+        t0 = kernel_table(lambda i: dnn.forward_nhwc(x), 2)
+        if 'conv0_kernel' in t0:
+            ms += t0['conv0_kernel']['ms']
+            alg += plan['flops0']
+            exe += plan['flops0']
+            layers += 1
+        for i in range(plan['n']):
+            p = plan['arr'][i]
+            if p.ksize != 3:
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            L.y2_conv_fwd(ctypes.byref(p), st)
+            e0.record()
+            for _ in range(reps):
+                L.y2_conv_fwd(ctypes.byref(p), st)
+            e1.record()
+            e1.synchronize()
+            ms += e0.elapsed_time(e1) / reps
+            a = 2.0 * p.Cin * p.Cout * 9 * p.B * p.H * p.W
+            alg += a
+            exe += 2.0 * p.Cin * p.Cout * 16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2) else a
+            layers += 1
+        return {'layers': layers, 'ms': round(ms, 4), 'executed_tflops': round(exe / ms / 1e9, 2), 'mfma_utilisation': round(exe / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                'direct_equiv_tflops': round(alg / ms / 1e9, 2), 'algorithmic_gflop': round(alg / 1e9, 1), 'executed_gflop': round(exe / 1e9, 1)}
+    out = {'workload': 'the 3x3 convolutions of Darknet-19 at %dx%d batch %d (inference plan, per-layer event pairs; transforms and fix-up kernels of a layer included in its time)' % (S, S, B),
+           'target': 'north_star: >= 0.40 MFMA utilisation', 'peak': PEAK_FP32_MFMA_TFLOPS}
+    out['autotuned'] = run()
+    if _hip.WINOGRAD and not args.no_direct_leg:
+        _hip.WINOGRAD = False
+        dnn._plan_cache = None
+        try:
+            out['direct_only'] = run()
+        finally:
+            _hip.WINOGRAD = True
+            dnn._plan_cache = None
+    del inf, dnn
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- train leg
+def train_leg(args, ctx):
+    import torch
+
+    import bench_data
+    import train as y2train
+    import utils
+    steps = args.train_steps or min(args.steps, 12)
+    B, S = args.train_batch, args.size
+    nbatch = max(1, min(args.rotate, 2))
+    data = []
+    for i in range(nbatch):
+        d = {k: v.to(ctx.dev) for k, v in bench_data.labels(B, S, args.classes, seed=2 + ctx.rank * 16 + i).items()}
+        d['tensor'] = bench_data.images(B, S, seed=11 + ctx.rank * 16 + i).to(ctx.dev)
+        data.append(d)
+
+    def make(wrap):
+        inf, anchors = bench_data.build_model(args.classes, ctx.dev, args.model)
+        inf.train()
+        m = y2train.ensure_model(inf) if wrap else inf
+        opt = utils.optim.SGD(m.parameters(), 1e-3, momentum=0.9)      # fused multi-tensor step (y2_opt_sgd), torch.optim.SGD semantics
+        last = {}
+
+        def step(i):
+            last['r'] = y2train.iterate(m, opt, data[i % nbatch], bench_data.HPARAM, bench_data.THRESHOLD, anchors)
+        return step, last, (inf, m, opt)
+
+    per_img = FLOPS_TRAIN_PER_IMG * (S / 416.0) ** 2 if args.model == 'darknet' else None
+    out = {'per_gpu_batch': B, 'global_batch': B * ctx.world, 'steps': steps, 'resident_batches_rotated': nbatch,
+           'optimizer': 'utils.optim.SGD(lr=1e-3, momentum=0.9): fused multi-tensor HIP kernel, torch.optim.SGD semantics',
+           'parallelism': 'dp%d: one process per GPU, bucketed RCCL all-reduce from inside backward + positive-count all-reduce' % ctx.world if ctx.world > 1 else 'single GPU'}
+    single = None
+    if ctx.world > 1:
+        # the same step without the wrapper, every rank at once: per-GPU rate with zero communication (DP efficiency denominator)
+        step, last, keep = make(False)
+        for i in range(3):
+            step(i)
+        dt, _ = ctx.timed(step, max(4, steps // 2))
+        single = B * max(4, steps // 2) / dt
+        out['single_gpu_images_per_sec'] = round(single, 2)
+        out['single_gpu_note'] = 'same step, no DP wrapper, all ranks running concurrently, MAX over ranks: per-GPU rate with zero communication'
+        del step, last, keep
+        torch.cuda.empty_cache()
+    step, last, keep = make(True)
+    for i in range(3):
+        step(i)
+    dt, host = ctx.timed(step, steps)
+    out.update({'images_per_sec': round(B * steps * ctx.world / dt, 2), 'ms_per_step': round(dt / steps * 1e3, 3), 'host_ms_per_step': round(host / steps * 1e3, 3),
+                'loss_total': float(last['r']['loss_total'].detach())})
+    if single:
+        out['dp_speedup_vs_single_gpu'] = round(out['images_per_sec'] / single, 3)
+    if per_img is not None:
+        out['direct_equiv_tflops_per_gpu'] = round(per_img * B * steps / dt / 1e12, 2)
+    if ctx.world == 1:
+        table = kernel_table(step, 2)
+        out['roofline'] = roofline_from(table, 'training step, batch %d: fprop / dgrad / wgrad kernels with their executed FLOPs' % B)
+        out['roofline']['step_ms_under_hooks'] = round(sum(e['ms'] for e in table.values()), 3)
+    del step, last, keep
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(sd, anchors, size, sample):
-    """Oracle (port) on the host cores: conv stack + decode + filter + NMS on `sample` images."""
-    import numpy as np
+    """Oracle (port of the reference path) on the host cores: conv stack + decode + filter + NMS on `sample` images.  The ONLY
+    place bench.py touches `oracle/`: a reported baseline beside the GPU number, never part of a GPU leg."""
+    import torch
     from oracle import darknet as odark
     from oracle import detect as odet
     from oracle import head as ohead
-    from oracle import synth
+    import bench_data
     cores = os.cpu_count() or 1
-    x = synth.images(min(sample, 16), size, seed=1).repeat((sample + 15) // 16, 1, 1, 1)[:sample]
+    x = bench_data.images(min(sample, 16), size, seed=1).repeat((sample + 15) // 16, 1, 1, 1)[:sample]
     with torch.no_grad():
-        # pick the thread count that serves the oracle best on this host (oneDNN degrades when oversubscribed)
-        best = (1e30, cores)
+        best = (1e30, cores)          # the thread count that serves the oracle best on this host (oneDNN degrades when oversubscribed)
         for th in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}):
             torch.set_num_threads(th)
-            odark.forward(x[:2], sd)  # warm-up
+            odark.forward(x[:2], sd)
             t0 = time.perf_counter()
             odark.forward(x[:2], sd)
             best = min(best, (time.perf_counter() - t0, th))
         torch.set_num_threads(best[1])
         t0 = time.perf_counter()
         for i0 in range(0, sample, 16):
-            xb = x[i0:i0 + 16]
-            feat = odark.forward(xb, sd)
+            feat = odark.forward(x[i0:i0 + 16], sd)
             pred = ohead.decode(feat, anchors)
             B = feat.shape[0]
             prob = torch.softmax(pred['logits'], -1).view(B, -1, pred['logits'].shape[-1]).numpy()
@@ -91,233 +448,119 @@ def cpu_baseline(sd, anchors, size, sample):
                 odet.postprocess(iou[b], mn[b], mx[b], prob[b], fix=True)
         dt = time.perf_counter() - t0
     return {'value': round(sample / dt, 3), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d synthetic %dx%d images in batches of 16, oracle conv stack (torch-CPU fp32, best of %d/%d/%d/%d threads) + decode + filter(fix=1) + NMS, %.1f s' % (sample, size, size, cores, cores // 2, cores // 4, cores // 8, dt)}
+            'sample': '%d synthetic %dx%d images in batches of 16, oracle conv stack (torch-CPU fp32, best of %d/%d/%d/%d threads) + decode + filter(fix=1) + NMS, %.1f s'
+                      % (sample, size, size, cores, cores // 2, cores // 4, cores // 8, dt)}
 
 
-def train_leg(args, dev, world, rank, barrier):
-    """BASELINE configs[2]: Darknet-19 VOC-20 training step at 416x416, per-GPU batch 64: forward (batch-stat BN) + region
-    loss + backward + SGD(lr 1e-3, momentum 0.9) (quick_start.sh:71).  N > 1: data parallel, gradients averaged with bucketed
-    RCCL all-reduce overlapped with backward (train.DataParallelRCCL), weak scaling."""
+# ---------------------------------------------------------------------------------------------------- dry run (no GPU)
+def dry_run(args, ctx):
+    """Stand-in CPU workload so that launch, rendezvous, the DP wrapper and the timing protocol can be exercised without a GPU.
+    Nothing of the hot path runs here (it has no CPU fallback): the printed numbers are meaningless and flagged as such."""
+    import torch
+    import torch.nn as nn
+
     import train as y2train
-    from oracle import loss as oloss
-    from oracle import synth
-    inf, anchors, sd = build_model(args.classes, dev, args.model)
-    del sd
-    inf.train()
-    wrapped = y2train.ensure_model(inf)
-    import utils
-    opt = utils.optim.SGD(wrapped.parameters(), 1e-3, momentum=0.9)      # fused multi-tensor step (y2_opt_sgd), torch.optim.SGD semantics
-    B, S = args.train_batch, args.size
-    data = {k: v.to(dev) for k, v in synth.labels(B, S, args.classes, seed=2 + rank).items()}
-    data['tensor'] = synth.images(B, S, seed=11 + rank).to(dev)
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(64, 256), nn.Tanh(), nn.Linear(256, 64))
+    m = y2train.ensure_model(net)
+    opt = torch.optim.SGD(m.parameters(), 1e-3, momentum=0.9)
+    x = torch.randn(args.train_batch, 64)
 
-    def step():
-        return y2train.iterate(wrapped, opt, data, oloss.HPARAM, 0.6, anchors)
+    def train_step(i):
+        opt.zero_grad()
+        m(x).pow(2).mean().backward()
+        opt.step()
 
-    for _ in range(2):
-        r = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.train_steps):
-        r = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = t.item()
-    per_img = 87.78e9 * (S / 416.0) ** 2 if args.model == 'darknet' else 3 * 60.85e9 * (S / 608.0) ** 2   # SURVEY.md 8d: fwd + wgrad + dgrad
-    flops = per_img * B * args.train_steps * world
-    out = {'metric': 'images/sec (%dx%d) train, %s YOLOv2 %d classes' % (S, S, 'Darknet-19' if args.model == 'darknet' else args.model, args.classes), 'value': round(B * args.train_steps * world / dt, 2), 'unit': 'images/sec',
-           'ms_per_step': round(dt / args.train_steps * 1e3, 3), 'steps': args.train_steps, 'per_gpu_batch': B, 'global_batch': B * world,
-           'parallelism': 'dp%d (RCCL all-reduce, bucketed, overlapped with backward)' % world if world > 1 else 'single GPU',
-           'optimizer': 'utils.optim.SGD(lr=1e-3, momentum=0.9): fused multi-tensor HIP kernel, torch.optim.SGD semantics', 'loss_total': float(r['loss_total'].detach()),
-           'conv_tflops': round(flops / dt / 1e12 / world, 2), 'conv_frac_of_fp32_mfma_peak': round(flops / dt / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4)}
-    del wrapped, opt, inf
-    torch.cuda.empty_cache()
-    return out
+    def detect_step(i):
+        with torch.no_grad():
+            net(x)
+    for i in range(args.warmup):
+        train_step(i)
+    dt_t, _ = ctx.timed(train_step, args.steps)
+    dt_d, _ = ctx.timed(detect_step, args.steps)
+    wrapped = type(m).__name__
+    return {'images_per_sec': round(args.train_batch * args.steps * ctx.world / dt_t, 2), 'ms_per_step': round(dt_t / args.steps * 1e3, 4), 'wrapper': wrapped}, \
+           {'images_per_sec': round(args.train_batch * args.steps * ctx.world / dt_d, 2), 'ms_per_step': round(dt_d / args.steps * 1e3, 4)}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch')
-    ap.add_argument('--size', type=int, default=416)
-    ap.add_argument('--classes', type=int, default=20)
-    ap.add_argument('--mode', default='detect', choices=['detect', 'forward'])
-    ap.add_argument('--model', default='darknet', help="darknet (default, BASELINE configs[1]) or a model.resnet plugin name, e.g. resnet50 (configs[4] forward: --size 608 --classes 80)")
-    ap.add_argument('--no-direct-leg', action='store_true', help='skip the extra Winograd-off measurement (roofline.direct_only)')
-    ap.add_argument('--no-graph', action='store_true', help='launch the detect step eagerly instead of replaying a captured hipGraph')
-    ap.add_argument('--train-steps', type=int, default=6, help='extra leg: timed training steps (fwd + region loss + bwd + SGD), 0 = skip')
-    ap.add_argument('--settle', type=float, default=2.0, help='seconds of idle between the inference legs and the training leg (outside every timed region)')
-    ap.add_argument('--train-batch', type=int, default=64, help='per-GPU batch of the training leg (BASELINE configs[2])')
-    ap.add_argument('--cpu-sample', type=int, default=192, help='images for the CPU baseline (0 = skip)')
-    args = ap.parse_args()
+    args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    ctx = Ctx(args)
+    torch = ctx.torch
+    if ctx.world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or let bench.py launch the ranks itself)' % (args.gpus, ctx.world, args.gpus))
+    if ctx.ranks_seen != ctx.world:
+        raise SystemExit('bench.py: all-reduce of ones saw %d ranks, expected %d' % (ctx.ranks_seen, ctx.world))
+    headline = args.headline if args.headline != 'auto' else ('detect' if ctx.world == 1 else 'train')
+    label = {'darknet': 'Darknet-19', 'tiny': 'tiny-yolo'}.get(args.model, args.model)
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    if world > 1:
-        import train as y2train
-        y2train.init_distributed()                      # backend "nccl" == RCCL on ROCm, one process per GPU
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if args.dry_run:
+        tr, de = dry_run(args, ctx)
+        if ctx.rank == 0:
+            src = tr if headline == 'train' else de
+            print(json.dumps({'metric': 'DRY RUN (stand-in CPU workload, launch/rendezvous/DP-wrapper/timing protocol only)', 'value': src['images_per_sec'], 'unit': 'images/sec',
+                              'n_gpus': ctx.world, 'ranks_seen': ctx.ranks_seen, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': src['ms_per_step'],
+                              'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'dry_run': True, 'valid': False,
+                              'headline': headline, 'config': {'workload': 'none: 2-layer CPU MLP stand-in'}, 'train': tr, 'detect': de}))
+        if ctx.world > 1:
+            ctx.dist.destroy_process_group()
+        return
+    assert ctx.gpu, 'bench.py needs an MI355X (use --dry-run to exercise the launch path without one)'
 
-    import detect
-    from oracle import synth
-    inf, anchors, sd = build_model(args.classes, dev, args.model)
-    dnn = inf.dnn
-    if args.model != 'darknet':
-        args.cpu_sample = 0
-    x = synth.images(args.batch, args.size, seed=1 + rank).to(dev)   # resident in HBM before timing
-
-    def step():
-        with torch.no_grad():
-            feat = dnn.forward_nhwc(x)
-            if args.mode == 'detect':
-                return detect.detect_batch(feat, anchors, fix=True, threshold_cls=0.005, overlap=0.45, limit=200)
-            return feat
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    import _hip
-
-    def conv_chain_rate(prof):
-        """(executed TF/s, direct-equivalent TF/s, chain ms/step, conv0 ms/step, Winograd layer count, flops/step, executed flops/step)"""
-        fl = fl_exec = ms = ms0 = 0.0
-        n_launch = n_wino = 0
-        for rec in prof:
-            name, flops, e0, e1 = rec[:4]
-            d = e0.elapsed_time(e1)
-            if name.startswith('conv_fwd'):
-                fl += flops
-                fl_exec += rec[4] if len(rec) > 4 else flops
-                n_wino = rec[5] if len(rec) > 5 else 0
-                ms += d
-                n_launch += 1
-            else:
-                ms0 += d
-        n = max(1, n_launch)
-        rate = lambda f: f / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        return rate(fl_exec), rate(fl), ms / n, ms0 / n, n_wino, fl / n, fl_exec / n
-
-    def measure(steps, warmup):
-        """W untimed warm-up steps, a roofline leg (eager steps, one HIP event pair around the conv chain each: events cannot
-        be queried inside a graph), then EXACTLY `steps` timed steps (hipGraph replay) between barrier + synchronize."""
-        for _ in range(warmup):
-            step()
-        barrier()
-        dnn.profile = []
-        for _ in range(min(steps, 10)):
-            step()
-        barrier()
-        prof, dnn.profile = dnn.profile, None
-        graphed = None
-        if not args.no_graph and args.mode == 'detect':
-            try:
-                graphed = detect.GraphedDetector(dnn, anchors, x, fix=True, threshold_cls=0.005, overlap=0.45, limit=200)
-            except Exception as e:   # capture not possible -> eager launches
-                print('hipGraph capture failed (%s); eager launches' % e, file=sys.stderr)
-                graphed = None
-        run = (lambda: graphed.run()) if graphed is not None else step
-        for _ in range(2):
-            run()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            run()
-        host_dt = time.perf_counter() - t0
-        barrier()
-        dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return t.item(), host_dt, prof, graphed is not None
-
-    dt, host_dt, prof, was_graphed = measure(args.steps, args.warmup)
-    executed, direct_equiv, chain_ms, conv0_ms, n_wino, fl_step, fl_exec_step = conv_chain_rate(prof)
-
-    # second leg, reported beside the metric: the same step with the Winograd algorithm disabled = pure implicit-GEMM
-    # convolutions (executed == algorithmic multiply-adds), the conv-MFMA roofline fraction north_star asks for
-    direct_leg = None
-    if _hip.WINOGRAD and args.model == 'darknet' and not args.no_direct_leg:      # rank-independent condition: every rank runs the same barriers
-        _hip.WINOGRAD = False
-        dnn._plan_cache = None
+    det = roof = state = anchors = None
+    if not args.no_detect:
+        det, roof, state, anchors = detect_leg(args, ctx)
+    conv3 = None
+    if ctx.world == 1 and args.model == 'darknet' and not args.no_conv3:
         try:
-            ddt, _, dprof, _ = measure(min(args.steps, 10), 2)
-            dex, _, dchain, _, _, _, _ = conv_chain_rate(dprof)
-            direct_leg = {'images_per_sec': round(args.batch * min(args.steps, 10) * world / ddt, 2), 'achieved': round(dex, 2),
-                          'frac': round(dex / PEAK_FP32_MFMA_TFLOPS, 4), 'conv_chain_ms_per_step': round(dchain, 4),
-                          'note': 'Y2_WINOGRAD=0: every 3x3 layer through the implicit-GEMM MFMA kernel'}
+            conv3 = conv3x3_leg(args, ctx)
         except Exception as e:
             import traceback
             traceback.print_exc()
-            direct_leg = {'error': '%s: %s' % (type(e).__name__, e)}
-        finally:
-            _hip.WINOGRAD = True
-            dnn._plan_cache = None
-
-    train_out = None
-    if args.train_steps > 0:
-        torch.cuda.synchronize()
-        time.sleep(args.settle)          # untimed pause between the inference legs and the training leg (see DESIGN.md 5)
+            conv3 = {'error': '%s: %s' % (type(e).__name__, e)}
+    tr = None
+    if not args.no_train:
+        ctx.sync()
+        time.sleep(args.settle)          # untimed pause between the inference legs and the training leg (DESIGN.md 5)
         try:
-            train_out = train_leg(args, dev, world, rank, barrier)
-        except Exception as e:           # the extra leg must not take the headline metric down with it
+            tr = train_leg(args, ctx)
+        except Exception as e:
+            if headline == 'train':
+                raise
             import traceback
             traceback.print_exc()
-            train_out = {'error': '%s: %s' % (type(e).__name__, e)}
-    traffic = None
-    try:   # HBM-side bytes per step of the same kernel family from the committed rocprofv3 PMC passes (separate runs)
-        import glob
-        tf = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_detect_b32_traffic.json')) if '_direct_' not in os.path.basename(f))
-        if tf and args.batch == 32 and args.size == 416 and args.model == 'darknet':
-            traffic = json.load(open(tf[-1]))['traffic_bytes_per_step']
-        tfd = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_direct_detect_b32_traffic.json')))
-        if direct_leg is not None and 'error' not in direct_leg and tfd and args.batch == 32 and args.size == 416 and args.model == 'darknet':
-            direct_leg['traffic'] = json.load(open(tfd[-1]))['traffic_bytes_per_step']
-    except Exception:
-        traffic = None
-    if rank == 0:
-        images = args.batch * args.steps * world
-        out = {
-            'metric': 'images/sec (416x416) detect, Darknet-19 YOLOv2',
-            'value': round(images / dt, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic', 'launch': 'hipGraph replay' if was_graphed else 'eager', 'host_ms_per_step': round(host_dt / args.steps * 1e3, 4),
-            'config': {'model': args.model, 'workload': 'Darknet-19 YOLOv2 %dx%d batch-%d/GPU inference: conv stack + decode + filter + NMS (BASELINE configs[1])'
-                                   % (args.size, args.size, args.batch) if args.mode == 'detect' else
-                                   'Darknet-19 YOLOv2 %dx%d batch-%d/GPU conv stack only' % (args.size, args.size, args.batch),
-                       'classes': args.classes, 'global_batch': args.batch * world, 'parallelism': 'replicas x%d (no collective)' % world,
-                       'weights': 'random-init seed 0'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_fwd_dma_kernel family (fp32 MFMA GEMMs: implicit-GEMM direct convs + the grouped GEMMs of the Winograd layers, with their transform kernels; the 22-layer chain timed as one event pair per step, inter-launch gaps included)',
-                         'achieved': round(direct_equiv, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(direct_equiv / PEAK_FP32_MFMA_TFLOPS, 4),
-                         'definition': 'ALGORITHMIC conv FLOPs (SURVEY.md 8d: 2*Cin*Cout*k*k*H*W per layer, 29.061 GFLOP/img) / measured chain time; it may exceed 1 because %d layers run Winograd F(2x2,3x3), which executes 16/36 of those multiply-adds' % n_wino,
-                         'mfma_executed_tflops': round(executed, 2), 'mfma_utilisation': round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
-                         'winograd_layers': n_wino, 'executed_flops_per_step': fl_exec_step,
-                         'flops_per_step': fl_step, 'ms_per_step': round(chain_ms, 4),
-                         'conv0_ms_per_step': round(conv0_ms, 4), 'traffic': traffic,
-                         'traffic_note': 'bytes per step (conv chain) from rocprofv3 PMC FETCH_SIZE(x2, gfx950 correction)+WRITE_SIZE, profiles/; L2 memory-side requests incl. Infinity-Cache hits',
-                         'direct_only': direct_leg},
-        }
-        if train_out is not None:
-            out['train'] = train_out
-        if world == 1 and args.cpu_sample > 0:
+            tr = {'error': '%s: %s' % (type(e).__name__, e)}
+    if ctx.rank == 0:
+        det_workload = '%s YOLOv2 %dx%d batch-%d/GPU inference: conv stack + decode + filter + NMS (BASELINE configs[1])' % (label, args.size, args.size, args.batch)
+        tr_workload = '%s YOLOv2 %d-class train %dx%d batch-%d/GPU: fwd + region loss + bwd + SGD (BASELINE configs[2])' % (label, args.classes, args.size, args.size, args.train_batch)
+        if headline == 'train':
+            value, ms, steps, workload = tr['images_per_sec'], tr['ms_per_step'], tr['steps'], tr_workload
+            metric = 'images/sec (%dx%d) train, %s YOLOv2, data parallel' % (args.size, args.size, label)
+        else:
+            value, ms, steps, workload = det['images_per_sec'], det['ms_per_step'], det['steps'], det_workload
+            metric = 'images/sec (%dx%d) detect, %s YOLOv2' % (args.size, args.size, label)
+        out = {'metric': metric, 'value': value, 'unit': 'images/sec', 'n_gpus': ctx.world, 'ranks_seen': ctx.ranks_seen, 'steps': steps, 'warmup': args.warmup,
+               'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'headline': headline,
+               'config': {'workload': workload, 'classes': args.classes, 'global_batch': (args.train_batch if headline == 'train' else args.batch) * ctx.world,
+                          'parallelism': (tr if headline == 'train' else det)['parallelism'], 'weights': 'random-init seed 0 (bench_data.randomize)'}}
+        if roof is not None:
+            out['roofline'] = roof
+        if conv3 is not None:
+            out['conv3x3_b64'] = conv3
+        if det is not None:
+            out['detect'] = dict(det, workload=det_workload)
+        if tr is not None:
+            out['train'] = dict(tr, workload=tr_workload)
+        if state is not None:
             try:
-                out['cpu_baseline'] = cpu_baseline(sd, anchors, args.size, args.cpu_sample)
+                out['cpu_baseline'] = cpu_baseline(state, anchors, args.size, args.cpu_sample)
             except Exception as e:
                 out['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    if ctx.world > 1:
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == '__main__':

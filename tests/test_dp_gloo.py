@@ -192,3 +192,25 @@ def test_norm_data():
     d = dict(yx_min=torch.tensor([[[104.0, 208.0]]]), yx_max=torch.tensor([[[416.0, 416.0]]]), cls=torch.tensor([[3]]))
     n = train.norm_data(d, 416, 416, 13, 13)
     assert n['yx_min'].tolist() == [[[3.25, 6.5]]] and n['yx_max'].tolist() == [[[13.0, 13.0]]] and n['cls'] is d['cls']
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launches_ranks_dry_run():
+    """`python bench.py --gpus 2` without a launcher must spawn the two ranks itself (torch.distributed.run, 127.0.0.1), rendezvous,
+    all-reduce `ranks_seen`, run the DP wrapper and print ONE JSON line on rank 0.  --dry-run swaps the GPU hot path (which has no
+    CPU fallback) for a stand-in CPU workload and flags the line as invalid: this test is about the launch protocol only."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '3', '--warmup', '1'],
+                         capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['ranks_seen'] == 2 and rec['dry_run'] is True and rec['valid'] is False
+    assert rec['headline'] == 'train' and rec['train']['wrapper'] == 'DataParallelRCCL' and rec['steps'] == 3
+    # a world size that contradicts --gpus is refused, not silently accepted
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '1'],
+                         capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'))
+    assert bad.returncode != 0 and 'WORLD_SIZE=1' in (bad.stderr + bad.stdout)

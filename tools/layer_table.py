@@ -16,8 +16,7 @@ for p in (ROOT, os.path.join(ROOT, 'yolo2-pytorch_amd')):
 import torch  # noqa: E402
 
 import _hip  # noqa: E402
-import bench  # noqa: E402
-from oracle import synth  # noqa: E402
+import bench_data  # noqa: E402
 
 TILES = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x64', 5: '64x128', 6: '128x32'}
 
@@ -29,9 +28,9 @@ def main():
     ap.add_argument('--reps', type=int, default=10)
     args = ap.parse_args()
     dev = torch.device('cuda:0')
-    inf, anchors, sd = bench.build_model(20, dev, 'darknet')
+    inf, anchors = bench_data.build_model(20, dev, 'darknet')
     dnn = inf.dnn
-    x = synth.images(args.batch, args.size, seed=1).to(dev)
+    x = bench_data.images(args.batch, args.size, seed=1).to(dev)
     with torch.no_grad():
         for _ in range(2):
             dnn.forward_nhwc(x)

@@ -52,22 +52,27 @@ def filter_visible(config, iou, yx_min, yx_max, prob):
     return (iou[0][idx], yx_min.view(-1, 2)[idx], yx_max.view(-1, 2)[idx], prob.view(-1, C)[idx], prob_cls[0][idx], cls[0][idx].long())
 
 
+def _expand_classes(iou, yx_min, yx_max, prob, threshold_cls):
+    """The `fix` branch of detect.py:73-77: every (kept box, class) pair whose score = iou * prob exceeds the class threshold becomes
+    a detection, in row-major (box, class) order.  Returns (yx_min, yx_max, cls, score) of the pairs."""
+    score = iou.unsqueeze(-1) * prob
+    box, cls = (score > threshold_cls).nonzero(as_tuple=True)
+    return yx_min[box], yx_max[box], cls, score[box, cls]
+
+
 def postprocess(config, iou, yx_min, yx_max, prob):
-    """detect.py:66-80, one image.  Returns (iou, yx_min, yx_max, cls, score) or None."""
+    """detect.py:66-80, one image: visibility filter -> NMS on objectness -> per-class expansion (`[detect] fix`) or arg-max class.
+    Returns (iou, yx_min, yx_max, cls, score) or None when nothing survives."""
     iou, yx_min, yx_max, prob, prob_cls, cls = filter_visible(config, iou, yx_min, yx_max, prob)
     keep = utils.postprocess.nms(iou, yx_min, yx_max, config.getfloat('detect', 'overlap'))
-    if keep:
-        keep = torch.tensor(keep, dtype=torch.long, device=iou.device)
-        iou, yx_min, yx_max, prob, prob_cls, cls = (t[keep] for t in (iou, yx_min, yx_max, prob, prob_cls, cls))
-        if config.getboolean('detect', 'fix'):
-            score = torch.unsqueeze(iou, -1) * prob
-            mask = score > config.getfloat('detect', 'threshold_cls')
-            indices, cls = torch.unbind(mask.nonzero(), -1)
-            yx_min, yx_max = (t[indices] for t in (yx_min, yx_max))
-            score = score[mask]
-        else:
-            score = iou
+    if not keep:
+        return None
+    keep = torch.tensor(keep, dtype=torch.long, device=iou.device)
+    iou, yx_min, yx_max, prob, cls = iou[keep], yx_min[keep], yx_max[keep], prob[keep], cls[keep]
+    if config.getboolean('detect', 'fix'):
+        yx_min, yx_max, cls, score = _expand_classes(iou, yx_min, yx_max, prob, config.getfloat('detect', 'threshold_cls'))
         return iou, yx_min, yx_max, cls, score
+    return iou, yx_min, yx_max, cls, iou
 
 
 def detect_batch(feature_nhwc, anchors, fix=False, threshold=0.3, threshold_cls=0.005, overlap=0.45, limit=200):
@@ -103,10 +108,8 @@ def postprocess_batch(d, fix=False, threshold_cls=0.005):
         src = d['index'][b].long()[d['keep'][b, :counts[b]].long()]
         _iou, _mn, _mx, _prob = iou[b][src], mn[b][src], mx[b][src], prob[b][src]
         if fix:
-            score = _iou.unsqueeze(-1) * _prob
-            mask = score > threshold_cls
-            indices, cls = torch.unbind(mask.nonzero(), -1)
-            out.append((_iou, _mn[indices], _mx[indices], cls, score[mask]))
+            e_mn, e_mx, cls, score = _expand_classes(_iou, _mn, _mx, _prob, threshold_cls)
+            out.append((_iou, e_mn, e_mx, cls, score))
         else:
             out.append((_iou, _mn, _mx, d['cls'].view(B, n)[b][src].long(), _iou))
     return out
@@ -116,10 +119,13 @@ class GraphedDetector(object):
     """hipGraph capture of the whole device-resident detect step (conv stack + decode + filter + NMS, ~30 launches) for a
     fixed input shape: one graph launch per batch instead of ~30 kernel launches and ~40 tensor allocations from Python.
     `run(x)` copies x into the static input buffer, replays the graph and returns the static result dict (overwritten
-    by the next run)."""
+    by the next run).  `static_input=True` captures on `example` itself (no private copy): `run()` then re-reads that tensor.
+    The graph bakes in the pointers of the packed / folded weights: after the parameters change (optimizer step, load_state_dict,
+    a training forward) a replay would use stale weights, so `run` checks the plugin's cache key and refuses."""
 
-    def __init__(self, dnn, anchors, example, fix=True, threshold=0.3, threshold_cls=0.005, overlap=0.45, limit=200, warmup=2):
-        self.static_x = example.clone()
+    def __init__(self, dnn, anchors, example, fix=True, threshold=0.3, threshold_cls=0.005, overlap=0.45, limit=200, warmup=2, static_input=False):
+        self.static_x = example if static_input else example.clone()
+        self.dnn = dnn
         kw = dict(fix=fix, threshold=threshold, threshold_cls=threshold_cls, overlap=overlap, limit=limit)
 
         def step():
@@ -135,8 +141,11 @@ class GraphedDetector(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.result = step()
+        self._versions = dnn._versions()
 
     def run(self, x=None):
+        if self.dnn._versions() != self._versions:
+            raise RuntimeError('GraphedDetector: the parameters changed since capture (the graph holds the old packed weights); capture a new one')
         if x is not None and x.data_ptr() != self.static_x.data_ptr():
             self.static_x.copy_(x)
         self.graph.replay()

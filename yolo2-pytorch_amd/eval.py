@@ -9,23 +9,23 @@ import utils.iou.torch
 
 
 def _matching(positive, index):
-    """eval.py:57-64: greedy true-positive assignment, each ground-truth box is detected at most once."""
-    detected = set()
-    tp = np.zeros([len(positive)], bool)
-    for i, (positive, index) in enumerate(zip(positive, index)):
-        if positive and index not in detected:
+    """eval.py:57-64: walking the predictions in descending-score order, a prediction is a true positive when it overlaps a
+    ground-truth box enough (`positive`) and that box (`index`) has not been claimed by an earlier prediction."""
+    positive, index = np.asarray(positive, bool), np.asarray(index)
+    tp = np.zeros(len(positive), bool)
+    claimed = set()
+    for i in np.flatnonzero(positive):
+        gt = int(index[i])
+        if gt not in claimed:
+            claimed.add(gt)
             tp[i] = True
-            detected.add(index)
     return tp
 
 
 def matching(data_yx_min, data_yx_max, yx_min, yx_max, threshold):
-    """eval.py:67-75: predictions (in descending-score order) vs ground truth of one class in one image."""
-    if data_yx_min.numel() > 0:
-        matrix = utils.iou.torch.iou_matrix(yx_min, yx_max, data_yx_min, data_yx_max)
-        iou, index = torch.max(matrix, -1)
-        positive = iou > threshold
-        tp = _matching(positive.cpu().numpy(), index.cpu().numpy())
-    else:
-        tp = np.zeros([yx_min.size(0)], bool)
-    return tp
+    """eval.py:67-75: predictions of one class in one image (descending score) against that class's ground truth.  The IoU matrix and
+    its row arg-max run on the device (y2_iou_matrix); only two n-vectors cross to the host for the sequential claim loop."""
+    if data_yx_min.numel() == 0:
+        return np.zeros([yx_min.size(0)], bool)
+    best, which = utils.iou.torch.iou_matrix(yx_min, yx_max, data_yx_min, data_yx_max).max(-1)
+    return _matching((best > threshold).cpu().numpy(), which.cpu().numpy())

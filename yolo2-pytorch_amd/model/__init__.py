@@ -15,37 +15,36 @@ import _hip
 
 
 class ConfigChannels(object):
-    """model/__init__.py:29-43: per-layer channel counts follow a checkpoint when one is given (pruned models)."""
+    """Channel-count oracle of the plugin constructors (model/__init__.py:29-43).  Without a checkpoint every layer gets its
+    default width; with one (pruned models, `--finetune`) the width is read off the named tensor - `fn(state_dict[name])`, by
+    default its first dimension.  Stateful: `channels` always holds the width decided last (the next layer's input width;
+    3 = the image planes before the first call)."""
 
     def __init__(self, config, state_dict=None, channels=3):
-        self.config = config
-        self.state_dict = state_dict
-        self.channels = channels
+        self.config, self.state_dict, self.channels = config, state_dict, channels
 
     def __call__(self, default, name, fn=lambda var: var.size(0)):
-        if self.state_dict is None:
-            self.channels = default
-        else:
-            var = self.state_dict[name]
-            self.channels = fn(var)
-            if self.channels != default:
-                logging.warning('%s: change number of output channels from %d to %d' % (name, default, self.channels))
-        return self.channels
+        width = default
+        if self.state_dict is not None:
+            width = fn(self.state_dict[name])
+            if width != default:
+                logging.warning('%s: change number of output channels from %d to %d' % (name, default, width))
+        self.channels = width
+        return width
 
 
 def output_channels(num_anchors, num_cls):
-    """model/__init__.py:46-50."""
-    if num_cls > 1:
-        return num_anchors * (5 + num_cls)
-    else:
-        return num_anchors * 5
+    """Head width (model/__init__.py:46-50): 5 box/objectness rows per anchor plus one row per class when there are several."""
+    return num_anchors * (5 + (num_cls if num_cls > 1 else 0))
 
 
 def meshgrid(rows, cols, swap=False):
-    """model/__init__.py:53-56 (kept for API compatibility; the decode kernel generates the grid itself)."""
-    i = torch.arange(0, rows).repeat(cols).view(-1, 1)
-    j = torch.arange(0, cols).view(-1, 1).repeat(1, rows).view(-1, 1)
-    return torch.cat([i, j], 1) if swap else torch.cat([j, i], 1)
+    """Cell-offset table of the decode (model/__init__.py:53-56): row k is (k // rows, k % rows) - equal to (row, col) of cell k
+    only for square grids, a quirk the decode kernel reproduces - or the two columns exchanged with swap=True.  Kept for API
+    compatibility; y2_decode generates the offsets itself."""
+    k = torch.arange(0, rows * cols)
+    fast, slow = (k % rows).view(-1, 1), torch.div(k, rows, rounding_mode='floor').view(-1, 1)
+    return torch.cat([fast, slow] if swap else [slow, fast], 1)
 
 
 _ANCHOR_CACHE = {}
@@ -122,14 +121,13 @@ def loss(anchors, data, pred, threshold):
     return train_graph.loss(anchors, data, pred, threshold)
 
 
+_PRED_KEYS = ('feature', 'iou', 'center_offset', 'size_norm', 'yx_min', 'yx_max', 'logits')
+
+
 def _inference(inference, tensor):
-    """model/__init__.py:170-179."""
-    feature, iou, center_offset, size_norm, yx_min, yx_max, logits = inference(tensor)
-    pred = dict(
-        feature=feature, iou=iou,
-        center_offset=center_offset, size_norm=size_norm,
-        yx_min=yx_min, yx_max=yx_max,
-    )
-    if logits is not None:
-        pred['logits'] = logits.contiguous()
+    """The head's 7-tuple as the dict train / eval / detect consume (model/__init__.py:170-179); `logits` is absent for
+    single-class models."""
+    pred = {k: v for k, v in zip(_PRED_KEYS, inference(tensor)) if v is not None}
+    if 'logits' in pred:
+        pred['logits'] = pred['logits'].contiguous()
     return pred

@@ -26,93 +26,84 @@ BN_EPS = 1e-5
 
 
 class _Block(nn.Module):
+    """A residual block as data: SPEC lists its convolutions as (kernel, width multiplier, carries the block stride, padding).
+    Attribute names conv<i>/bn<i>/downsample are the reference's state_dict keys (= torchvision's)."""
+    SPEC = ()
+
+    def __init__(self, config_channels, prefix, channels, stride=1):
+        nn.Module.__init__(self)
+        self.stride = stride
+        c_in = config_channels.channels
+        self._convs = []
+        for i, (k, mult, strided, pad) in enumerate(self.SPEC, 1):
+            cin = config_channels.channels
+            cout = config_channels(channels * mult, '%s.conv%d.weight' % (prefix, i))
+            s_i = stride if strided else 1
+            conv, bn = nn.Conv2d(cin, cout, k, s_i, pad, bias=False), nn.BatchNorm2d(cout)
+            setattr(self, 'conv%d' % i, conv)
+            setattr(self, 'bn%d' % i, bn)
+            self._convs.append((conv, bn, s_i, pad))
+        c_out = config_channels.channels
+        self.downsample = None
+        if stride > 1 or c_in != c_out:      # projection shortcut (model/resnet.py:44-50, 86-92)
+            self.downsample = nn.Sequential(nn.Conv2d(c_in, c_out, 1, stride, bias=False), nn.BatchNorm2d(c_out))
+
+    def convs(self):
+        return list(self._convs)
+
     def forward(self, x):
         raise RuntimeError('model.resnet blocks are parameter containers; the network runs through ResNet.forward (HIP)')
 
-    def _downsample(self, channels_in, channels_out, stride):
-        if stride > 1 or channels_in != channels_out:
-            return nn.Sequential(nn.Conv2d(channels_in, channels_out, kernel_size=1, stride=stride, bias=False), nn.BatchNorm2d(channels_out))
-        return None
-
 
 class BasicBlock(_Block):
-    """model/resnet.py:29-62."""
-
-    def __init__(self, config_channels, prefix, channels, stride=1):
-        nn.Module.__init__(self)
-        channels_in = config_channels.channels
-        self.stride = stride
-        self.conv1 = nn.Conv2d(config_channels.channels, config_channels(channels, '%s.conv1.weight' % prefix), 3, stride, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(config_channels.channels)
-        self.conv2 = nn.Conv2d(config_channels.channels, config_channels(channels, '%s.conv2.weight' % prefix), 3, 1, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(config_channels.channels)
-        self.downsample = self._downsample(channels_in, config_channels.channels, stride)
-
-    def convs(self):
-        return [(self.conv1, self.bn1, self.stride, 1), (self.conv2, self.bn2, 1, 1)]
+    """model/resnet.py:29-62: 3x3 (strided) -> 3x3."""
+    SPEC = ((3, 1, True, 1), (3, 1, False, 1))
 
 
 class Bottleneck(_Block):
-    """model/resnet.py:65-104."""
-
-    def __init__(self, config_channels, prefix, channels, stride=1):
-        nn.Module.__init__(self)
-        channels_in = config_channels.channels
-        self.stride = stride
-        self.conv1 = nn.Conv2d(config_channels.channels, config_channels(channels, '%s.conv1.weight' % prefix), kernel_size=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(config_channels.channels)
-        self.conv2 = nn.Conv2d(config_channels.channels, config_channels(channels, '%s.conv2.weight' % prefix), kernel_size=3, stride=stride, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(config_channels.channels)
-        self.conv3 = nn.Conv2d(config_channels.channels, config_channels(channels * 4, '%s.conv3.weight' % prefix), kernel_size=1, bias=False)
-        self.bn3 = nn.BatchNorm2d(config_channels.channels)
-        self.downsample = self._downsample(channels_in, config_channels.channels, stride)
-
-    def convs(self):
-        return [(self.conv1, self.bn1, 1, 0), (self.conv2, self.bn2, self.stride, 1), (self.conv3, self.bn3, 1, 0)]
+    """model/resnet.py:65-104: 1x1 -> 3x3 (strided) -> 1x1 (4x wide)."""
+    SPEC = ((1, 1, False, 0), (3, 1, True, 1), (1, 4, False, 0))
 
 
 class ResNet(nn.Module):
     """model/resnet.py:107-159."""
+    STAGES = ((64, 1), (128, 2), (256, 2), (512, 2))       # (width, stride of the first block) of layer1..layer4
 
     def __init__(self, config_channels, anchors, num_cls, block, layers):
         nn.Module.__init__(self)
-        self.conv1 = nn.Conv2d(config_channels.channels, config_channels(64, 'conv1.weight'), kernel_size=7, stride=2, padding=3, bias=False)
+        c_in = config_channels.channels
+        self.conv1 = nn.Conv2d(c_in, config_channels(64, 'conv1.weight'), kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(config_channels.channels)
-        self.layer1 = self._make_layer(config_channels, 'layer1', block, 64, layers[0])
-        self.layer2 = self._make_layer(config_channels, 'layer2', block, 128, layers[1], stride=2)
-        self.layer3 = self._make_layer(config_channels, 'layer3', block, 256, layers[2], stride=2)
-        self.layer4 = self._make_layer(config_channels, 'layer4', block, 512, layers[3], stride=2)
+        for li, ((width, stride), count) in enumerate(zip(self.STAGES, layers), 1):
+            name = 'layer%d' % li
+            blocks = [block(config_channels, '%s.%d' % (name, bi), width, stride if bi == 0 else 1) for bi in range(count)]
+            setattr(self, name, nn.Sequential(*blocks))
         self.conv = nn.Conv2d(config_channels.channels, model.output_channels(len(anchors), num_cls), 1)
-        for m in self.modules():
+        for m in self.modules():       # model/resnet.py:120-126
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight)
             elif isinstance(m, nn.BatchNorm2d):
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
         self._cache = None
         self._plan_cache = None
         self.profile = None
         self.grad_ready_hook = None   # train.DataParallelRCCL: called as hook(param, grad) from inside backward
 
-    def _make_layer(self, config_channels, prefix, block, channels, blocks, stride=1):
-        layers = [block(config_channels, '%s.%d' % (prefix, 0), channels, stride)]
-        for i in range(1, blocks):
-            layers.append(block(config_channels, '%s.%d' % (prefix, i), channels))
-        return nn.Sequential(*layers)
-
     def scope(self, name):
-        comp = name.split('.')[:-1]
+        """Pruning helper (model/resnet.py:142-156): the block-level scope of a parameter name - 'layer1.0.conv2.weight' ->
+        'layer1.0.2', 'layer2.0.downsample.0.weight' -> 'layer2.0', 'conv.weight' -> 'conv'."""
         import re
-        try:
-            comp[-1] = re.search(r'[(conv)|(bn)](\d+)', comp[-1]).group(1)
-        except AttributeError:
-            if len(comp) > 1:
-                if comp[-2] == 'downsample':
-                    comp = comp[:-1]
-                else:
-                    assert False, name
-            else:
-                assert comp[-1] == 'conv', name
+        comp = name.split('.')[:-1]
+        m = re.search(r'[(conv)|(bn)](\d+)', comp[-1])
+        if m is not None:
+            comp[-1] = m.group(1)
+        elif len(comp) > 1:
+            if comp[-2] != 'downsample':
+                raise ValueError('unexpected parameter name %s' % name)
+            comp = comp[:-1]
+        elif comp[-1] != 'conv':
+            raise ValueError('unexpected parameter name %s' % name)
         return '.'.join(comp)
 
     # ------------------------------------------------------------------ preparation: packed weights + folded BN

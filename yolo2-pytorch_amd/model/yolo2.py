@@ -56,69 +56,79 @@ class _Pool(nn.Module):
         raise RuntimeError('pooling is fused into the producing convolution')
 
 
+POOL = 'pool'
+# Darknet-19 as data: per stage a list of POOL markers and (kernel, e, halved) entries whose width is (base << e) // (2 if halved
+# else 1) with base = int(32 * ratio).  The order of the entries IS the order in which ConfigChannels is consulted (it is stateful:
+# each call also sets the next layer's input width), and a layer's name is '<stage>.<position in the stage list>' - both are part
+# of the checkpoint contract of the reference's plugin (model/yolo2.py:76-113).
+_STAGE1 = [(3, 0, False), POOL, (3, 1, False), POOL,
+           (3, 2, False), (1, 2, True), (3, 2, False), POOL,
+           (3, 3, False), (1, 3, True), (3, 3, False), POOL,
+           (3, 4, False), (1, 4, True), (3, 4, False), (1, 4, True), (3, 4, False)]
+_STAGE2 = [POOL, (3, 5, False), (1, 5, True), (3, 5, False), (1, 5, True), (3, 5, False), (3, 5, False), (3, 5, False)]
+
+
+def _build_stage(config_channels, prefix, spec, base, bn):
+    mods = []
+    for entry in spec:
+        if entry is POOL:
+            mods.append(_Pool())
+            continue
+        k, e, halved = entry
+        width = (base << e) // (2 if halved else 1)
+        cin = config_channels.channels
+        cout = config_channels(width, '%s.%d.conv.weight' % (prefix, len(mods)))
+        mods.append(Conv2d(cin, cout, k, bn=bn, padding=(k == 3)))
+    return nn.Sequential(*mods)
+
+
+def _init_reference(net, conv_init):
+    """Initialisation of the reference plugins (model/yolo2.py:117-123, :165-171): conv weights by `conv_init`, BN gamma 1 / beta 0."""
+    for m in net.modules():
+        if isinstance(m, nn.Conv2d):
+            conv_init(m.weight)
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+
+
 class Darknet(nn.Module):
     def __init__(self, config_channels, anchors, num_cls, stride=2, ratio=1):
         nn.Module.__init__(self)
-        assert stride == 2
+        if stride != 2:
+            raise ValueError('the passthrough reorg is implemented for stride 2 (the only value the reference ships)')
         self.stride = stride
-        channels = int(32 * ratio)
-        layers = []
         bn = config_channels.config.getboolean('batch_norm', 'enable')
-        # layers1 — identical construction order to model/yolo2.py:76-96 (ConfigChannels is stateful)
-        for _ in range(2):
-            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-            layers.append(_Pool())
-            channels *= 2
-        for _ in range(2):
-            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-            layers.append(Conv2d(config_channels.channels, config_channels(channels // 2, 'layers1.%d.conv.weight' % len(layers)), 1, bn=bn))
-            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-            layers.append(_Pool())
-            channels *= 2
-        for _ in range(2):
-            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-            layers.append(Conv2d(config_channels.channels, config_channels(channels // 2, 'layers1.%d.conv.weight' % len(layers)), 1, bn=bn))
-        layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers1.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-        self.layers1 = nn.Sequential(*layers)
-
-        layers = []
-        layers.append(_Pool())
-        channels *= 2
-        for _ in range(2):
-            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers2.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-            layers.append(Conv2d(config_channels.channels, config_channels(channels // 2, 'layers2.%d.conv.weight' % len(layers)), 1, bn=bn))
-        for _ in range(3):
-            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers2.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-        self.layers2 = nn.Sequential(*layers)
-
-        self.passthrough = Conv2d(self.layers1[-1].conv.weight.size(0), config_channels(int(64 * ratio), 'passthrough.conv.weight'), 1, bn=bn)
-
-        layers = []
-        layers.append(Conv2d(self.passthrough.conv.weight.size(0) * self.stride * self.stride + self.layers2[-1].conv.weight.size(0), config_channels(int(1024 * ratio), 'layers3.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-        layers.append(Conv2d(config_channels.channels, model.output_channels(len(anchors), num_cls), 1, bn=False, act=False))
-        self.layers3 = nn.Sequential(*layers)
-
+        base = int(32 * ratio)
+        self.layers1 = _build_stage(config_channels, 'layers1', _STAGE1, base, bn)
+        self.layers2 = _build_stage(config_channels, 'layers2', _STAGE2, base, bn)
+        c_route = self.layers1[-1].conv.out_channels          # the 26x26 map both layers2 and the passthrough read
+        c_deep = self.layers2[-1].conv.out_channels
+        c_pass = config_channels(int(64 * ratio), 'passthrough.conv.weight')
+        self.passthrough = Conv2d(c_route, c_pass, 1, bn=bn)
+        c_cat = c_pass * stride * stride + c_deep             # reorg'ed passthrough channels first, then layers2 (model/yolo2.py:129)
+        c_mix = config_channels(int(1024 * ratio), 'layers3.0.conv.weight')
+        self.layers3 = nn.Sequential(Conv2d(c_cat, c_mix, 3, bn=bn, padding=True),
+                                     Conv2d(c_mix, model.output_channels(len(anchors), num_cls), 1, bn=False, act=False))
         self.init()
         self._cache = None  # packed weights / folded BN for eval, keyed on parameter versions
         self._plan_cache = None
         self.grad_ready_hook = None  # set by train.DataParallelRCCL: called as hook(param, grad) inside backward, layer by layer
-        self.profile = None  # bench.py: list receiving (kernel, flops, start_event, end_event) per conv launch
+        self.profile = None  # tools: list receiving (kernel, flops, start_event, end_event) per conv launch
 
     def init(self):
-        """model/yolo2.py:117-123."""
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d):
-                nn.init.kaiming_normal_(m.weight)
-            elif isinstance(m, nn.BatchNorm2d):
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
+        _init_reference(self, nn.init.kaiming_normal_)
 
     def scope(self, name):
-        return '.'.join(name.split('.')[:-2])
+        """Pruning helper (model/yolo2.py:132-133): 'layers1.4.conv.weight' -> 'layers1.4'."""
+        return name.rsplit('.', 2)[0]
 
     def get_mapper(self, index):
-        if index == 94:
-            return lambda indices, channels: torch.cat([indices + i * channels for i in range(self.stride * self.stride)])
+        """Pruning helper (model/yolo2.py:135-137): how channel indices of the passthrough map onto the reorg'ed concat input."""
+        if index != 94:
+            return None
+        copies = self.stride * self.stride
+        return lambda indices, channels: torch.cat([indices + c * channels for c in range(copies)])
 
     # ------------------------------------------------------------------ execution plan
     def _blocks(self):
@@ -335,20 +345,22 @@ class Tiny(Darknet):
 
     def __init__(self, config_channels, anchors, num_cls, channels=16):
         nn.Module.__init__(self)
-        layers = []
         bn = config_channels.config.getboolean('batch_norm', 'enable')
-        for _ in range(5):
-            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-            layers.append(_Pool())
-            channels *= 2
-        layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-        layers.append(_PadPool())
-        layers.append(_PadPool())
-        channels *= 2
-        for _ in range(2):
-            layers.append(Conv2d(config_channels.channels, config_channels(channels, 'layers.%d.conv.weight' % len(layers)), 3, bn=bn, padding=True))
-        layers.append(Conv2d(config_channels.channels, model.output_channels(len(anchors), num_cls), 1, bn=False, act=False))
-        self.layers = nn.Sequential(*layers)
+        # five conv+pool pairs (16..256), conv 512 + the padded stride-1 pool (two entries in the reference's Sequential), two conv 1024, head
+        spec = []
+        for e in range(5):
+            spec += [(3, channels << e), _Pool]
+        spec += [(3, channels << 5), _PadPool, _PadPool, (3, channels << 6), (3, channels << 6)]
+        mods = []
+        for entry in spec:
+            if isinstance(entry, type):
+                mods.append(entry())
+                continue
+            k, width = entry
+            cin = config_channels.channels
+            mods.append(Conv2d(cin, config_channels(width, 'layers.%d.conv.weight' % len(mods)), k, bn=bn, padding=True))
+        mods.append(Conv2d(config_channels.channels, model.output_channels(len(anchors), num_cls), 1, bn=False, act=False))
+        self.layers = nn.Sequential(*mods)
         self.init()
         self._cache = None
         self._plan_cache = None
@@ -356,12 +368,7 @@ class Tiny(Darknet):
         self.profile = None
 
     def init(self):
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d):
-                nn.init.xavier_normal_(m.weight)
-            elif isinstance(m, nn.BatchNorm2d):
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
+        _init_reference(self, nn.init.xavier_normal_)
 
     def _first_block(self):
         return self.layers[0]
