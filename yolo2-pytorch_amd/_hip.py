@@ -203,6 +203,9 @@ if TUNE_CACHE and os.path.exists(TUNE_CACHE):
 
 
 WINOGRAD = os.environ.get('Y2_WINOGRAD', '1') != '0'     # 0: never pick the Winograd F(2x2,3x3) algorithm
+FORCE_ALGO = os.environ.get('Y2_FORCE_ALGO') or None     # 'direct' | 'winograd' | 'fused': no autotune, that algorithm wherever the library accepts it
+if FORCE_ALGO not in (None, 'direct', 'winograd', 'fused'):
+    raise ValueError('Y2_FORCE_ALGO must be direct, winograd or fused (got %r)' % FORCE_ALGO)
 WINO_MIN_CIN = 64                                        # below this the transforms cost more than the GEMM saves (measured)
 
 
@@ -249,6 +252,15 @@ def autotune_conv(params, dev, wino_w=None):
         params.algo, params.tile = algo, tile
         params.w = wino_w.data_ptr() if algo in (1, 2) else w_direct
         return choice
+    if FORCE_ALGO is not None:
+        # deterministic algorithm coverage (tests, A/B runs): every eligible layer takes the named algorithm, everything else the
+        # direct kernel with the library's own tile choice; no measurement, no cache
+        want = {'direct': None, 'winograd': (1, 5), 'fused': (2, 0)}[FORCE_ALGO]
+        if want is not None and wino_ok and (want[0] != 2 or params.Cin % 32 == 0):
+            apply(want)
+            if lib().y2_conv_fwd_workspace_bytes(ctypes.byref(params)) >= 0:
+                return want
+        return apply((0, 0))
     hit = _TUNE.get(key)
     if hit is not None:
         return apply(tuple(hit) if isinstance(hit, (list, tuple)) else (0, hit))
