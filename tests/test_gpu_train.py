@@ -408,6 +408,44 @@ def test_darknet_training_step_matches_oracle_autograd(bn):
     print('worst relative gradient error', worst)
 
 
+@pytest.mark.parametrize('bn', [False, True])
+def test_eval_caches_follow_raw_pointer_writers(bn):
+    """Packed / folded / Winograd-transformed weights are cached per parameter version, but the fused optimizer (and y2_bn_finalize)
+    write parameter memory through raw pointers, invisibly to torch's version counters.  eval -> train step with utils.optim.SGD ->
+    eval must see the NEW weights (with [batch_norm] enable=0 nothing else would invalidate the cache), and a captured
+    GraphedDetector must refuse to replay its stale weights."""
+    import detect
+    import model
+    import utils
+    widths = dict(NARROW)
+    widths['layers1.5'] = 8
+    sd = odark.init_state_dict(5, 20, seed=0, channels=widths, head_scale=1 / 8.0, bn=bn)
+    inf, anchors = build(sd, bn=bn)
+    x = synth.images(2, 96, seed=1)
+    data = synth.norm_data(synth.labels(2, 96, 20, seed=2), 96, 96, 3, 3)
+    inf.eval()
+    with torch.no_grad():
+        f0 = inf.dnn(x.to(dev())).clone()
+    graphed = detect.GraphedDetector(inf.dnn, anchors, x.to(dev()))
+    graphed.run()
+    inf.train()
+    opt = utils.optim.SGD(inf.parameters(), lr=0.05, momentum=0.9)
+    pred = model._inference(inf, x.to(dev()))
+    loss, _ = model.loss(anchors, data, pred, 0.6)
+    opt.zero_grad()
+    sum(loss[k] * oloss.HPARAM[k] for k in loss).backward()
+    opt.step()
+    inf.eval()
+    with torch.no_grad():
+        f1 = inf.dnn(x.to(dev())).clone()
+        now = {k: v.detach().cpu().double() for k, v in inf.dnn.state_dict().items()}
+        ref = odark.forward(x.double(), now)
+    assert rel(f1, ref) <= TOL, rel(f1, ref)               # the updated weights (and running statistics) are what ran
+    assert rel(f0, ref) > 100 * TOL                        # ... and they are not the old ones
+    with pytest.raises(RuntimeError, match='parameters changed'):
+        graphed.run()
+
+
 # ------------------------------------------------------------------ ResNet training path (BASELINE config 5)
 @pytest.mark.parametrize('B,cin,cout,H,W,k,stride,pad', [(2, 16, 32, 19, 19, 3, 2, 1), (2, 32, 64, 20, 20, 1, 2, 0), (1, 4, 64, 32, 40, 7, 2, 3), (2, 64, 64, 10, 10, 3, 2, 1), (2, 8, 16, 9, 9, 3, 1, 1)])
 def test_strided_wgrad_and_transposed_dgrad(B, cin, cout, H, W, k, stride, pad):
