@@ -111,7 +111,7 @@ def _dp_rank(rank, world, port, tmp, sync):
     sum(loss[k] * oloss.HPARAM[k] for k in loss).backward()
     torch.cuda.synchronize()
     torch.save({'loss': {k: v.item() for k, v in loss.items()}, 'positives': int(debug['positive'].sum().item()),
-                'grads': {k: p.grad.cpu() for k, p in inf.named_parameters()},
+                'grads': {k: p.grad.cpu() for k, p in inf.dnn.named_parameters()},
                 'buffers': {k: b.cpu() for k, b in inf.dnn.named_buffers()}}, os.path.join(tmp, 'rank%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
