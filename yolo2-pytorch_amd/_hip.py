@@ -12,7 +12,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libyolo2_hip.so')
+LIB_PATH = os.environ.get('Y2_LIB') or os.path.join(_HERE, 'csrc', 'libyolo2_hip.so')     # Y2_LIB: A/B builds of the same ABI (tools/)
 _lib = None
 
 c_int, c_float, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p

@@ -5,10 +5,10 @@ set -e
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-OUT="$HERE/libyolo2_hip.so"
-OBJ="$HERE/build"
+OUT="${Y2_OUT:-$HERE/libyolo2_hip.so}"          # experiments: Y2_OUT / Y2_OBJ / Y2_EXTRA_FLAGS build an A/B variant beside the product library
+OBJ="${Y2_OBJ:-$HERE/build}"
 mkdir -p "$OBJ"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I$ROOT/include -I$HERE"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I$ROOT/include -I$HERE $Y2_EXTRA_FLAGS"
 pids=()
 for f in "$HERE"/*.hip; do
     o="$OBJ/$(basename "${f%.hip}").o"

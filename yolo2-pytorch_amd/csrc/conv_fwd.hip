@@ -32,6 +32,10 @@
 #include <stdlib.h>
 #include "common.h"
 
+#ifndef Y2_CONV_SPREAD
+#define Y2_CONV_SPREAD 1      // 1: issue the LDS-DMA of slab s+1 between the MFMAs of slab s (see compute_slab_spread); 0: all in front (A/B builds)
+#endif
+
 namespace {
 
 constexpr int BK_DEFAULT = 32;   // floats of K per pipeline step (template parameter BK of the kernel)
@@ -504,6 +508,26 @@ __global__ __launch_bounds__(NTH) void conv_fwd_dma_kernel(const ConvArgs a) {
         }
     };
 
+    // one DMA instruction of a standard slab (piece j < AR: A rows, else B rows): the pieces of slab s+1 can be issued one by one
+    // BETWEEN the MFMAs of slab s (Y2_CONV_SPREAD) instead of all in front of them
+    auto issue_piece = [&](int tap, int c0, int buf, int j) {
+        float* sa = smem + buf * STAGE + wave * (8 * BK);
+        float* sb = sa + BM * BK;
+        const int ky = (a.taps == 9) ? tap / 3 : 0, kx = (a.taps == 9) ? tap % 3 : 0;
+        const bool cok = !CTAIL || (c0 + 4 * lchunk) < a.Cin;
+        if (j < AR) {
+            const unsigned toff = (unsigned)(((ky * a.W + kx) * a.ldx + c0) * 4);
+            const bool ok = (a_mask[j] & (1u << tap)) != 0 && cok;
+            const unsigned voff = ok ? a_base[j] + toff : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + j * RPP * BK), 16, (int)voff, 0, 0, 0);
+        } else {
+            const int i = j - AR;
+            const unsigned woff = (unsigned)((tap * a.Cin + c0) * 4);
+            const unsigned voff = (CTAIL && !cok) ? OOB : b_base[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sb + i * RPP * BK), 16, (int)voff, (int)woff, 0, 0);
+        }
+    };
+
     f32x16 acc[MB][NB];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -539,6 +563,39 @@ __global__ __launch_bounds__(NTH) void conv_fwd_dma_kernel(const ConvArgs a) {
         }
     };
 
+    // compute_slab with the DMA pieces of the NEXT slab spread over the first half of its MFMAs (one piece per MFMA group of
+    // TOTAL/2/NPIECES instructions; the second half of the slab is left for the pieces to land before the next vmcnt(0))
+    auto compute_slab_spread = [&](int buf, int ntap, int nc0, int nbuf) {
+        const float* sbuf = smem + buf * STAGE;
+        constexpr int TOTAL = 16 * MB * NB, NPIECES = AR + BR;
+        constexpr int EVERY = (TOTAL / 2) / NPIECES > 0 ? (TOTAL / 2) / NPIECES : 1;
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 fa4[MB], fb4[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) fa4[i] = *reinterpret_cast<const f32x4*>(sbuf + fa + i * 32 * BK + foff[q]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) fb4[j] = *reinterpret_cast<const f32x4*>(sbuf + fb + j * 32 * BK + foff[q]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa4[i][e], fb4[j][e], acc[i][j], 0, 0, 0);
+                        if (cnt % EVERY == 0 && cnt / EVERY < NPIECES) {
+                            issue_piece(ntap, nc0, nbuf, cnt / EVERY);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        ++cnt;
+                    }
+        }
+        // tiles with fewer MFMAs than pieces in half a slab: the rest goes out behind the last MFMA
+#pragma unroll
+        for (int j = (TOTAL + EVERY - 1) / EVERY; j < NPIECES; ++j) issue_piece(ntap, nc0, nbuf, j);
+    };
+
     const int nk_all = GEN ? (a.K + BK - 1) / BK : a.taps * a.cchunks;
     int ks0 = 0, ks1 = nk_all;
     if (is_split) {
@@ -555,8 +612,12 @@ __global__ __launch_bounds__(NTH) void conv_fwd_dma_kernel(const ConvArgs a) {
                 __syncthreads();                                     // ... everybody's has, and nobody still reads the other buffer
                 c0 += BK;
                 if (c0 >= a.Cin) { c0 = 0; ++tap; }
-                issue_slab(ks0 + ks + 1, tap, c0, (ks + 1) & 1);
-                compute_slab(ks & 1);
+                if (Y2_CONV_SPREAD && !GEN) {
+                    compute_slab_spread(ks & 1, tap, c0, (ks + 1) & 1);
+                } else {
+                    issue_slab(ks0 + ks + 1, tap, c0, (ks + 1) & 1);
+                    compute_slab(ks & 1);
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();

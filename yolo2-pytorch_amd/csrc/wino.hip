@@ -19,6 +19,7 @@
 //      per-channel sum / sum of squares of the raw output (training-mode BatchNorm statistics)
 // Stages 1 and 3 are streaming kernels (HBM/Infinity-Cache bound: V is 4x the input, M is 4x the output).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -26,6 +27,7 @@ namespace {
 struct WinoInArgs {
     const float* x;
     float* v;
+    int32_t* tile_pix;     // optional [T]: output pixel index (b*H + 2*ty)*W + 2*tx of tile t | (2*ty+1 < H) << 30 | (2*tx+1 < W) << 31
     int B, H, W, Cin, ldx, th, tw, T, c4n;
     y2_fastdiv d_c4, d_tt, d_tw;
 };
@@ -40,6 +42,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoInArgs a) {
     const int ty = (int)y2_div((uint32_t)r, a.d_tw);
     const int tx = r - ty * a.tw;
     const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+    if (a.tile_pix != nullptr && c4 == 0)     // decode table for the fused GEMM + output-transform kernel (one entry per tile)
+        a.tile_pix[t] = (int32_t)(((uint32_t)((b * a.H + 2 * ty) * a.W + 2 * tx)) | (2 * ty + 1 < a.H ? 0x40000000u : 0u) | (2 * tx + 1 < a.W ? 0x80000000u : 0u));
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 d[4][4];
 #pragma unroll
@@ -221,10 +225,12 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 //   * epilogue: accumulator register r of the 16 positions belongs to the same (tile, channel): 24 adds give the 2x2 output
 //     pixels, then affine + LeakyReLU, optional 2x2 max-pool (a tile is a pooling window) and BN statistics (valid pixels only).
 constexpr int WF_POS_FLOATS = (64 + 64) * 32;      // one position's A + B slab (16 KB)
+constexpr int WF2_DEFAULT_VARIANT = 7;             // which fused kernel y2_conv_fwd launches by default: -1 = first generation, else the feature mask of wino_fused2_kernel
 
 struct WinoFusedArgs {
     const float* v;       // [16][T][Cin]
     const float* u;       // [16][Cout][Cin]
+    const int32_t* tile_pix;   // [T] (wino_input_kernel): output pixel index of each tile + edge flags
     const float* scale; const float* shift;
     float* y; float* y_pool; double* stats;
     int H, W, Cin, Cout, ldy, coff, ldp, poff, th, tw, T, tiles_m, tiles_n;
@@ -441,6 +447,282 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }   // persistent tile loop
 }
 
+// ---- fused kernel, second generation.  Same tile (64 tiles x 64 channels x 16 positions per workgroup, 4 waves, 256 accumulator
+// registers, one wave per SIMD, 2 x 64 KB LDS ring) and the same arithmetic (bit-identical results) as wino_fused_kernel; what
+// changes is the instruction stream of the single wave a SIMD runs, because with one wave nothing else hides a stall:
+//   VAR bit 0  DMA spread: the 16 LDS-DMA instructions that fetch stage s+1 are issued two at a time behind the first 8 groups of
+//              four MFMAs of stage s (an LDS-DMA issue costs ~60 cycles, a 32x32x2 fp32 MFMA occupies the pipe for 64) instead of
+//              all 16 in front of the stage's first MFMAs (~0.7k of 4.1k cycles per stage with an idle matrix pipe); the second
+//              half of the stage is left for them to land before the next vmcnt(0).  The fetch stream runs ACROSS tiles: the last
+//              stage of a tile fetches the first stage of the workgroup's next tile.
+//   VAR bit 1  fragment double buffering: the 8 ds_read_b128 of k-group q+1 are issued before the 16 MFMAs of group q.
+//   VAR bit 2  deferred epilogue: after a tile's K loop only the output transform runs (accumulators -> 4 outputs per element in
+//              64 VGPRs); affine + LeakyReLU + pooling + statistics + stores of those outputs are interleaved, row by row, with the
+//              MFMAs of the NEXT tile's first two stages (the tile row index is wave-uniform up to the lane half, so its decode runs
+//              on the scalar unit).  The last tile of a workgroup drains its outputs after the loop.
+//   VAR bit 3  no accumulator clearing: the first MFMA of every accumulator of a tile takes the constant 0 as its C operand.
+// Every MFMA "slot" ends with a scheduling barrier so that the compiler keeps the hand-placed interleave.
+template <int VAR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fused2_kernel(const WinoFusedArgs a) {
+    constexpr bool SPREAD = (VAR & 1) != 0, DBUF = (VAR & 2) != 0, DEFER = (VAR & 4) != 0, ZEROC = false;
+    constexpr int DMODE = (VAR >> 3) & 3;          // experiments: 0 = two pieces per slot in slots 0-7, 1 = one per slot in all 16, 2 = four per slot in slots 0-3
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int PG = 4;
+    constexpr int STAGE_FLOATS = PG * WF_POS_FLOATS;          // 64 KB
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int xcd = blockIdx.x % Y2_NUM_XCD, wg_in_xcd = blockIdx.x / Y2_NUM_XCD;
+    const int wgs_per_xcd = gridDim.x / Y2_NUM_XCD;
+    const int per_xcd = (ntiles + Y2_NUM_XCD - 1) / Y2_NUM_XCD;
+    const int xcd_end = min(ntiles, (xcd + 1) * per_xcd);
+    int tile = xcd * per_xcd + wg_in_xcd;
+    if (tile >= xcd_end) return;
+
+    const int srow = t >> 3;
+    const int lchunk = (lane & 7) ^ ((srow >> 1) & 7);
+    unsigned a_off[2], b_off[2];                 // operand row offsets of the tile whose stages are being FETCHED
+    int fm0 = 0, fn0 = 0;                        // ... and its origin
+    auto place = [&](int tl) {
+        fm0 = (tl / a.tiles_n) * 64;
+        fn0 = (tl % a.tiles_n) * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = fm0 + srow + 32 * i, n = fn0 + srow + 32 * i;
+            a_off[i] = m < a.T ? (unsigned)(((size_t)m * a.Cin + 4 * lchunk) * 4) : OOB;
+            b_off[i] = n < a.Cout ? (unsigned)(((size_t)n * a.Cin + 4 * lchunk) * 4) : OOB;
+        }
+    };
+    place(tile);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.v), 0, a.v_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
+    const unsigned v_plane = (unsigned)((size_t)a.T * a.Cin * 4), u_plane = (unsigned)((size_t)a.Cout * a.Cin * 4);
+
+    // one of the 16 DMA instructions of stage (kslab, g) into ring slot `slot`: j = 4*pp + w, w = 0,1: A rows, 2,3: B rows
+    auto dma_piece = [&](int kslab, int g, int slot, int j) {
+        const int pp = j >> 2, w = j & 3, p = g * PG + pp;
+        float* sa = smem + slot * STAGE_FLOATS + pp * WF_POS_FLOATS + wave * (8 * 32);
+        if (w < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(sa + w * 32 * 32), 16, (int)a_off[w], (int)((unsigned)p * v_plane + (unsigned)kslab * 128u), 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(sa + 64 * 32 + (w - 2) * 32 * 32), 16, (int)b_off[w - 2], (int)((unsigned)p * u_plane + (unsigned)kslab * 128u), 0, 0);
+    };
+
+    f32x16 acc[16];
+    const int sw = (l31 >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) foff[q] = l31 * 32 + (((2 * q + half) ^ sw) << 2);
+    const int fa = wm * 32 * 32, fb = 64 * 32 + wn * 32 * 32;
+
+    // ---- deferred outputs of the previous tile
+    float o[16][4];                               // [register r][2*i + j]: raw output pixel (i, j) of tile row r, this lane's channel
+    int prow[16];                                 // tile_pix entry of tile row r (this lane's half), -1 beyond the last tile
+    bool pending = false;
+    int pm0 = 0;                                  // origin of the tile the pending outputs belong to
+    int pn = 0;                                   // this lane's channel of that tile
+    float psc = 1.f, psh = 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    const size_t row_stride = (size_t)a.W * a.ldy;
+
+    // affine + activation + pooling + statistics + stores of tile row r (one of 16) of the pending tile
+    auto emit_row = [&](int r) {
+        const int e = prow[r];
+        if (e == -1 || pn >= a.Cout) return;     // (a real entry is never -1: bits 30 and 31 set would need a pixel index of 2^30 - 1)
+        const bool y1 = (e & 0x40000000) != 0, x1 = e < 0;
+        const unsigned pix = (unsigned)e & 0x3fffffffu;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = o[r][k];
+        if (a.stats != nullptr) {
+            s1 += v[0]; s2 += v[0] * v[0];
+            if (x1) { s1 += v[1]; s2 += v[1] * v[1]; }
+            if (y1) { s1 += v[2]; s2 += v[2] * v[2]; }
+            if (y1 && x1) { s1 += v[3]; s2 += v[3] * v[3]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float uu = v[k] * psc + psh;
+            v[k] = uu > 0.f ? uu : uu * a.slope;
+        }
+        if (a.y != nullptr) {
+            float* dst = a.y + (size_t)pix * a.ldy + a.coff + pn;
+            dst[0] = v[0];
+            if (x1) dst[a.ldy] = v[1];
+            if (y1) {
+                dst[row_stride] = v[2];
+                if (x1) dst[row_stride + a.ldy] = v[3];
+            }
+        }
+        if (a.y_pool != nullptr) {               // H, W even: the pooled pixel index IS the tile index
+            const int tt = pm0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            a.y_pool[(size_t)tt * a.ldp + a.poff + pn] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        }
+    };
+    auto flush_stats = [&]() {
+        if (a.stats != nullptr) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (half == 0 && pn < a.Cout) {
+                double* st = a.stats + (size_t)((pm0 >> 6) % Y2_STATS_REPL) * 2 * a.Cout;
+                atomicAdd(st + pn, (double)s1);
+                atomicAdd(st + a.Cout + pn, (double)s2);
+            }
+            s1 = 0.f; s2 = 0.f;
+        }
+    };
+
+    // ---- one pipeline stage: consume ring slot SLOT into the 4 accumulators c[0..3].
+    //   FETCH: also issue the 16 DMA pieces of stage (fk, fg) into the other slot.   FIRST: these accumulators start at 0.
+    //   EROW0 >= 0: also emit the pending rows EROW0 .. EROW0+7.
+    auto stage = [&](auto SLOT, f32x16* c, auto FETCH, int fk, int fg, auto FIRST, auto EROW0) {
+        constexpr int slot = decltype(SLOT)::value;
+        constexpr bool fetch = decltype(FETCH)::value, first = decltype(FIRST)::value;
+        constexpr int erow0 = decltype(EROW0)::value;
+        const float* sbuf = smem + slot * STAGE_FLOATS;
+        f32x4 av[2][PG], bv[2][PG];
+        auto reads = [&](int q, int buf) {
+#pragma unroll
+            for (int pp = 0; pp < PG; ++pp) {
+                av[buf][pp] = *reinterpret_cast<const f32x4*>(sbuf + pp * WF_POS_FLOATS + fa + foff[q]);
+                bv[buf][pp] = *reinterpret_cast<const f32x4*>(sbuf + pp * WF_POS_FLOATS + fb + foff[q]);
+            }
+        };
+        if (fetch && !SPREAD) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dma_piece(fk, fg, slot ^ 1, j);
+        }
+        reads(0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cb = DBUF ? (q & 1) : 0;
+            if (DBUF && q < 3) reads(q + 1, cb ^ 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int sl = q * 4 + e;                 // MFMA slot 0..15 of the stage
+#pragma unroll
+                for (int pp = 0; pp < PG; ++pp) {
+                    if (first && ZEROC && q == 0 && e == 0) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        c[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][pp][e], bv[cb][pp][e], z, 0, 0, 0);
+                    } else {
+                        c[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][pp][e], bv[cb][pp][e], c[pp], 0, 0, 0);
+                    }
+                    // behind MFMA pp of slot sl: two DMA pieces per slot in the first 8 slots (after MFMAs 0 and 2), one pending row per
+                    // two slots (after MFMA 1 of the even slots)
+                    if (SPREAD && fetch) {
+                        if (DMODE == 0 && sl < 8 && (pp == 0 || pp == 2)) dma_piece(fk, fg, slot ^ 1, 2 * sl + (pp >> 1));
+                        if (DMODE == 1 && pp == 0) dma_piece(fk, fg, slot ^ 1, sl);
+                        if (DMODE == 2 && sl < 4) dma_piece(fk, fg, slot ^ 1, 4 * sl + pp);
+                    }
+                    if (DEFER && erow0 >= 0 && pp == 1 && (sl & 1) == 0) emit_row(erow0 + (sl >> 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (!DBUF && q < 3) reads(q + 1, 0);
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using NoRow = std::integral_constant<int, -1>;
+    using Row0 = std::integral_constant<int, 0>;
+    using Row8 = std::integral_constant<int, 8>;
+
+    const int nks = a.Cin / 32;                  // host guarantees nks >= 2: every tile runs 4 * nks stages, an even number, so a
+    // prologue: the first stage of the first tile     // tile always starts in ring slot 0 and stage g of a K slab sits in slot g & 1
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dma_piece(0, 0, 0, j);
+    for (;;) {
+        const int em0 = fm0, en0 = fn0;           // this tile's origin (the fetch cursor is still on this tile)
+        if (!ZEROC) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+        }
+#define Y2_WF2_SYNC()                                              \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           \
+        __builtin_amdgcn_s_barrier()
+        // ---- first K slab: carries the previous tile's deferred rows in its first two stages
+        Y2_WF2_SYNC();
+        if (DEFER && pending) stage(S0{}, &acc[0], T_{}, 0, 1, T_{}, Row0{}); else stage(S0{}, &acc[0], T_{}, 0, 1, T_{}, NoRow{});
+        Y2_WF2_SYNC();
+        if (DEFER && pending) { stage(S1{}, &acc[4], T_{}, 0, 2, T_{}, Row8{}); flush_stats(); pending = false; } else stage(S1{}, &acc[4], T_{}, 0, 2, T_{}, NoRow{});
+        Y2_WF2_SYNC();
+        stage(S0{}, &acc[8], T_{}, 0, 3, T_{}, NoRow{});
+        Y2_WF2_SYNC();
+        stage(S1{}, &acc[12], T_{}, 1, 0, T_{}, NoRow{});
+        // ---- steady K slabs
+        for (int ks = 1; ks < nks - 1; ++ks) {
+            Y2_WF2_SYNC();
+            stage(S0{}, &acc[0], T_{}, ks, 1, F_{}, NoRow{});
+            Y2_WF2_SYNC();
+            stage(S1{}, &acc[4], T_{}, ks, 2, F_{}, NoRow{});
+            Y2_WF2_SYNC();
+            stage(S0{}, &acc[8], T_{}, ks, 3, F_{}, NoRow{});
+            Y2_WF2_SYNC();
+            stage(S1{}, &acc[12], T_{}, ks + 1, 0, F_{}, NoRow{});
+        }
+        // ---- last K slab; its last stage fetches the first stage of the workgroup's next tile
+        Y2_WF2_SYNC();
+        stage(S0{}, &acc[0], T_{}, nks - 1, 1, F_{}, NoRow{});
+        Y2_WF2_SYNC();
+        stage(S1{}, &acc[4], T_{}, nks - 1, 2, F_{}, NoRow{});
+        Y2_WF2_SYNC();
+        stage(S0{}, &acc[8], T_{}, nks - 1, 3, F_{}, NoRow{});
+        tile += wgs_per_xcd;
+        const bool more = tile < xcd_end;
+        // decode-table entries of this tile's 16 rows (two distinct addresses per wave: L1/L2 broadcast); in flight during the last stage
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tt = em0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            prow[r] = tt < a.T ? a.tile_pix[tt] : -1;
+        }
+        Y2_WF2_SYNC();
+        if (more) {
+            place(tile);
+            stage(S1{}, &acc[12], T_{}, 0, 0, F_{}, NoRow{});
+        } else {
+            stage(S1{}, &acc[12], F_{}, 0, 0, F_{}, NoRow{});
+        }
+#undef Y2_WF2_SYNC
+        // ---- output transform A^T M A: accumulator register r of the 16 positions belongs to the same (tile row, channel)
+        pm0 = em0;
+        pn = en0 + wn * 32 + l31;
+        psc = (a.scale != nullptr && pn < a.Cout) ? a.scale[pn] : 1.f;
+        psh = (a.shift != nullptr && pn < a.Cout) ? a.shift[pn] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float sm[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sm[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+                sm[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                o[r][2 * i + 0] = sm[i][0] + sm[i][1] + sm[i][2];
+                o[r][2 * i + 1] = sm[i][1] - sm[i][2] - sm[i][3];
+            }
+            if (!DEFER) { emit_row(r); __builtin_amdgcn_sched_barrier(0); }
+        }
+        pending = DEFER;
+        if (!DEFER) flush_stats();
+        if (DEFER && !more) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { emit_row(r); __builtin_amdgcn_sched_barrier(0); }
+            flush_stats();
+            pending = false;
+        }
+        if (!more) break;
+    }
+}
+
 // ---- weight gradient:  dU[p][co][ci] = sum_t dM[p][t][co] * V[p][t][ci],   dM = A dz A^T (4x4 from the 2x2 gradient tile),
 //      dg = G^T dU G.  16 reductions over T tiles instead of 9 shifted reductions over 4T pixels (2.25x fewer MACs).
 struct WinoDzArgs {
@@ -566,7 +848,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     const long long T = (long long)cb * th * tw;    // tiles of a full chunk
     if (T * (p->Cin / 4) >= 0xffffffffLL || T * (p->Cout / 4) >= 0xffffffffLL || T > 0x7fffffff) return Y2_ENOSUP;
     const size_t vbytes = align256((size_t)16 * T * p->Cin * sizeof(float));
-    const size_t mbytes = fused ? 0 : align256((size_t)16 * T * p->Cout * sizeof(float));
+    const size_t mbytes = fused ? align256((size_t)T * sizeof(int32_t)) : align256((size_t)16 * T * p->Cout * sizeof(float));   // fused: tile decode table
     if (fused && (vbytes >= 0x7fffffffull || (size_t)16 * p->Cout * p->Cin * 4 >= 0x7fffffffull)) return Y2_ENOSUP;
 
     // stage 2 as a grouped 1x1 "convolution" over an image of 1 x T pixels
@@ -599,11 +881,12 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
         ia.x = p->x + in_off * p->ldx; ia.v = V; ia.B = nb; ia.H = p->H; ia.W = p->W; ia.Cin = p->Cin; ia.ldx = p->ldx; ia.th = th; ia.tw = tw;
         ia.T = (int)Tc; ia.c4n = p->Cin / 4;
         ia.d_c4 = y2_make_fastdiv((uint32_t)ia.c4n); ia.d_tt = d_tt; ia.d_tw = d_tw;
+        ia.tile_pix = fused ? reinterpret_cast<int32_t*>(M) : nullptr;      // the fused path has no product tensor: the table sits behind V
         Y2_LAUNCH("wino_input_kernel", 0.0, wino_input_kernel, dim3((unsigned)y2_cdiv(Tc * ia.c4n, 256)), dim3(256), 0, s, ia);
 
         if (fused) {
             WinoFusedArgs fa;
-            fa.v = V; fa.u = p->w; fa.scale = p->scale; fa.shift = p->shift; fa.stats = p->stats;
+            fa.v = V; fa.u = p->w; fa.tile_pix = ia.tile_pix; fa.scale = p->scale; fa.shift = p->shift; fa.stats = p->stats;
             fa.y = p->y != nullptr ? p->y + in_off * p->ldy : nullptr;
             fa.y_pool = p->y_pool != nullptr ? p->y_pool + (size_t)b0 * th * tw * p->ldp : nullptr;
             fa.H = p->H; fa.W = p->W; fa.Cin = p->Cin; fa.Cout = p->Cout; fa.ldy = p->ldy; fa.coff = p->coff; fa.ldp = p->ldp; fa.poff = p->poff;
@@ -621,6 +904,33 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
                 if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(kern))) return rc_;                                  \
                 Y2_LAUNCH("wino_fused_kernel", 2.0 * 16.0 * (double)fa.T * fa.Cout * fa.Cin, kern, dim3((unsigned)grid), dim3(256), lds, s, fa);                                             \
             } while (0)
+#define Y2_WF2_LAUNCH(VAR_)                                                                                                        \
+            do {                                                                                                                   \
+                auto kern = wino_fused2_kernel<VAR_>;                                                                              \
+                const size_t lds = (size_t)2 * 4 * WF_POS_FLOATS * sizeof(float);                                                  \
+                static Y2LdsAttr attr;                                                                                             \
+                if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(kern))) return rc_;                                  \
+                Y2_LAUNCH("wino_fused2_kernel", 2.0 * 16.0 * (double)fa.T * fa.Cout * fa.Cin, kern, dim3((unsigned)grid), dim3(256), lds, s, fa); \
+            } while (0)
+            // second-generation instruction stream (see wino_fused2_kernel); Y2_WF_VARIANT = -1 selects the first generation, 0..15 a
+            // feature mask (experiments).  Its 32-bit output offsets need the output tensors below 2^31 elements.
+            const char* ve = getenv("Y2_WF_VARIANT");           // read per call (experiments / tests switch it at run time)
+            const int variant = ve != nullptr ? atoi(ve) : WF2_DEFAULT_VARIANT;
+            const bool small_out = (unsigned long long)p->B * p->H * p->W * (unsigned long long)(p->ldy > p->ldp ? p->ldy : p->ldp) < 0x7fffffffull;
+            if (variant >= 0 && p->Cin >= 64 && small_out) {
+                switch (variant) {
+                    case 1: Y2_WF2_LAUNCH(1); break;
+                    case 5: Y2_WF2_LAUNCH(5); break;
+                    case 9: Y2_WF2_LAUNCH(9); break;       // 1 + DMA mode 1
+                    case 13: Y2_WF2_LAUNCH(13); break;     // 5 + DMA mode 1
+                    case 15: Y2_WF2_LAUNCH(15); break;     // 7 + DMA mode 1
+                    case 21: Y2_WF2_LAUNCH(21); break;     // 5 + DMA mode 2
+                    case 23: Y2_WF2_LAUNCH(23); break;     // 7 + DMA mode 2
+                    default: Y2_WF2_LAUNCH(7); break;
+                }
+                continue;
+            }
+#undef Y2_WF2_LAUNCH
             // measured on the 52x52 / 26x26 / 13x13 layers (B=32): 4 positions per stage + 2-deep ring (64 MFMAs per wave between
             // barriers) 0.341 / 0.283 / 0.330 ms; 2 positions x 4-deep 0.357 / 0.289 / 0.336; 1 position x 6-deep 0.373 / 0.315 / 0.369
             Y2_WF_LAUNCH(4, 2);
@@ -680,6 +990,7 @@ extern "C" int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, 
     if (e != hipSuccess) return -(1000 + (int)e);
 
     WinoInArgs ia;
+    ia.tile_pix = nullptr;
     ia.x = x; ia.v = V; ia.B = B; ia.H = H; ia.W = W; ia.Cin = Cin; ia.ldx = ldx; ia.th = th; ia.tw = tw; ia.T = (int)T; ia.c4n = Cin / 4;
     ia.d_c4 = y2_make_fastdiv((uint32_t)ia.c4n); ia.d_tt = y2_make_fastdiv((uint32_t)(th * tw)); ia.d_tw = y2_make_fastdiv((uint32_t)tw);
     if (v_transformed == nullptr) Y2_LAUNCH("wino_input_kernel", 0.0, wino_input_kernel, dim3((unsigned)y2_cdiv(T * ia.c4n, 256)), dim3(256), 0, s, ia);
