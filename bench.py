@@ -494,6 +494,10 @@ def main():
     if ctx.ranks_seen != ctx.world:
         raise SystemExit('bench.py: all-reduce of ones saw %d ranks, expected %d' % (ctx.ranks_seen, ctx.world))
     headline = args.headline if args.headline != 'auto' else ('detect' if ctx.world == 1 else 'train')
+    if args.no_detect and headline == 'detect':
+        headline = 'train'
+    if args.no_train and headline == 'train':
+        headline = 'detect'
     label = {'darknet': 'Darknet-19', 'tiny': 'tiny-yolo'}.get(args.model, args.model)
 
     if args.dry_run:

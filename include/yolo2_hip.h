@@ -54,6 +54,23 @@ const char* y2_build_info(void);
  * (filters rotated by 180 deg, in/out swapped).  dst holds Cout*Cin*k*k floats. */
 int y2_pack_weight(const float* w, float* dst, int Cout, int Cin, int ksize, int mode, y2_stream_t stream);
 
+/* Multi-tensor form for a whole network: ONE launch prepares every listed operand from the state_dict layout [Cout][Cin][k][k]
+ * (a training step re-derives ~90 operands from the freshly updated weights; as separate launches they are launch-latency bound).
+ * Modes: Y2_PREP_FPROP / Y2_PREP_DGRAD = y2_pack_weight modes 0 / 1;  Y2_PREP_WINO_FPROP / Y2_PREP_WINO_DGRAD = the Winograd
+ * filter transform U[16][Cout][Cin] resp. U[16][Cin][Cout] (rotated, in/out swapped) of a 3x3 filter, bit-identical to
+ * y2_pack_weight + y2_wino_weight.  dst sizes: Cout*Cin*k*k floats (packs), 16*Cout*Cin floats (transforms). */
+#define Y2_PREP_FPROP 0
+#define Y2_PREP_DGRAD 1
+#define Y2_PREP_WINO_FPROP 2
+#define Y2_PREP_WINO_DGRAD 3
+#define Y2_PREP_MAX_ITEMS 96
+typedef struct {
+    const float* src;
+    float* dst;
+    int32_t Cout, Cin, ksize, mode;
+} y2_prep_item;
+int y2_prep_weights(const y2_prep_item* items, int32_t count, y2_stream_t stream);
+
 /* Inverse of mode 0 for a weight GRADIENT: src[co][tap][ci] -> dst[Cout][Cin][k][k]. */
 int y2_unpack_weight_grad(const float* src, float* dst, int Cout, int Cin, int ksize, y2_stream_t stream);
 
@@ -218,6 +235,9 @@ int y2_iou_pair_host(const float* yx_min1, const float* yx_max1, const float* yx
 int y2_prof_enable(int on);
 int y2_prof_count(void);
 int y2_prof_get(int i, char* name, int name_cap, float* ms, double* flops);
+/* Caller-defined non-negative tag stamped on every record made until the next call (e.g. the layer being executed), and its readback. */
+int y2_prof_set_tag(int tag);
+int y2_prof_get_tag(int i);
 
 /* ------------------------------------------------------------------------------------------------
  * Training path.  The reference trains through torch autograd (train.py:344-357): conv / BN / LeakyReLU /

@@ -39,9 +39,18 @@ class OptTensor(ctypes.Structure):
 
 OPT_MAX_TENSORS = 48
 
+
+class PrepItem(ctypes.Structure):
+    """y2_prep_item (include/yolo2_hip.h)."""
+    _fields_ = [('src', c_void_p), ('dst', c_void_p), ('Cout', ctypes.c_int32), ('Cin', ctypes.c_int32), ('ksize', ctypes.c_int32), ('mode', ctypes.c_int32)]
+
+
+PREP_FPROP, PREP_DGRAD, PREP_WINO_FPROP, PREP_WINO_DGRAD = 0, 1, 2, 3
+
 SIGNATURES = {
     'y2_abi_version': [],
     'y2_pack_weight': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    'y2_prep_weights': [ctypes.POINTER(PrepItem), c_int, c_void_p],
     'y2_unpack_weight_grad': [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'y2_bn_fold': [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p],
     'y2_conv_fwd': [ctypes.POINTER(ConvParams), c_void_p],
@@ -87,6 +96,8 @@ SIGNATURES = {
     'y2_iou_pair_host': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p],
     'y2_prof_enable': [c_int],
     'y2_prof_count': [],
+    'y2_prof_set_tag': [c_int],
+    'y2_prof_get_tag': [c_int],
     'y2_prof_get': [c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_float), ctypes.POINTER(ctypes.c_double)],
     'y2_nms': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
 }

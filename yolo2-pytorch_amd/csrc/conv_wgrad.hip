@@ -17,6 +17,10 @@
 // wave against 16 KB + 16 KB of DMA: the same MFMA-bound balance as the forward kernel.
 #include "common.h"
 
+#ifndef Y2_WGRAD_SPREAD
+#define Y2_WGRAD_SPREAD 1     // 1: LDS-DMA of slab s+1 between the MFMAs of slab s; 0: all in front (A/B builds)
+#endif
+
 namespace {
 
 constexpr int NT = 256;
@@ -143,6 +147,60 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     const int fa = wm * WI + l31 + half * TI;              // + (2s)*TI + 32*block
     const int fb = KS * TI + wn * WJ + l31 + half * 128;   // + (2s)*128 + 32*block
 
+    // The same slab fetch, split: voffsets of the NEXT slab first (VALU), then one DMA instruction at a time between the MFMAs of
+    // the current slab (an LDS-DMA issue costs ~60 cycles, an fp32 32x32x2 MFMA keeps the pipe busy for 64): pieces go out in the
+    // first half of the slab so that they have landed by the next vmcnt(0).
+    unsigned nva[PA], nvb[4];
+    auto plan_slab = [&](int slab) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int m = slab * KS + prow_a + RA * p;
+            nva[p] = (m < a.M && a_ok) ? (unsigned)(((size_t)m * a.ldz + ca) * 4) : OOB;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int m = slab * KS + prow + 8 * p;
+            const bool mok = m < a.M;
+            const int yi = py[p] * a.stride + dy, xi = px[p] * a.stride + dx;
+            const bool in = (unsigned)yi < (unsigned)a.Hi && (unsigned)xi < (unsigned)a.Wi;
+            nvb[p] = (mok && b_ok && in) ? (unsigned)(((size_t)((pb[p] * a.Hi + yi) * a.Wi + xi) * a.ldx + ci) * 4) : OOB;
+            px[p] += r32; py[p] += q32;
+            if (px[p] >= a.W) { px[p] -= a.W; py[p] += 1; }
+            while (py[p] >= a.H) { py[p] -= a.H; pb[p] += 1; }
+        }
+    };
+    auto issue_piece = [&](int buf, int j) {
+        if (j < PA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (lds_ptr_t)(smem + buf * STAGE + wave * 256 + j * RA * TI), 16, (int)nva[j], 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + buf * STAGE + KS * TI + wave * 256 + (j - PA) * 8 * 128), 16, (int)nvb[j - PA], 0, 0, 0);
+    };
+    auto compute_slab_spread = [&](int buf, int nbuf) {
+        const float* sbuf = smem + buf * STAGE;
+        constexpr int TOTAL = (KS / 2) * IB * JB, NPIECES = PA + 4;
+        constexpr int EVERY = (TOTAL / 2) / NPIECES > 0 ? (TOTAL / 2) / NPIECES : 1;
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < KS / 2; ++s) {
+            float av[IB], bv[JB];
+#pragma unroll
+            for (int i = 0; i < IB; ++i) av[i] = sbuf[fa + s * 2 * TI + 32 * i];
+#pragma unroll
+            for (int j = 0; j < JB; ++j) bv[j] = sbuf[fb + s * 256 + 32 * j];
+#pragma unroll
+            for (int i = 0; i < IB; ++i)
+#pragma unroll
+                for (int j = 0; j < JB; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    if (cnt % EVERY == 0 && cnt / EVERY < NPIECES) {
+                        issue_piece(nbuf, cnt / EVERY);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    ++cnt;
+                }
+        }
+#pragma unroll
+        for (int j = (TOTAL + EVERY - 1) / EVERY; j < NPIECES; ++j) issue_piece(nbuf, j);
+    };
+
     auto compute_slab = [&](int buf) {
         const float* sbuf = smem + buf * STAGE;
 #pragma unroll
@@ -162,10 +220,15 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 
     issue_slab(slab_lo, 0);
     for (int ks = 0; ks < nk - 1; ++ks) {
+        if (Y2_WGRAD_SPREAD) plan_slab(slab_lo + ks + 1);      // VALU only: overlaps the tail of the previous slab's MFMAs
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        issue_slab(slab_lo + ks + 1, (ks + 1) & 1);
-        compute_slab(ks & 1);
+        if (Y2_WGRAD_SPREAD) {
+            compute_slab_spread(ks & 1, (ks + 1) & 1);
+        } else {
+            issue_slab(slab_lo + ks + 1, (ks + 1) & 1);
+            compute_slab(ks & 1);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

@@ -28,6 +28,70 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
     }
 }
 
+// Multi-tensor weight preparation: one launch for every layer's GEMM operand (y2_prep_weights).  The item table travels in the
+// kernel arguments (like the optimizer's pointer table); block b works on the item whose [first_block, next first_block) range holds b.
+struct PrepTable {
+    y2_prep_item item[Y2_PREP_MAX_ITEMS];
+    int first_block[Y2_PREP_MAX_ITEMS + 1];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void prep_weights_kernel(const PrepTable tb) {
+    int it = 0;
+    while (it + 1 < tb.count && (int)blockIdx.x >= tb.first_block[it + 1]) ++it;      // uniform scan, count <= 96
+    const y2_prep_item& q = tb.item[it];
+    const int nblk = tb.first_block[it + 1] - tb.first_block[it];
+    const int blk = blockIdx.x - tb.first_block[it];
+    const float* __restrict__ w = q.src;
+    float* __restrict__ dst = q.dst;
+    const int Cout = q.Cout, Cin = q.Cin, taps = q.ksize * q.ksize;
+    if (q.mode == Y2_PREP_FPROP || q.mode == Y2_PREP_DGRAD) {
+        const long long total = (long long)Cout * Cin * taps;
+        for (long long i = (long long)blk * 256 + threadIdx.x; i < total; i += (long long)nblk * 256) {
+            if (q.mode == Y2_PREP_FPROP) {      // dst[co][tap][ci] = w[co][ci][tap]                   (= y2_pack_weight mode 0)
+                const int ci = (int)(i % Cin);
+                const long long r = i / Cin;
+                dst[i] = w[((long long)(r / taps) * Cin + ci) * taps + (int)(r % taps)];
+            } else {                              // dst[ci][taps-1-tap][co] = w[co][ci][tap]           (= y2_pack_weight mode 1)
+                const int co = (int)(i % Cout);
+                const long long r = i / Cout;
+                dst[i] = w[((long long)co * Cin + (int)(r / taps)) * taps + (taps - 1 - (int)(r % taps))];
+            }
+        }
+        return;
+    }
+    // Winograd F(2x2,3x3) filter transform straight from the state_dict layout: U[p][n][k] = (G g G^T)[p].
+    //   WINO_FPROP: n = co, k = ci, g[t] = w[co][ci][t];   WINO_DGRAD: n = ci, k = co, g[t] = w[co][ci][8 - t] (rotated, in/out swapped)
+    // Same arithmetic as wino_weight_kernel on the packed operand: bit-identical U.
+    const bool dg = q.mode == Y2_PREP_WINO_DGRAD;
+    const int N = dg ? Cin : Cout, K = dg ? Cout : Cin;
+    const long long total = (long long)N * K;
+    for (long long i = (long long)blk * 256 + threadIdx.x; i < total; i += (long long)nblk * 256) {
+        const int k = (int)(i % K);
+        const int n = (int)(i / K);
+        const float* src = dg ? w + ((long long)k * Cin + n) * 9 : w + ((long long)n * Cin + k) * 9;
+        float g[3][3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = dg ? src[8 - t] : src[t];
+        float s[4][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            s[0][j] = g[0][j];
+            s[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+            s[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+            s[3][j] = g[2][j];
+        }
+        float* d = dst + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            d[(4 * r + 0) * total] = s[r][0];
+            d[(4 * r + 1) * total] = 0.5f * (s[r][0] + s[r][1] + s[r][2]);
+            d[(4 * r + 2) * total] = 0.5f * (s[r][0] - s[r][1] + s[r][2]);
+            d[(4 * r + 3) * total] = s[r][2];
+        }
+    }
+}
+
 __global__ void bn_fold_kernel(const float* g, const float* b, const float* m, const float* v, float eps, float* scale, float* shift, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < C) {
@@ -134,6 +198,31 @@ extern "C" int y2_pack_weight(const float* w, float* dst, int Cout, int Cin, int
     const long long total = (long long)Cout * Cin * ksize * ksize;
     Y2_LAUNCH("pack_weight_kernel", 0.0, pack_weight_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), w, dst, Cout, Cin, ksize * ksize, mode, total);
     Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_prep_weights(const y2_prep_item* items, int32_t count, y2_stream_t stream) {
+    if (items == nullptr || count < 0) return Y2_EINVAL;
+    for (int lo = 0; lo < count; lo += Y2_PREP_MAX_ITEMS) {
+        PrepTable tb;
+        tb.count = count - lo < Y2_PREP_MAX_ITEMS ? count - lo : Y2_PREP_MAX_ITEMS;
+        int blocks = 0;
+        for (int i = 0; i < tb.count; ++i) {
+            const y2_prep_item& q = items[lo + i];
+            if (q.src == nullptr || q.dst == nullptr || q.Cout <= 0 || q.Cin <= 0 || q.ksize <= 0 || q.mode < Y2_PREP_FPROP || q.mode > Y2_PREP_WINO_DGRAD) return Y2_EINVAL;
+            if ((q.mode == Y2_PREP_WINO_FPROP || q.mode == Y2_PREP_WINO_DGRAD) && q.ksize != 3) return Y2_ENOSUP;
+            const long long n = (q.mode <= Y2_PREP_DGRAD) ? (long long)q.Cout * q.Cin * q.ksize * q.ksize : (long long)q.Cout * q.Cin;
+            long long nb = (n + 1023) / 1024;          // ~4 elements per thread
+            if (nb < 1) nb = 1;
+            if (nb > 2048) nb = 2048;
+            tb.item[i] = q;
+            tb.first_block[i] = blocks;
+            blocks += (int)nb;
+        }
+        tb.first_block[tb.count] = blocks;
+        if (blocks > 0) Y2_LAUNCH("prep_weights_kernel", 0.0, prep_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, y2_s(stream), tb);
+        Y2_LAUNCH_CHECK();
+    }
     return Y2_OK;
 }
 

@@ -15,8 +15,10 @@ namespace {
 struct Rec {
     const char* name;
     double flops;
+    int tag;
     hipEvent_t e0, e1;
 };
+int cur_tag = 0;
 std::vector<Rec>& recs() { static std::vector<Rec> r; return r; }
 std::vector<hipEvent_t>& pool() { static std::vector<hipEvent_t> p; return p; }
 size_t pool_used = 0;
@@ -36,7 +38,7 @@ hipEvent_t take_event() {
 void y2_prof_begin(const char* name, hipStream_t s, double flops) {
     if (recs().size() >= (1u << 20)) { open_rec = false; return; }
     Rec r;
-    r.name = name; r.flops = flops; r.e0 = take_event(); r.e1 = take_event();
+    r.name = name; r.flops = flops; r.tag = cur_tag; r.e0 = take_event(); r.e1 = take_event();
     if (r.e0 == nullptr || r.e1 == nullptr) { open_rec = false; return; }
     (void)hipEventRecord(r.e0, s);
     recs().push_back(r);
@@ -56,6 +58,10 @@ extern "C" int y2_prof_enable(int on) {
 }
 
 extern "C" int y2_prof_count(void) { return (int)recs().size(); }
+
+extern "C" int y2_prof_set_tag(int tag) { cur_tag = tag; return Y2_OK; }
+
+extern "C" int y2_prof_get_tag(int i) { return (i < 0 || (size_t)i >= recs().size()) ? Y2_EINVAL : recs()[(size_t)i].tag; }
 
 extern "C" int y2_prof_get(int i, char* name, int name_cap, float* ms, double* flops) {
     if (i < 0 || (size_t)i >= recs().size()) return Y2_EINVAL;

@@ -56,9 +56,10 @@ def _new(dev, *shape, dtype=torch.float32):
     return torch.empty(*shape, dtype=dtype, device=dev)
 
 
-def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=None, slope=1.0, stats=None, y_pool=None, ldp=0, coff=0, out_mode=0, keep_v=False):
+def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=None, slope=1.0, stats=None, y_pool=None, ldp=0, coff=0, out_mode=0, keep_v=False, u=False):
     """One y2_conv_fwd.  keep_v: when the Winograd algorithm is chosen, run it in a workspace of its own and return that tensor -
-    its head is the transformed input V, which the weight gradient of the same layer reuses (y2_wino_wgrad v_transformed)."""
+    its head is the transformed input V, which the weight gradient of the same layer reuses (y2_wino_wgrad v_transformed).
+    u: the layer's Winograd filter transform when the caller prepared it (y2_prep_weights), None = not eligible, False = derive it here."""
     p = _hip.ConvParams()
     p.x, p.w = x.data_ptr(), wp.data_ptr()
     p.scale = scale.data_ptr() if scale is not None else None
@@ -70,7 +71,10 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
     p.ldy, p.coff, p.ldp, p.poff, p.out_mode = ldy, coff, ldp, 0, out_mode
     p.slope, p.tile = slope, 0
     # 3x3 layers: also offer the Winograd algorithm (filter transform of the packed weight: fprop and dgrad alike)
-    u = _hip.wino_weight(wp, cout, cin) if (out_mode == 0 and _hip.wino_eligible(cout, cin, k)) else None
+    if u is False:
+        u = _hip.wino_weight(wp, cout, cin) if (out_mode == 0 and _hip.wino_eligible(cout, cin, k)) else None
+    elif out_mode != 0:
+        u = None
     _hip.autotune_conv(p, x.device, wino_w=u)
     kept = None
     if keep_v and p.algo in (1, 2):
@@ -89,6 +93,58 @@ class _Block(object):
     """One conv block of the forward pass: geometry + saved tensors for backward."""
     __slots__ = ('mod', 'name', 'x', 'ldx', 'H', 'W', 'cin', 'cout', 'k', 'z', 'scale', 'shift', 'mean', 'invstd', 'pool',
                  'out_full', 'out_pool', 'out_ld', 'out_off', 'out_mode', 'has_bn', 'slope', 'first', 'wino_v')
+
+
+def _train_operands(dnn, dev):
+    """GEMM operands of every convolution block for one parameter version, produced by ONE y2_prep_weights launch from the
+    state_dict layout: fprop pack, dgrad pack (rotated, in/out swapped) and, where the Winograd algorithm is eligible, both filter
+    transforms.  The optimizer rewrites the weights every step, so this runs once per step (it used to be ~90 separate small
+    launches: pack + transform per layer, forward and backward).  Returns {Conv2d block: dict(wp, wd, uf, ud)}; the first layer
+    (y2_conv0_fwd reads the state_dict layout) and blocks whose output width is not a multiple of 4 (the 125 / 425-channel head: its
+    data gradient runs zero-padded) are left to the per-layer path."""
+    from model import yolo2 as _yolo2
+    key = (dev, dnn._versions())
+    cache = getattr(dnn, '_train_cache', None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    bufs = getattr(dnn, '_train_bufs', None)
+    if bufs is None or bufs[0] != dev:
+        bufs = (dev, {})
+        dnn._train_bufs = bufs
+
+    def buf(tag, n):
+        t = bufs[1].get(tag)
+        if t is None or t.numel() != n:
+            t = torch.empty(n, dtype=torch.float32, device=dev)
+            bufs[1][tag] = t
+        return t
+    first = dnn._first_block()
+    items, ops = [], {}
+    for name, blk in dnn.named_modules():
+        if not isinstance(blk, _yolo2.Conv2d) or blk is first:
+            continue
+        w = blk.conv.weight.detach()
+        cout, cin, k, _ = w.shape
+        if cout % 4 or cin % 4 or not w.is_contiguous() or w.dtype != torch.float32:
+            continue
+        n = w.numel()
+        d = dict(wp=buf((name, 'wp'), n), wd=buf((name, 'wd'), n), uf=None, ud=None)
+        items.append((w, d['wp'], cout, cin, k, _hip.PREP_FPROP))
+        items.append((w, d['wd'], cout, cin, k, _hip.PREP_DGRAD))
+        if _hip.wino_eligible(cout, cin, k):
+            d['uf'] = buf((name, 'uf'), 16 * cout * cin)
+            items.append((w, d['uf'], cout, cin, k, _hip.PREP_WINO_FPROP))
+        if _hip.wino_eligible(cin, cout, k):          # the data gradient is a convolution with the roles of Cin and Cout exchanged
+            d['ud'] = buf((name, 'ud'), 16 * cout * cin)
+            items.append((w, d['ud'], cout, cin, k, _hip.PREP_WINO_DGRAD))
+        ops[blk] = d
+    if items:
+        table = (_hip.PrepItem * len(items))()
+        for e, (src, dst, cout, cin, k, mode) in zip(table, items):
+            e.src, e.dst, e.Cout, e.Cin, e.ksize, e.mode = src.data_ptr(), dst.data_ptr(), cout, cin, k, mode
+        _hip.check(_hip.lib().y2_prep_weights(table, len(items), _hip.stream()), 'y2_prep_weights')
+    dnn._train_cache = (key, ops)
+    return ops
 
 
 def darknet_forward(dnn, x):
@@ -110,6 +166,7 @@ class DarknetTrainFn(torch.autograd.Function):
             raise ValueError('input size must be a multiple of 32 (got %dx%d)' % (H, W))
         dev = x.device
         b1, b2, b3 = dnn._blocks()
+        prepared = _train_operands(dnn, dev)
         # one zero-filled arena for every layer's replicated BN-statistics accumulators (one fill kernel instead of 22)
         couts = [m.conv.weight.shape[0] for _, m, _ in b1 + b2 + b3] + [dnn.passthrough.conv.weight.shape[0]]
         arena = torch.zeros(_hip.STATS_REPL * 2 * sum(couts), dtype=torch.float64, device=dev)
@@ -124,6 +181,7 @@ class DarknetTrainFn(torch.autograd.Function):
         def run_block(name, mod, xin, ldx, h, w, pool, out_full=None, out_ld=0, out_off=0, out_mode=0, want_full=True, first=False):
             """raw conv + stats -> finalize -> act.  Returns (_Block, full activation or None, pooled activation or None)."""
             blk = _Block()
+            L.y2_prof_set_tag(1 + len(blocks))          # measurement hooks: forward launches of block i carry tag 1 + i
             weight = mod.conv.weight.detach()
             cout, cin, k, _ = weight.shape
             blk.mod, blk.name, blk.x, blk.ldx, blk.H, blk.W, blk.cin, blk.cout, blk.k = mod, name, xin, ldx, h, w, cin, cout, k
@@ -134,6 +192,8 @@ class DarknetTrainFn(torch.autograd.Function):
             if first:
                 _hip.check(L.y2_conv0_fwd(_hip.ptr(xin), _hip.ptr(_hip.f32c(weight)), None, None, _hip.ptr(z), None, _hip.ptr(stats),
                                           B, h, w, cin, cout, cout, 0, 1.0, st), 'y2_conv0_fwd')
+            elif mod in prepared:
+                blk.wino_v = _conv(L, st, xin, prepared[mod]['wp'], z, B, h, w, cin, ldx, cout, k, cout, stats=stats, keep_v=True, u=prepared[mod]['uf'])
             else:
                 wp = _new(dev, weight.numel())
                 _hip.check(L.y2_pack_weight(_hip.ptr(_hip.f32c(weight)), _hip.ptr(wp), cout, cin, k, 0, st), 'y2_pack_weight')
@@ -197,9 +257,11 @@ class DarknetTrainFn(torch.autograd.Function):
             cur, ld = yf, blk.cout
         ctx.dnn = dnn
         ctx.blocks = blocks
+        ctx.prepared = prepared
         ctx.geom = (B, cin0, H, W, c_pt, c_l2)
         ctx.x = x
         ctx.param_ids = [id(p) for p in params]
+        L.y2_prof_set_tag(0)
         return cur
 
     @staticmethod
@@ -207,6 +269,9 @@ class DarknetTrainFn(torch.autograd.Function):
         L = _hip.lib()
         st = _hip.stream()
         dnn, blocks = ctx.dnn, ctx.blocks
+        if ctx.prepared and getattr(dnn, '_train_cache', (None, None))[1] is not ctx.prepared:
+            raise RuntimeError('model.yolo2: the weights changed (another forward after an optimizer step) between this forward and its backward; '
+                               'the prepared GEMM operands of this graph are gone')
         B, cin0, H, W, c_pt, c_l2 = ctx.geom
         dev = dout.device
         dout = _hip.f32c(dout)
@@ -234,6 +299,7 @@ class DarknetTrainFn(torch.autograd.Function):
         sums_used = 0
         for i in order:
             blk = blocks[i]
+            L.y2_prof_set_tag(101 + i)                  # backward launches of block i: tag 101 + i
             h, w, cout, cin, k = blk.H, blk.W, blk.cout, blk.cin, blk.k
             sums = sums_arena[sums_used:sums_used + 2 * cout]
             sums_used += 2 * cout
@@ -279,15 +345,19 @@ class DarknetTrainFn(torch.autograd.Function):
                 _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cop, cin, k, st), 'y2_unpack_weight_grad')
                 ready(weight, dw if cop == cout else dw[:cout].contiguous())
                 # data gradient -> the producer's gradient source
-                wsrc = _hip.f32c(weight.detach())
-                if cop != cout:
-                    wpad = torch.zeros(cop, cin, k, k, dtype=torch.float32, device=dev)
-                    wpad[:cout] = wsrc                                   # zero rows for the padded output channels
-                    wsrc = wpad
-                wd = _new(dev, wsrc.numel())
-                _hip.check(L.y2_pack_weight(_hip.ptr(wsrc), _hip.ptr(wd), cop, cin, k, 1, st), 'y2_pack_weight')
                 dx = _new(dev, B, h, w, cin)
-                _conv(L, st, dz, wd, dx, B, h, w, cop, cop, cin, k, cin)
+                ready_ops = ctx.prepared.get(blk.mod)
+                if ready_ops is not None:        # rotated / in-out-swapped operands prepared with the forward's (same parameter version)
+                    _conv(L, st, dz, ready_ops['wd'], dx, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'])
+                else:
+                    wsrc = _hip.f32c(weight.detach())
+                    if cop != cout:
+                        wpad = torch.zeros(cop, cin, k, k, dtype=torch.float32, device=dev)
+                        wpad[:cout] = wsrc                                   # zero rows for the padded output channels
+                        wsrc = wpad
+                    wd = _new(dev, wsrc.numel())
+                    _hip.check(L.y2_pack_weight(_hip.ptr(wsrc), _hip.ptr(wd), cop, cin, k, 1, st), 'y2_pack_weight')
+                    _conv(L, st, dz, wd, dx, B, h, w, cop, cop, cin, k, cin)
                 # route dx
                 if blk.name == 'layers3.0':
                     dcat = dx                                           # [B,h,w,4*c_pt + c_l2]
@@ -305,10 +375,12 @@ class DarknetTrainFn(torch.autograd.Function):
                     else:
                         src_full[prod] = (dx, cin, 0, 0)
             blk.z = None   # free as we go
+        L.y2_prof_set_tag(0)
         out = [None, None]
         for pid in ctx.param_ids:
             out.append(grads.get(pid))
         ctx.blocks = None
+        ctx.prepared = None
         return tuple(out)
 
 
