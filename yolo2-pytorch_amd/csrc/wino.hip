@@ -225,12 +225,13 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 //   * epilogue: accumulator register r of the 16 positions belongs to the same (tile, channel): 24 adds give the 2x2 output
 //     pixels, then affine + LeakyReLU, optional 2x2 max-pool (a tile is a pooling window) and BN statistics (valid pixels only).
 constexpr int WF_POS_FLOATS = (64 + 64) * 32;      // one position's A + B slab (16 KB)
-constexpr int WF2_DEFAULT_VARIANT = 7;             // which fused kernel y2_conv_fwd launches by default: -1 = first generation, else the feature mask of wino_fused2_kernel
+constexpr int WF2_DEFAULT_VARIANT = 3;             // which fused kernel y2_conv_fwd launches by default: -1 = first generation, else the feature mask of wino_fused2_kernel
 
 struct WinoFusedArgs {
     const float* v;       // [16][T][Cin]
     const float* u;       // [16][Cout][Cin]
     const int32_t* tile_pix;   // [T] (wino_input_kernel): output pixel index of each tile + edge flags
+    float* dump;               // >= 256 floats of scratch: where the lanes of pixels / tiles / channels that do not exist store (branch-free epilogue)
     const float* scale; const float* shift;
     float* y; float* y_pool; double* stats;
     int H, W, Cin, Cout, ldy, coff, ldp, poff, th, tw, T, tiles_m, tiles_n;
@@ -450,22 +451,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // ---- fused kernel, second generation.  Same tile (64 tiles x 64 channels x 16 positions per workgroup, 4 waves, 256 accumulator
 // registers, one wave per SIMD, 2 x 64 KB LDS ring) and the same arithmetic (bit-identical results) as wino_fused_kernel; what
 // changes is the instruction stream of the single wave a SIMD runs, because with one wave nothing else hides a stall:
-//   VAR bit 0  DMA spread: the 16 LDS-DMA instructions that fetch stage s+1 are issued two at a time behind the first 8 groups of
-//              four MFMAs of stage s (an LDS-DMA issue costs ~60 cycles, a 32x32x2 fp32 MFMA occupies the pipe for 64) instead of
-//              all 16 in front of the stage's first MFMAs (~0.7k of 4.1k cycles per stage with an idle matrix pipe); the second
-//              half of the stage is left for them to land before the next vmcnt(0).  The fetch stream runs ACROSS tiles: the last
-//              stage of a tile fetches the first stage of the workgroup's next tile.
-//   VAR bit 1  fragment double buffering: the 8 ds_read_b128 of k-group q+1 are issued before the 16 MFMAs of group q.
-//   VAR bit 2  deferred epilogue: after a tile's K loop only the output transform runs (accumulators -> 4 outputs per element in
-//              64 VGPRs); affine + LeakyReLU + pooling + statistics + stores of those outputs are interleaved, row by row, with the
-//              MFMAs of the NEXT tile's first two stages (the tile row index is wave-uniform up to the lane half, so its decode runs
-//              on the scalar unit).  The last tile of a workgroup drains its outputs after the loop.
-//   VAR bit 3  no accumulator clearing: the first MFMA of every accumulator of a tile takes the constant 0 as its C operand.
-// Every MFMA "slot" ends with a scheduling barrier so that the compiler keeps the hand-placed interleave.
-template <int VAR>
+//   * DMA spread (VAR bit 0): the 16 LDS-DMA instructions that fetch stage s+1 are issued two at a time behind the first 8 groups
+//     of four MFMAs of stage s (an LDS-DMA issue costs ~60 cycles, a 32x32x2 fp32 MFMA occupies the pipe for 64) instead of all 16
+//     in front of the stage's first MFMAs (~0.7k of 4.1k cycles per stage with an idle matrix pipe); the second half of the stage is
+//     left for them to land before the next vmcnt(0) (one piece per slot over the whole stage measured 4-8 % slower).  The fetch
+//     stream runs ACROSS tiles: the last stage of a tile fetches the first stage of the workgroup's next tile.
+//   * fragment double buffering (VAR bit 1): the 8 ds_read_b128 of k-group q+1 are issued before the 16 MFMAs of group q.
+//   * branch-free epilogue with compile-time output set (OUT): pixels / tiles / channels that do not exist store to a dump area
+//     instead of being predicated off, the tile row -> pixel decode comes from a table wino_input_kernel writes (one entry per
+//     tile), and y / pooled output / statistics are template flags.  No control flow, ~40 instead of ~190 instructions per row.
+//   Every MFMA "slot" ends with a scheduling barrier so that the compiler keeps the hand-placed DMA interleave.
+// Measured B=32 (kernel alone, first generation -> this): 104x104 Cin 64 0.319 -> 0.243 ms, 52x52 Cin 128 0.272 -> 0.211,
+// 26x26 Cin 256 0.250 -> 0.196, 26x26 Cin 512 0.457 -> 0.371, 13x13 Cin 512 0.310 -> 0.251 (93 / 108 / 116 / 122 / 105 TF/s).
+// Negative results kept out of the code: (a) deferring the output rows into the next tile's first stages (interleaved row by row,
+// or phase by phase behind single MFMAs) was 8-25 % SLOWER than this stand-alone epilogue once it was branch-free - the extra 64
+// live VGPRs spill and the VALU/stores delay MFMA issue; (b) exchanging the MFMA operand roles (accumulator rows = channels, so
+// a lane stores 16 bytes) lost 10-30 %: 64 lanes x 16 B to 64 different cache lines per store instruction; (c) skipping the
+// filter-operand DMA altogether (a wrong-result experiment) gains only 2-6 %: the K loop is not LDS-DMA-bandwidth bound.
+template <int VAR, int OUT>     // OUT: bit 0 = full-resolution output y, bit 1 = pooled output, bit 2 = BatchNorm statistics
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fused2_kernel(const WinoFusedArgs a) {
-    constexpr bool SPREAD = (VAR & 1) != 0, DBUF = (VAR & 2) != 0, DEFER = (VAR & 4) != 0, ZEROC = false;
-    constexpr int DMODE = (VAR >> 3) & 3;          // experiments: 0 = two pieces per slot in slots 0-7, 1 = one per slot in all 16, 2 = four per slot in slots 0-3
+    constexpr bool HAS_Y = (OUT & 1) != 0, HAS_POOL = (OUT & 2) != 0, HAS_STATS = (OUT & 4) != 0;
+    constexpr bool SPREAD = (VAR & 1) != 0, DBUF = (VAR & 2) != 0;
     constexpr unsigned OOB = 0x80000000u;
     constexpr int PG = 4;
     constexpr int STAGE_FLOATS = PG * WF_POS_FLOATS;          // 64 KB
@@ -518,70 +524,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int q = 0; q < 4; ++q) foff[q] = l31 * 32 + (((2 * q + half) ^ sw) << 2);
     const int fa = wm * 32 * 32, fb = 64 * 32 + wn * 32 * 32;
 
-    // ---- deferred outputs of the previous tile
-    float o[16][4];                               // [register r][2*i + j]: raw output pixel (i, j) of tile row r, this lane's channel
-    int prow[16];                                 // tile_pix entry of tile row r (this lane's half), -1 beyond the last tile
-    bool pending = false;
-    int pm0 = 0;                                  // origin of the tile the pending outputs belong to
-    int pn = 0;                                   // this lane's channel of that tile
-    float psc = 1.f, psh = 0.f;
-    float s1 = 0.f, s2 = 0.f;
-    const size_t row_stride = (size_t)a.W * a.ldy;
-
-    // affine + activation + pooling + statistics + stores of tile row r (one of 16) of the pending tile
-    auto emit_row = [&](int r) {
-        const int e = prow[r];
-        if (e == -1 || pn >= a.Cout) return;     // (a real entry is never -1: bits 30 and 31 set would need a pixel index of 2^30 - 1)
-        const bool y1 = (e & 0x40000000) != 0, x1 = e < 0;
-        const unsigned pix = (unsigned)e & 0x3fffffffu;
-        float v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = o[r][k];
-        if (a.stats != nullptr) {
-            s1 += v[0]; s2 += v[0] * v[0];
-            if (x1) { s1 += v[1]; s2 += v[1] * v[1]; }
-            if (y1) { s1 += v[2]; s2 += v[2] * v[2]; }
-            if (y1 && x1) { s1 += v[3]; s2 += v[3] * v[3]; }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float uu = v[k] * psc + psh;
-            v[k] = uu > 0.f ? uu : uu * a.slope;
-        }
-        if (a.y != nullptr) {
-            float* dst = a.y + (size_t)pix * a.ldy + a.coff + pn;
-            dst[0] = v[0];
-            if (x1) dst[a.ldy] = v[1];
-            if (y1) {
-                dst[row_stride] = v[2];
-                if (x1) dst[row_stride + a.ldy] = v[3];
-            }
-        }
-        if (a.y_pool != nullptr) {               // H, W even: the pooled pixel index IS the tile index
-            const int tt = pm0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            a.y_pool[(size_t)tt * a.ldp + a.poff + pn] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-        }
-    };
-    auto flush_stats = [&]() {
-        if (a.stats != nullptr) {
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (half == 0 && pn < a.Cout) {
-                double* st = a.stats + (size_t)((pm0 >> 6) % Y2_STATS_REPL) * 2 * a.Cout;
-                atomicAdd(st + pn, (double)s1);
-                atomicAdd(st + a.Cout + pn, (double)s2);
-            }
-            s1 = 0.f; s2 = 0.f;
-        }
-    };
-
-    // ---- one pipeline stage: consume ring slot SLOT into the 4 accumulators c[0..3].
-    //   FETCH: also issue the 16 DMA pieces of stage (fk, fg) into the other slot.   FIRST: these accumulators start at 0.
-    //   EROW0 >= 0: also emit the pending rows EROW0 .. EROW0+7.
-    auto stage = [&](auto SLOT, f32x16* c, auto FETCH, int fk, int fg, auto FIRST, auto EROW0) {
+    // ---- one pipeline stage: consume ring slot SLOT into the 4 accumulators c[0..3];  FETCH: also issue the 16 DMA pieces of
+    //      stage (fk, fg) into the other slot
+    auto stage = [&](auto SLOT, f32x16* c, auto FETCH, int fk, int fg) {
         constexpr int slot = decltype(SLOT)::value;
-        constexpr bool fetch = decltype(FETCH)::value, first = decltype(FIRST)::value;
-        constexpr int erow0 = decltype(EROW0)::value;
+        constexpr bool fetch = decltype(FETCH)::value;
         const float* sbuf = smem + slot * STAGE_FLOATS;
         f32x4 av[2][PG], bv[2][PG];
         auto reads = [&](int q, int buf) {
@@ -605,20 +552,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const int sl = q * 4 + e;                 // MFMA slot 0..15 of the stage
 #pragma unroll
                 for (int pp = 0; pp < PG; ++pp) {
-                    if (first && ZEROC && q == 0 && e == 0) {
-                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        c[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][pp][e], bv[cb][pp][e], z, 0, 0, 0);
-                    } else {
-                        c[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][pp][e], bv[cb][pp][e], c[pp], 0, 0, 0);
-                    }
-                    // behind MFMA pp of slot sl: two DMA pieces per slot in the first 8 slots (after MFMAs 0 and 2), one pending row per
-                    // two slots (after MFMA 1 of the even slots)
-                    if (SPREAD && fetch) {
-                        if (DMODE == 0 && sl < 8 && (pp == 0 || pp == 2)) dma_piece(fk, fg, slot ^ 1, 2 * sl + (pp >> 1));
-                        if (DMODE == 1 && pp == 0) dma_piece(fk, fg, slot ^ 1, sl);
-                        if (DMODE == 2 && sl < 4) dma_piece(fk, fg, slot ^ 1, 4 * sl + pp);
-                    }
-                    if (DEFER && erow0 >= 0 && pp == 1 && (sl & 1) == 0) emit_row(erow0 + (sl >> 1));
+                    c[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][pp][e], bv[cb][pp][e], c[pp], 0, 0, 0);
+                    // two DMA pieces per slot in the first 8 slots, behind MFMAs 0 and 2 of the slot
+                    if (SPREAD && fetch && sl < 8 && (pp == 0 || pp == 2)) dma_piece(fk, fg, slot ^ 1, 2 * sl + (pp >> 1));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -629,55 +565,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     using F_ = std::false_type;
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    using NoRow = std::integral_constant<int, -1>;
-    using Row0 = std::integral_constant<int, 0>;
-    using Row8 = std::integral_constant<int, 8>;
 
+    float* const dump = a.dump + t;
+    const size_t row_stride = (size_t)a.W * a.ldy;
     const int nks = a.Cin / 32;                  // host guarantees nks >= 2: every tile runs 4 * nks stages, an even number, so a
     // prologue: the first stage of the first tile     // tile always starts in ring slot 0 and stage g of a K slab sits in slot g & 1
 #pragma unroll
     for (int j = 0; j < 16; ++j) dma_piece(0, 0, 0, j);
     for (;;) {
         const int em0 = fm0, en0 = fn0;           // this tile's origin (the fetch cursor is still on this tile)
-        if (!ZEROC) {
 #pragma unroll
-            for (int p = 0; p < 16; ++p)
+        for (int p = 0; p < 16; ++p)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-        }
+            for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 #define Y2_WF2_SYNC()                                              \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           \
         __builtin_amdgcn_s_barrier()
-        // ---- first K slab: carries the previous tile's deferred rows in its first two stages
-        Y2_WF2_SYNC();
-        if (DEFER && pending) stage(S0{}, &acc[0], T_{}, 0, 1, T_{}, Row0{}); else stage(S0{}, &acc[0], T_{}, 0, 1, T_{}, NoRow{});
-        Y2_WF2_SYNC();
-        if (DEFER && pending) { stage(S1{}, &acc[4], T_{}, 0, 2, T_{}, Row8{}); flush_stats(); pending = false; } else stage(S1{}, &acc[4], T_{}, 0, 2, T_{}, NoRow{});
-        Y2_WF2_SYNC();
-        stage(S0{}, &acc[8], T_{}, 0, 3, T_{}, NoRow{});
-        Y2_WF2_SYNC();
-        stage(S1{}, &acc[12], T_{}, 1, 0, T_{}, NoRow{});
-        // ---- steady K slabs
-        for (int ks = 1; ks < nks - 1; ++ks) {
+        for (int ks = 0; ks < nks - 1; ++ks) {
             Y2_WF2_SYNC();
-            stage(S0{}, &acc[0], T_{}, ks, 1, F_{}, NoRow{});
+            stage(S0{}, &acc[0], T_{}, ks, 1);
             Y2_WF2_SYNC();
-            stage(S1{}, &acc[4], T_{}, ks, 2, F_{}, NoRow{});
+            stage(S1{}, &acc[4], T_{}, ks, 2);
             Y2_WF2_SYNC();
-            stage(S0{}, &acc[8], T_{}, ks, 3, F_{}, NoRow{});
+            stage(S0{}, &acc[8], T_{}, ks, 3);
             Y2_WF2_SYNC();
-            stage(S1{}, &acc[12], T_{}, ks + 1, 0, F_{}, NoRow{});
+            stage(S1{}, &acc[12], T_{}, ks + 1, 0);
         }
         // ---- last K slab; its last stage fetches the first stage of the workgroup's next tile
         Y2_WF2_SYNC();
-        stage(S0{}, &acc[0], T_{}, nks - 1, 1, F_{}, NoRow{});
+        stage(S0{}, &acc[0], T_{}, nks - 1, 1);
         Y2_WF2_SYNC();
-        stage(S1{}, &acc[4], T_{}, nks - 1, 2, F_{}, NoRow{});
+        stage(S1{}, &acc[4], T_{}, nks - 1, 2);
         Y2_WF2_SYNC();
-        stage(S0{}, &acc[8], T_{}, nks - 1, 3, F_{}, NoRow{});
+        stage(S0{}, &acc[8], T_{}, nks - 1, 3);
         tile += wgs_per_xcd;
         const bool more = tile < xcd_end;
-        // decode-table entries of this tile's 16 rows (two distinct addresses per wave: L1/L2 broadcast); in flight during the last stage
+        // decode-table entries of this tile's 16 rows (two distinct addresses per wave: broadcast loads), in flight during the last stage
+        int prow[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int tt = em0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -686,16 +610,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         Y2_WF2_SYNC();
         if (more) {
             place(tile);
-            stage(S1{}, &acc[12], T_{}, 0, 0, F_{}, NoRow{});
+            stage(S1{}, &acc[12], T_{}, 0, 0);
         } else {
-            stage(S1{}, &acc[12], F_{}, 0, 0, F_{}, NoRow{});
+            stage(S1{}, &acc[12], F_{}, 0, 0);
         }
 #undef Y2_WF2_SYNC
-        // ---- output transform A^T M A: accumulator register r of the 16 positions belongs to the same (tile row, channel)
-        pm0 = em0;
-        pn = en0 + wn * 32 + l31;
-        psc = (a.scale != nullptr && pn < a.Cout) ? a.scale[pn] : 1.f;
-        psh = (a.shift != nullptr && pn < a.Cout) ? a.shift[pn] : 0.f;
+        // ---- epilogue: output transform A^T M A in registers (accumulator register r of the 16 positions belongs to the same
+        //      (tile row, channel)), then affine + LeakyReLU, pooling, statistics, stores - branch-free
+        const int pn = en0 + wn * 32 + l31;
+        const bool nok = pn < a.Cout;
+        const float psc = (a.scale != nullptr && nok) ? a.scale[pn] : 1.f;
+        const float psh = (a.shift != nullptr && nok) ? a.shift[pn] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float sm[2][4];
@@ -704,20 +630,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 sm[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
                 sm[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
             }
+            float o[4];                                       // o[2*i + j]: raw output pixel (i, j) of the tile
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                o[r][2 * i + 0] = sm[i][0] + sm[i][1] + sm[i][2];
-                o[r][2 * i + 1] = sm[i][1] - sm[i][2] - sm[i][3];
+                o[2 * i + 0] = sm[i][0] + sm[i][1] + sm[i][2];
+                o[2 * i + 1] = sm[i][1] - sm[i][2] - sm[i][3];
             }
-            if (!DEFER) { emit_row(r); __builtin_amdgcn_sched_barrier(0); }
-        }
-        pending = DEFER;
-        if (!DEFER) flush_stats();
-        if (DEFER && !more) {
+            const int e = prow[r];
+            const bool ok = e != -1 && nok;                   // (a real entry is never -1: bits 30 and 31 set would need a pixel index of 2^30 - 1)
+            const bool y1 = ok && (e & 0x40000000) != 0, x1 = ok && e < 0;
+            float* const dst = HAS_Y ? a.y + (size_t)((unsigned)e & 0x3fffffffu) * a.ldy + a.coff + pn : nullptr;
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { emit_row(r); __builtin_amdgcn_sched_barrier(0); }
-            flush_stats();
-            pending = false;
+            for (int k = 0; k < 4; ++k) {
+                const bool valid = k == 0 ? ok : (k == 1 ? x1 : (k == 2 ? y1 : (y1 && x1)));
+                if (HAS_STATS) { const float m = valid ? o[k] : 0.f; s1 += m; s2 += m * m; }
+                const float uu = o[k] * psc + psh;
+                v[k] = uu > 0.f ? uu : uu * a.slope;
+                if (HAS_Y) {
+                    float* p = dst + ((k & 1) ? a.ldy : 0) + ((k >> 1) ? row_stride : 0);
+                    *(valid ? p : dump) = v[k];
+                }
+            }
+            if (HAS_POOL) {                                   // H, W even (host check): the pooled pixel index IS the tile index
+                const int tt = em0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float* p = a.y_pool + (size_t)tt * a.ldp + a.poff + pn;
+                *(ok ? p : dump) = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            }
+        }
+        if (HAS_STATS) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (half == 0 && nok) {
+                double* st = a.stats + (size_t)((em0 >> 6) % Y2_STATS_REPL) * 2 * a.Cout;
+                atomicAdd(st + pn, (double)s1);
+                atomicAdd(st + a.Cout + pn, (double)s2);
+            }
         }
         if (!more) break;
     }
@@ -848,7 +796,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     const long long T = (long long)cb * th * tw;    // tiles of a full chunk
     if (T * (p->Cin / 4) >= 0xffffffffLL || T * (p->Cout / 4) >= 0xffffffffLL || T > 0x7fffffff) return Y2_ENOSUP;
     const size_t vbytes = align256((size_t)16 * T * p->Cin * sizeof(float));
-    const size_t mbytes = fused ? align256((size_t)T * sizeof(int32_t)) : align256((size_t)16 * T * p->Cout * sizeof(float));   // fused: tile decode table
+    const size_t mbytes = fused ? align256((size_t)T * sizeof(int32_t)) + 1024 : align256((size_t)16 * T * p->Cout * sizeof(float));   // fused: tile decode table + 1 KB dump area
     if (fused && (vbytes >= 0x7fffffffull || (size_t)16 * p->Cout * p->Cin * 4 >= 0x7fffffffull)) return Y2_ENOSUP;
 
     // stage 2 as a grouped 1x1 "convolution" over an image of 1 x T pixels
@@ -886,7 +834,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
 
         if (fused) {
             WinoFusedArgs fa;
-            fa.v = V; fa.u = p->w; fa.tile_pix = ia.tile_pix; fa.scale = p->scale; fa.shift = p->shift; fa.stats = p->stats;
+            fa.v = V; fa.u = p->w; fa.tile_pix = ia.tile_pix; fa.dump = M + (mbytes - 1024) / sizeof(float); fa.scale = p->scale; fa.shift = p->shift; fa.stats = p->stats;
             fa.y = p->y != nullptr ? p->y + in_off * p->ldy : nullptr;
             fa.y_pool = p->y_pool != nullptr ? p->y_pool + (size_t)b0 * th * tw * p->ldp : nullptr;
             fa.H = p->H; fa.W = p->W; fa.Cin = p->Cin; fa.Cout = p->Cout; fa.ldy = p->ldy; fa.coff = p->coff; fa.ldp = p->ldp; fa.poff = p->poff;
@@ -904,33 +852,38 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
                 if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(kern))) return rc_;                                  \
                 Y2_LAUNCH("wino_fused_kernel", 2.0 * 16.0 * (double)fa.T * fa.Cout * fa.Cin, kern, dim3((unsigned)grid), dim3(256), lds, s, fa);                                             \
             } while (0)
-#define Y2_WF2_LAUNCH(VAR_)                                                                                                        \
+#define Y2_WF2_LAUNCH_(VAR_, OUT_)                                                                                                 \
             do {                                                                                                                   \
-                auto kern = wino_fused2_kernel<VAR_>;                                                                              \
+                auto kern = wino_fused2_kernel<VAR_, OUT_>;                                                                        \
                 const size_t lds = (size_t)2 * 4 * WF_POS_FLOATS * sizeof(float);                                                  \
                 static Y2LdsAttr attr;                                                                                             \
                 if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(kern))) return rc_;                                  \
                 Y2_LAUNCH("wino_fused2_kernel", 2.0 * 16.0 * (double)fa.T * fa.Cout * fa.Cin, kern, dim3((unsigned)grid), dim3(256), lds, s, fa); \
             } while (0)
-            // second-generation instruction stream (see wino_fused2_kernel); Y2_WF_VARIANT = -1 selects the first generation, 0..15 a
-            // feature mask (experiments).  Its 32-bit output offsets need the output tensors below 2^31 elements.
+#define Y2_WF2_LAUNCH(VAR_)                                                                                                        \
+            do {                                                                                                                   \
+                if (out_mask == 1) Y2_WF2_LAUNCH_(VAR_, 1);                                                                        \
+                else if (out_mask == 2) Y2_WF2_LAUNCH_(VAR_, 2);                                                                   \
+                else if (out_mask == 3) Y2_WF2_LAUNCH_(VAR_, 3);                                                                   \
+                else if (out_mask == 5) Y2_WF2_LAUNCH_(VAR_, 5);                                                                   \
+                else Y2_WF2_LAUNCH_(VAR_, 7);                                                                                      \
+            } while (0)
+            const int out_mask = (p->y != nullptr ? 1 : 0) | (p->y_pool != nullptr ? 2 : 0) | (p->stats != nullptr ? 4 : 0);
+            // second-generation instruction stream (see wino_fused2_kernel); Y2_WF_VARIANT = -1 selects the first generation, 0 / 1 / 3 a
+            // feature mask (A/B runs).  Its 32-bit output offsets need the output tensors below 2^31 elements.
             const char* ve = getenv("Y2_WF_VARIANT");           // read per call (experiments / tests switch it at run time)
             const int variant = ve != nullptr ? atoi(ve) : WF2_DEFAULT_VARIANT;
             const bool small_out = (unsigned long long)p->B * p->H * p->W * (unsigned long long)(p->ldy > p->ldp ? p->ldy : p->ldp) < 0x7fffffffull;
             if (variant >= 0 && p->Cin >= 64 && small_out) {
                 switch (variant) {
-                    case 1: Y2_WF2_LAUNCH(1); break;
-                    case 5: Y2_WF2_LAUNCH(5); break;
-                    case 9: Y2_WF2_LAUNCH(9); break;       // 1 + DMA mode 1
-                    case 13: Y2_WF2_LAUNCH(13); break;     // 5 + DMA mode 1
-                    case 15: Y2_WF2_LAUNCH(15); break;     // 7 + DMA mode 1
-                    case 21: Y2_WF2_LAUNCH(21); break;     // 5 + DMA mode 2
-                    case 23: Y2_WF2_LAUNCH(23); break;     // 7 + DMA mode 2
-                    default: Y2_WF2_LAUNCH(7); break;
+                    case 0: Y2_WF2_LAUNCH(0); break;       // branch-free epilogue only
+                    case 1: Y2_WF2_LAUNCH(1); break;       // + DMA spread
+                    default: Y2_WF2_LAUNCH(3); break;      // + fragment double buffering
                 }
                 continue;
             }
 #undef Y2_WF2_LAUNCH
+#undef Y2_WF2_LAUNCH_
             // measured on the 52x52 / 26x26 / 13x13 layers (B=32): 4 positions per stage + 2-deep ring (64 MFMAs per wave between
             // barriers) 0.341 / 0.283 / 0.330 ms; 2 positions x 4-deep 0.357 / 0.289 / 0.336; 1 position x 6-deep 0.373 / 0.315 / 0.369
             Y2_WF_LAUNCH(4, 2);
