@@ -226,6 +226,21 @@ int y2_iou_pair_host(const float* yx_min1, const float* yx_max1, const float* yx
                      int n, float min_union, float* out);
 
 /* ------------------------------------------------------------------------------------------------
+ * Deterministic mode (opt-in, process-global; one process per GPU, one stream).  By default the split-K weight gradient, the
+ * BatchNorm-backward sums, the BatchNorm statistics and the loss sums combine partial results with atomics, in completion order:
+ * run-to-run differences of ~1e-6 relative.  y2_set_deterministic(1, ws, bytes) makes y2_conv_wgrad / _ex / y2_wino_wgrad /
+ * y2_conv0_wgrad / y2_bn_act_bwd / _ex / y2_region_loss_fwd write their partials into the scratch area `ws` (device memory, 16-B
+ * aligned, >= 1 MiB; 256 MiB covers Darknet-19 at batch 64; a call that needs more returns Y2_EINVAL) and add them in a fixed
+ * tree.  y2_conv_fwd / y2_conv0_fwd then refuse `stats` (Y2_ENOSUP): the forward statistics are taken by y2_colstats_det over the
+ * raw convolution output z [M, C] (row stride ld): stats = [sum z | sum z^2] in fp64, written (not added) to stats[0 .. 2C) -
+ * copy 0 of the Y2_STATS_REPL layout y2_bn_finalize reads (the caller keeps the other copies zero).  `workspace` of
+ * y2_colstats_det: min(1024, ceil(M / 256)) * 2 * C doubles.  NOT covered: y2_opt_grad_sumsq (gradient-norm clipping) and y2_colsum.
+ * ------------------------------------------------------------------------------------------------ */
+int y2_set_deterministic(int on, float* workspace, long long workspace_bytes);
+int y2_get_deterministic(void);
+int y2_colstats_det(const float* z, long long M, int32_t C, int32_t ld, double* stats, float* workspace, long long workspace_bytes, y2_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py, tools/): y2_prof_enable(1) clears the record table and starts bracketing EVERY kernel launch of
  * this library with a HIP event pair on the launch stream; y2_prof_enable(0) stops.  Record i = (kernel name, milliseconds
  * between its two events, multiply-add FLOPs the launch executes: 2*M*N*K of the GEMM it runs, 0 for non-GEMM kernels).

@@ -664,3 +664,108 @@ def test_multi_scale_training_steps_with_fused_adam_and_clip():
         seen.setdefault(S, []).append(lt)
     for S, ls in seen.items():
         assert ls[-1] < ls[0], (S, ls)              # the same batch at the same size: three Adam steps apart the loss went down
+
+
+# ------------------------------------------------------------------ deterministic mode
+def _one_training_step(S=96, B=3, seed=0):
+    import model
+    widths = dict(NARROW)
+    widths['layers1.5'] = 8
+    sd = odark.init_state_dict(5, 20, seed=seed, channels=widths, head_scale=1 / 8.0)
+    inf, anchors = build(sd)
+    inf.train()
+    x = synth.images(B, S, seed=1)
+    data = synth.norm_data(synth.labels(B, S, 20, seed=2), S, S, S // 32, S // 32)
+    pred = model._inference(inf, x.to(dev()))
+    loss, _ = model.loss(anchors, data, pred, 0.6)
+    sum(loss[k] * oloss.HPARAM[k] for k in loss).backward()
+    torch.cuda.synchronize()
+    out = {'loss.' + k: v.detach().cpu().clone() for k, v in loss.items()}
+    out.update({'grad.' + k: p.grad.detach().cpu().clone() for k, p in inf.dnn.named_parameters()})
+    out.update({'buf.' + k: b.detach().cpu().clone() for k, b in inf.dnn.named_buffers()})
+    return out
+
+
+def test_deterministic_mode_is_bit_reproducible_and_agrees_with_the_default_mode():
+    """y2_set_deterministic: fixed-order reductions (split-K weight gradient, BatchNorm backward sums, BatchNorm statistics via
+    y2_colstats_det, loss sums) and no timing-based algorithm selection.  Two runs of the same training step must agree BIT FOR BIT
+    (losses, every parameter gradient, running statistics); the default (atomic) mode must agree with it to rounding."""
+    import _hip
+    base = _one_training_step()
+    _hip.set_deterministic(True)
+    try:
+        assert _hip.lib().y2_get_deterministic() == 1
+        a = _one_training_step()
+        b = _one_training_step()
+        c = _one_training_step()
+    finally:
+        _hip.set_deterministic(False)
+    assert _hip.lib().y2_get_deterministic() == 0
+    for k in a:
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    worst = 0.0
+    for k in a:
+        if not a[k].is_floating_point():
+            continue
+        scale = base[k].double().abs().max().item()
+        err = (a[k].double() - base[k].double()).abs().max().item() / max(scale, 1e-30)
+        worst = max(worst, err)
+        assert err <= 2e-3, (k, err)     # default-mode atomics and a possibly different (timed) algorithm choice: same tolerance as the fp64-oracle test
+    print('deterministic vs default mode: worst relative difference %.2e' % worst)
+
+
+def test_deterministic_wgrad_matches_fp64_and_repeats():
+    """The K-split weight gradient under deterministic mode (partials + fixed-tree sum) against fp64 autograd, twice, bit-identical;
+    direct, Winograd (grouped) and first-layer kernels."""
+    import _hip
+    L = _hip.lib()
+    d = dev()
+    _hip.set_deterministic(True)
+    try:
+        g = torch.Generator().manual_seed(5)
+        B, cin, cout, H, W = 4, 64, 128, 26, 26
+        x = torch.randn(B, cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+        w = (torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+        dz = torch.randn(B, cout, H, W, generator=g, dtype=torch.float64)
+        F.conv2d(x, w, padding=1).backward(dz)
+        xd, dzd = nhwc(x.detach().float()).to(d), nhwc(dz.float()).to(d)
+        outs = []
+        for rep in range(2):
+            dwp = torch.full((w.numel(),), 3.0, device=d)          # deterministic mode writes, it does not accumulate
+            _hip.check(L.y2_conv_wgrad(_hip.ptr(xd), _hip.ptr(dzd), _hip.ptr(dwp), B, H, W, cin, cin, cout, cout, 3, _hip.stream()), 'wgrad')
+            ws = torch.empty(L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout) // 4 + 4, device=d)
+            dwq = torch.full((w.numel(),), 3.0, device=d)
+            _hip.check(L.y2_wino_wgrad(_hip.ptr(xd), _hip.ptr(dzd), _hip.ptr(dwq), B, H, W, cin, cin, cout, cout, None, _hip.ptr(ws), ws.numel() * 4, _hip.stream()), 'wino_wgrad')
+            outs.append((dwp.clone(), dwq.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        for t, tol in ((outs[0][0], TOL), (outs[0][1], 4 * TOL)):
+            dw = torch.empty(cout, cin, 3, 3, device=d)
+            _hip.check(L.y2_unpack_weight_grad(_hip.ptr(t), _hip.ptr(dw), cout, cin, 3, _hip.stream()), 'unpack')
+            assert rel(dw, w.grad) <= tol
+        # first layer
+        x0 = torch.randn(3, 3, 64, 64, generator=g, dtype=torch.float64, requires_grad=True)
+        w0 = (torch.randn(32, 3, 3, 3, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+        dz0 = torch.randn(3, 32, 64, 64, generator=g, dtype=torch.float64)
+        F.conv2d(x0, w0, padding=1).backward(dz0)
+        x0d, dz0d = x0.detach().float().to(d).contiguous(), nhwc(dz0.float()).to(d)
+        r = []
+        for rep in range(2):
+            dw0 = torch.full((32, 3, 3, 3), 5.0, device=d)
+            _hip.check(L.y2_conv0_wgrad(_hip.ptr(x0d), _hip.ptr(dz0d), _hip.ptr(dw0), 3, 64, 64, 3, 32, 32, _hip.stream()), 'conv0_wgrad')
+            r.append(dw0.clone())
+        assert torch.equal(r[0], r[1]) and rel(r[0], w0.grad) <= TOL
+        # the convolution refuses epilogue statistics in this mode (they would be atomics)
+        p = _hip.ConvParams()
+        st = torch.zeros(_hip.STATS_REPL * 2 * cout, dtype=torch.float64, device=d)
+        y = torch.empty(B, H, W, cout, device=d)
+        wp = torch.empty(w.numel(), device=d)
+        p.x, p.w, p.y, p.stats = xd.data_ptr(), wp.data_ptr(), y.data_ptr(), st.data_ptr()
+        p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize, p.ldy, p.slope = B, H, W, cin, cin, cout, 3, cout, 1.0
+        assert L.y2_conv_fwd(ctypes.byref(p), _hip.stream()) == -3
+        # ... and y2_colstats_det gives the sums the epilogue would have
+        z = torch.randn(B * H * W, cout, generator=g).to(d)
+        _hip.colstats_det(z, B * H * W, cout, cout, st)
+        ref = torch.cat([z.double().sum(0), (z.double() ** 2).sum(0)])
+        assert torch.allclose(st[:2 * cout], ref, rtol=1e-12, atol=1e-9) and float(st[2 * cout:].abs().max()) == 0.0
+    finally:
+        _hip.set_deterministic(False)

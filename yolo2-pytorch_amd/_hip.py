@@ -94,6 +94,9 @@ SIGNATURES = {
     'y2_nms_host': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     'y2_iou_matrix_host': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p],
     'y2_iou_pair_host': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p],
+    'y2_set_deterministic': [c_int, c_void_p, ctypes.c_longlong],
+    'y2_get_deterministic': [],
+    'y2_colstats_det': [c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p, c_void_p, ctypes.c_longlong, c_void_p],
     'y2_prof_enable': [c_int],
     'y2_prof_count': [],
     'y2_prof_set_tag': [c_int],
@@ -175,6 +178,47 @@ def mutated():
 
 def epoch():
     return _EPOCH[0]
+
+
+# ---- deterministic mode (include/yolo2_hip.h: y2_set_deterministic): fixed-order reductions instead of atomics, heuristic instead of
+# timed algorithm selection.  Y2_DETERMINISTIC=1 turns it on at the first GPU use; set_deterministic() switches at run time.
+DETERMINISTIC = os.environ.get('Y2_DETERMINISTIC', '0') == '1'
+_DET_WS = {}
+_DET_BYTES = int(os.environ.get('Y2_DET_WS_MB', '256')) << 20
+
+
+def set_deterministic(on, dev=None):
+    """Bit-reproducible training on `dev` (default: the current GPU): the library's reductions go through a scratch area owned here."""
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
+    L = lib()
+    if not on:
+        check(L.y2_set_deterministic(0, None, 0), 'y2_set_deterministic')
+        return
+    dev = torch.device('cuda', torch.cuda.current_device()) if dev is None else torch.device(dev)
+    ws = _DET_WS.get(str(dev))
+    if ws is None:
+        ws = torch.empty(_DET_BYTES // 4, dtype=torch.float32, device=dev)
+        _DET_WS[str(dev)] = ws
+    check(L.y2_set_deterministic(1, ws.data_ptr(), ws.numel() * 4), 'y2_set_deterministic')
+
+
+def ensure_deterministic(dev):
+    """Called by the training graph: arm the library when the mode was requested (env / set_deterministic) but not yet armed on this device."""
+    if DETERMINISTIC and (str(torch.device(dev)) not in _DET_WS or not lib().y2_get_deterministic()):
+        set_deterministic(True, dev)
+    return DETERMINISTIC
+
+
+def colstats_det(z, M, C, ld, stats):
+    """Deterministic BatchNorm statistics of the raw convolution output into copy 0 of a zeroed stats buffer (y2_colstats_det)."""
+    G = min(1024, (M + 255) // 256)
+    key = 'colstats:' + str(z.device)
+    ws = _DET_WS.get(key)
+    if ws is None or ws.numel() * 4 < G * 2 * C * 8:
+        ws = torch.empty(max(G * 2 * C * 2, 1 << 18), dtype=torch.float32, device=z.device)
+        _DET_WS[key] = ws
+    check(lib().y2_colstats_det(ptr(z), M, C, ld, ptr(stats), ptr(ws), ws.numel() * 4, stream()), 'y2_colstats_det')
 
 
 _WS = {}
@@ -272,11 +316,11 @@ def autotune_conv(params, dev, wino_w=None):
             if lib().y2_conv_fwd_workspace_bytes(ctypes.byref(params)) >= 0:
                 return want
         return apply((0, 0))
-    hit = _TUNE.get(key)
+    hit = None if DETERMINISTIC else _TUNE.get(key)      # deterministic mode ignores measured choices (they may differ between runs)
     if hit is not None:
         return apply(tuple(hit) if isinstance(hit, (list, tuple)) else (0, hit))
-    if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
-        # no measurement possible: the choices the measurements converge to on MI355X (profiles/r01_detect_b32_layer_table.txt)
+    if not AUTOTUNE or DETERMINISTIC or torch.cuda.is_current_stream_capturing():
+        # no measurement possible (or, deterministic mode: a timed choice may differ from run to run and with it the rounding): the choices the measurements converge to on MI355X (profiles/r01_detect_b32_layer_table.txt)
         prefer = []
         if wino_ok and params.Cin % 32 == 0 and params.H * params.W >= 26 * 26:
             prefer.append((2, 0))       # fused Winograd on the 104x104 ... 26x26 layers
@@ -336,7 +380,7 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None):
     nw = cout * cin * k * k
     eligible = wino_eligible(cout, cin, k) and not (ldx % 4) and not (ldz % 4)
     key = ('wgrad', B, H, W, cin, ldx, cout, ldz, v is not None, str(dev))
-    choice = _TUNE.get(key) if eligible else 0
+    choice = (None if DETERMINISTIC else _TUNE.get(key)) if eligible else 0
     # the direct kernel accumulates split partial sums into a zeroed buffer; the Winograd path overwrites (no fill needed)
     dwp = torch.empty(nw, dtype=torch.float32, device=dev) if choice == 1 else torch.zeros(nw, dtype=torch.float32, device=dev)
 
@@ -354,7 +398,7 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None):
     def wino():
         check(L.y2_wino_wgrad(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, ptr(v), ptr(ws), ws.numel() * 4, st), 'y2_wino_wgrad')
     if choice is None:
-        if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        if not AUTOTUNE or DETERMINISTIC or torch.cuda.is_current_stream_capturing():
             choice = 1 if cin >= 128 else 0
         else:
             times = []

@@ -46,6 +46,12 @@ struct Y2LdsAttr {
     }
 };
 
+// ---- deterministic mode (det.hip; include/yolo2_hip.h: y2_set_deterministic): reductions write partials into `ws` and add them
+// in a fixed tree instead of using atomics.  Process-global opt-in state; the scratch area is reused by consecutive calls on one stream.
+struct Y2Det { int on; float* ws; size_t bytes; };
+__attribute__((visibility("hidden"))) extern Y2Det y2_det;
+__attribute__((visibility("hidden"))) int y2_det_reduce_f32(const float* part, int R, long long N, long long stride, double* out_d, float* out_f, hipStream_t s);
+
 // ---- measurement hooks (prof.hip; include/yolo2_hip.h: y2_prof_*): when recording is on, every kernel launch of the library is
 // bracketed by a HIP event pair on ITS launch stream and tagged with the multiply-add work it executes.
 __attribute__((visibility("hidden"))) extern int y2_prof_on;

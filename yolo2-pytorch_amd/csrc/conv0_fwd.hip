@@ -172,6 +172,7 @@ extern "C" int y2_conv0_fwd(const float* x_nchw, const float* w, const float* sc
     if (B <= 0 || H <= 0 || W <= 0 || Cin < 1 || Cin > 4 || Cout < 1 || Cout > 64) return Y2_ENOSUP;
     if (y != nullptr && ldy < Cout) return Y2_EINVAL;
     if (y_pool != nullptr && (ldp < Cout || (H & 1) || (W & 1))) return Y2_EINVAL;
+    if (stats != nullptr && y2_det.on) return Y2_ENOSUP;      // deterministic mode: statistics come from y2_colstats_det
     Conv0Args a;
     a.x = x_nchw; a.w = w; a.scale = scale; a.shift = shift; a.y = y; a.y_pool = y_pool; a.stats = stats;
     a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.ldy = ldy; a.ldp = ldp; a.slope = slope;

@@ -1120,6 +1120,7 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
     const bool pool = p->y_pool != nullptr;
     if (pool && ((p->H & 1) || (p->W & 1) || p->ldp < p->poff + p->Cout)) return Y2_EINVAL;
     if (p->residual != nullptr && (pool || p->out_mode != 0 || p->ldr < p->Cout)) return Y2_ENOSUP;
+    if (p->stats != nullptr && y2_det.on && ws_need == nullptr) return Y2_ENOSUP;      // deterministic mode: statistics come from y2_colstats_det, not from epilogue atomics
     const long long Min = (long long)p->B * p->H * p->W;
     const long long M = (long long)p->B * Ho * Wo;
     if (M > 0x7fffffffLL / 2 || Min > 0x7fffffffLL / 2) return Y2_EINVAL;

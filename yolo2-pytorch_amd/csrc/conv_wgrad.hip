@@ -30,6 +30,7 @@ struct WgradArgs {
     const float* x;     // [B,H,W,Cin] pixel stride ldx
     const float* dz;    // [B,H,W,Cout] pixel stride ldz
     float* dw;          // [Cout][taps*Cin], pre-zeroed
+    float* partial;     // deterministic mode: [groups][splits][Cout][taps*Cin] partial sums, plain stores (added by det_reduce_rows_kernel)
     int B, H, W, Cin, ldx, Cout, ldz, taps;   // H, W: spatial size of dz (the conv OUTPUT)
     int Hi, Wi, stride, pad, KW;              // conv input size, stride, padding, kernel width
     int M, tiles_i, tiles_j, splits, slabs_per_split;
@@ -245,6 +246,10 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int co = i0 + wm * WI + ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (co < a.Cout) {
+                    if (a.partial != nullptr) {
+                        a.partial[((size_t)(grp * a.splits + split) * a.Cout + co) * ncols + j] = acc[ib][jbk][r];
+                        continue;
+                    }
                     float* dst = gw_ptr + (size_t)co * ncols + j;
                     if (a.splits > 1) atomicAdd(dst, acc[ib][jbk][r]);
                     else *dst = acc[ib][jbk][r];
@@ -288,6 +293,12 @@ static int wgrad_impl(const float* x, const float* dz, float* dw, int B, int Hi,
     a.slabs_per_split = y2_cdiv(slabs, splits);
     a.splits = y2_cdiv(slabs, a.slabs_per_split);
     a.x_bytes = (unsigned)xb; a.dz_bytes = (unsigned)zb;
+    a.partial = nullptr;
+    const long long wsize = (long long)Cout * a.taps * Cin;            // floats per group
+    if (y2_det.on && a.splits > 1) {
+        if ((size_t)groups * a.splits * wsize * sizeof(float) > y2_det.bytes) return Y2_EINVAL;     // deterministic scratch too small
+        a.partial = y2_det.ws;
+    }
     const long long grid = (long long)tiles * a.splits * groups;
     if (grid > 0x7fffffffLL) return Y2_EINVAL;
     hipStream_t s = y2_s(stream);
@@ -303,6 +314,12 @@ static int wgrad_impl(const float* x, const float* dz, float* dw, int B, int Hi,
     else Y2_WGRAD_LAUNCH(128, 2);
 #undef Y2_WGRAD_LAUNCH
     Y2_LAUNCH_CHECK();
+    if (a.partial != nullptr) {       // fixed-order sum of the K-split partials; group g's result goes to dw + g*gw
+        for (int g = 0; g < groups; ++g) {
+            const int rc = y2_det_reduce_f32(a.partial + (size_t)g * a.splits * wsize, a.splits, wsize, wsize, nullptr, dw + (size_t)g * gw, s);
+            if (rc != Y2_OK) return rc;
+        }
+    }
     return Y2_OK;
 }
 
@@ -317,6 +334,7 @@ namespace {
 
 struct W0Args {
     const float* x; const float* dz; float* dw;
+    float* partial;      // deterministic mode: [gridDim.x][Cout*K] per-workgroup sums (plain stores)
     int B, H, W, Cin, Cout, ldz, rows_total;
 };
 
@@ -375,7 +393,8 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const W0Args a) {
         const int co = e >> 5, j = e & 31;
         if (co < a.Cout && j < K) {
             const float v = red[0][co * 33 + j] + red[1][co * 33 + j] + red[2][co * 33 + j] + red[3][co * 33 + j];
-            atomicAdd(a.dw + (size_t)co * K + j, v);
+            if (a.partial != nullptr) a.partial[(size_t)blockIdx.x * a.Cout * K + (size_t)co * K + j] = v;
+            else atomicAdd(a.dw + (size_t)co * K + j, v);
         }
     }
 }
@@ -388,9 +407,15 @@ extern "C" int y2_conv0_wgrad(const float* x_nchw, const float* dz, float* dw, i
     W0Args a;
     a.x = x_nchw; a.dz = dz; a.dw = dw; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldz = ldz; a.rows_total = B * H;
     const int grid = a.rows_total < 4 * 4 * Y2_NUM_CU ? y2_cdiv(a.rows_total, 4) : 4 * Y2_NUM_CU;
+    a.partial = nullptr;
+    if (y2_det.on) {
+        if ((size_t)grid * Cout * Cin * 9 * sizeof(float) > y2_det.bytes) return Y2_EINVAL;
+        a.partial = y2_det.ws;
+    }
     if (Cout <= 32) Y2_LAUNCH("conv0_wgrad_kernel", 2.0 * (double)B * H * W * 9 * Cin * Cout, (conv0_wgrad_kernel<1>), dim3(grid), dim3(256), 0, y2_s(stream), a);
     else Y2_LAUNCH("conv0_wgrad_kernel", 2.0 * (double)B * H * W * 9 * Cin * Cout, (conv0_wgrad_kernel<2>), dim3(grid), dim3(256), 0, y2_s(stream), a);
     Y2_LAUNCH_CHECK();
+    if (a.partial != nullptr) return y2_det_reduce_f32(a.partial, grid, (long long)Cout * Cin * 9, (long long)Cout * Cin * 9, nullptr, dw, y2_s(stream));
     return Y2_OK;
 }
 

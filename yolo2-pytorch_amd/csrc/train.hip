@@ -133,6 +133,7 @@ struct ActBwdArgs {
     const float* res; int ldr;          // residual that was added before the activation (decides the ReLU mask)
     float* dres; int lddr;              // optional output: gradient w.r.t. that residual (= gradient of the pre-activation sum)
     double* sums;      // [2C]: sum g, sum g*zhat
+    float* partial;    // deterministic mode (pass 1): [threads / Cg][2C] per-thread sums, plain stores (added by det_reduce_rows_kernel)
     float* dz;         // [B,H,W,C] stride ldd
     int B, H, W, C, ldz, ldf, foff, fmode, ldp, poff, ldd;
     float slope;
@@ -258,6 +259,12 @@ __global__ void bn_act_bwd_kernel(const ActBwdArgs a, long long total) {
                 }
             }
         }
+    }
+    if (!APPLY && a.partial != nullptr) {
+        float* row = a.partial + (size_t)(tid / Cg) * 2 * a.C;
+#pragma unroll
+        for (int e = 0; e < CV; ++e) { row[c + e] = s1[e]; row[a.C + c + e] = s2[e]; }
+        return;
     }
     if (!APPLY) {
 #pragma unroll
@@ -431,7 +438,7 @@ __device__ __forceinline__ void slot_targets(const LossArgs& a, int b, int i, fl
 }
 
 // sums[0..5] = foreground, background, center, size, cls (sum over positives), number of positives   (fp64 atomics)
-__global__ __launch_bounds__(256) void loss_fwd_kernel(const LossArgs a, double* sums) {
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const LossArgs a, double* sums, float* blocksums) {      // blocksums: deterministic mode, [blocks][6]
     __shared__ float part[6][4];
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -479,7 +486,8 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const LossArgs a, double*
     __syncthreads();
     if (threadIdx.x < 6) {
         const float x = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
-        if (x != 0.f) atomicAdd(sums + threadIdx.x, (double)x);
+        if (blocksums != nullptr) blocksums[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = x;
+        else if (x != 0.f) atomicAdd(sums + threadIdx.x, (double)x);
     }
 }
 
@@ -615,9 +623,19 @@ extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float*
     a.d_wo = y2_make_fastdiv((uint32_t)(pool ? W / 2 : W)); a.d_ho = y2_make_fastdiv((uint32_t)(pool ? H / 2 : H));
     const size_t lds = (size_t)2 * C * sizeof(float);
     hipStream_t s = y2_s(stream);
+    a.partial = nullptr;
+    const long long prow = (long long)grid * 256 / Cg;            // rows of per-thread partials (grid * 256 is a multiple of Cg)
+    if (y2_det.on) {
+        if ((size_t)prow * 2 * C * sizeof(float) > y2_det.bytes || prow > 0x7fffffffLL) return Y2_EINVAL;
+        a.partial = y2_det.ws;
+    }
 #define Y2_BWD(POOL, CV)                                                                                             \
     do {                                                                                                             \
         Y2_LAUNCH("bn_act_bwd_kernel", 0.0, (bn_act_bwd_kernel<POOL, CV, false>), dim3(grid), dim3(256), lds, s, a, total);            \
+        if (a.partial != nullptr) {                                                                                  \
+            const int rc_ = y2_det_reduce_f32(a.partial, (int)prow, (long long)2 * C, (long long)2 * C, sums, nullptr, s);            \
+            if (rc_ != Y2_OK) return rc_;                                                                            \
+        }                                                                                                            \
         Y2_LAUNCH("bn_act_bwd_kernel", 0.0, (bn_act_bwd_kernel<POOL, CV, true>), dim3(grid), dim3(256), 0, s, a, total);               \
     } while (0)
     if (pool) { if (vec) Y2_BWD(true, 4); else Y2_BWD(true, 1); }
@@ -693,7 +711,17 @@ extern "C" int y2_region_loss_fwd(const float* iou, const float* center_offset, 
     a.iou = iou; a.co = center_offset; a.sn = size_norm; a.logits = logits; a.best_iou = best_iou; a.best_idx = best_idx; a.positive = positive;
     a.gt_min = gt_yx_min; a.gt_max = gt_yx_max; a.gt_cls = gt_cls; a.gt_onehot = gt_onehot; a.anchors = anchors;
     a.B = B; a.n = n; a.N = N; a.A = A; a.C = C; a.threshold = threshold;
-    Y2_LAUNCH("loss_fwd_kernel", 0.0, loss_fwd_kernel, dim3(y2_cdiv(n, 256), B), dim3(256), 0, s, a, sums);
+    float* blocksums = nullptr;
+    const long long nblk = (long long)y2_cdiv(n, 256) * B;
+    if (y2_det.on) {
+        if ((size_t)nblk * 6 * sizeof(float) > y2_det.bytes) return Y2_EINVAL;
+        blocksums = y2_det.ws;
+    }
+    Y2_LAUNCH("loss_fwd_kernel", 0.0, loss_fwd_kernel, dim3(y2_cdiv(n, 256), B), dim3(256), 0, s, a, sums, blocksums);
+    if (blocksums != nullptr) {
+        const int rc = y2_det_reduce_f32(blocksums, (int)nblk, 6, 6, sums, nullptr, s);
+        if (rc != Y2_OK) return rc;
+    }
     Y2_LAUNCH("loss_finalize_kernel", 0.0, loss_finalize_kernel, dim3(1), dim3(64), 0, s, sums, (double)B * n, gt_cls != nullptr ? 1 : 0, loss_out);
     Y2_LAUNCH_CHECK();
     return Y2_OK;

@@ -167,6 +167,7 @@ class DarknetTrainFn(torch.autograd.Function):
         dev = x.device
         b1, b2, b3 = dnn._blocks()
         prepared = _train_operands(dnn, dev)
+        det = _hip.ensure_deterministic(dev)      # fixed-order reductions: BN statistics by y2_colstats_det instead of epilogue atomics
         # one zero-filled arena for every layer's replicated BN-statistics accumulators (one fill kernel instead of 22)
         couts = [m.conv.weight.shape[0] for _, m, _ in b1 + b2 + b3] + [dnn.passthrough.conv.weight.shape[0]]
         arena = torch.zeros(_hip.STATS_REPL * 2 * sum(couts), dtype=torch.float64, device=dev)
@@ -189,15 +190,18 @@ class DarknetTrainFn(torch.autograd.Function):
             blk.wino_v = None
             z = _new(dev, B, h, w, cout)
             stats = take(_hip.STATS_REPL * 2 * cout) if blk.has_bn else None
+            estats = None if det else stats          # statistics accumulated by the convolution's epilogue (atomics)
             if first:
-                _hip.check(L.y2_conv0_fwd(_hip.ptr(xin), _hip.ptr(_hip.f32c(weight)), None, None, _hip.ptr(z), None, _hip.ptr(stats),
+                _hip.check(L.y2_conv0_fwd(_hip.ptr(xin), _hip.ptr(_hip.f32c(weight)), None, None, _hip.ptr(z), None, _hip.ptr(estats),
                                           B, h, w, cin, cout, cout, 0, 1.0, st), 'y2_conv0_fwd')
             elif mod in prepared:
-                blk.wino_v = _conv(L, st, xin, prepared[mod]['wp'], z, B, h, w, cin, ldx, cout, k, cout, stats=stats, keep_v=True, u=prepared[mod]['uf'])
+                blk.wino_v = _conv(L, st, xin, prepared[mod]['wp'], z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=True, u=prepared[mod]['uf'])
             else:
                 wp = _new(dev, weight.numel())
                 _hip.check(L.y2_pack_weight(_hip.ptr(_hip.f32c(weight)), _hip.ptr(wp), cout, cin, k, 0, st), 'y2_pack_weight')
-                blk.wino_v = _conv(L, st, xin, wp, z, B, h, w, cin, ldx, cout, k, cout, stats=stats, keep_v=True)
+                blk.wino_v = _conv(L, st, xin, wp, z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=True)
+            if det and stats is not None:
+                _hip.colstats_det(z, B * h * w, cout, cout, stats)
             blk.z = z
             if blk.has_bn:
                 bn = mod.bn
@@ -588,7 +592,10 @@ class ResNetTrainFn(torch.autograd.Function):
             ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
             z = _new(dev, B, ho, wo, cout)
             stats = torch.zeros(_hip.STATS_REPL * 2 * cout, dtype=torch.float64, device=dev) if bn is not None else None
-            _gen_conv(L, st, xin, wp, z, B, h, w, ldx, ldx, cout, k, stride, pad, stats=stats)
+            det = _hip.ensure_deterministic(dev)
+            _gen_conv(L, st, xin, wp, z, B, h, w, ldx, ldx, cout, k, stride, pad, stats=None if det else stats)
+            if det and stats is not None:
+                _hip.colstats_det(z, B * ho * wo, cout, cout, stats)
             op.kind, op.conv, op.bn, op.x, op.ldx, op.h, op.w, op.ho, op.wo = 'conv', conv, bn, xin, ldx, h, w, ho, wo
             op.stride, op.pad, op.k, op.cin, op.cout, op.z, op.residual, op.slope, op.first = stride, pad, k, cin_true, cout, z, residual, slope, first
             if bn is not None:
