@@ -27,8 +27,14 @@ struct Conv0Args {
     int tiles_y, tiles_x;
 };
 
-template <int CIN, int NBLK>
+// OUT >= 0: the output set is a compile-time constant (bit 0 = y, bit 1 = pooled output, bit 2 = statistics); FULL: every tile lies
+// inside the image and Cout == 32 * NBLK, so the epilogue has no bounds checks.  With both, the epilogue is straight-line code
+// (the runtime-flag form spends more instructions on tests than on arithmetic).  OUT = -1, FULL = false: the general kernel.
+template <int CIN, int NBLK, int OUT = -1, bool FULL = false>
 __global__ __launch_bounds__(256) void conv0_kernel(const Conv0Args a) {
+    const bool has_y = OUT < 0 ? a.y != nullptr : (OUT & 1) != 0;
+    const bool has_pool = OUT < 0 ? a.y_pool != nullptr : (OUT & 2) != 0;
+    const bool has_stats = OUT < 0 ? a.stats != nullptr : (OUT & 4) != 0;
     constexpr int K = CIN * 9;
     constexpr int KS = (K + 1) / 2;
     __shared__ __attribute__((aligned(16))) float patch[CIN * PLANE];
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const Conv0Args a) {
 #pragma unroll
         for (int j = 0; j < NBLK; ++j) {
             const int n = j * 32 + l31;
-            const bool nok = n < a.Cout;
+            const bool nok = FULL || n < a.Cout;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int w = 2 * g + half;
@@ -118,27 +124,27 @@ __global__ __launch_bounds__(256) void conv0_kernel(const Conv0Args a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float z = acc[j][4 * g + q];
-                    const bool in = (Y + (q >> 1)) < a.H && (X + (q & 1)) < a.W;
-                    if (in) { s1[j] += z; s2[j] += z * z; }
+                    const bool in = FULL || ((Y + (q >> 1)) < a.H && (X + (q & 1)) < a.W);
+                    if (has_stats && in) { s1[j] += z; s2[j] += z * z; }
                     const float u = z * sc[j] + sh[j];
                     v[q] = u > 0.f ? u : u * a.slope;
                 }
                 if (!nok) continue;
-                if (a.y != nullptr) {
+                if (has_y) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int yy = Y + (q >> 1), xx = X + (q & 1);
-                        if (yy < a.H && xx < a.W) a.y[((size_t)(b * a.H + yy) * a.W + xx) * a.ldy + n] = v[q];
+                        if (FULL || (yy < a.H && xx < a.W)) a.y[((size_t)(b * a.H + yy) * a.W + xx) * a.ldy + n] = v[q];
                     }
                 }
-                if (a.y_pool != nullptr && Y < a.H && X < a.W) {
+                if (has_pool && (FULL || (Y < a.H && X < a.W))) {
                     const float pm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                     a.y_pool[((size_t)(b * (a.H >> 1) + (Y >> 1)) * (a.W >> 1) + (X >> 1)) * a.ldp + n] = pm;
                 }
             }
         }
     }
-    if (a.stats != nullptr) {
+    if (has_stats) {
 #pragma unroll
         for (int j = 0; j < NBLK; ++j) {
             const int n = j * 32 + l31;
@@ -157,8 +163,22 @@ template <int CIN>
 int launch0(const Conv0Args& a, hipStream_t s) {
     const long long grid = (long long)a.B * a.tiles_y * a.tiles_x;
     if (grid <= 0 || grid > 0x7fffffffLL) return Y2_EINVAL;
-    if (a.Cout <= 32) Y2_LAUNCH("conv0_kernel", 2.0 * (double)a.B * a.H * a.W * 9 * CIN * a.Cout, (conv0_kernel<CIN, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    else Y2_LAUNCH("conv0_kernel", 2.0 * (double)a.B * a.H * a.W * 9 * CIN * a.Cout, (conv0_kernel<CIN, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    const double flops = 2.0 * (double)a.B * a.H * a.W * 9 * CIN * a.Cout;
+    if (CIN == 3 && (a.H % TH) == 0 && (a.W % TW) == 0 && (a.Cout == 32 || a.Cout == 64)) {
+        // the shipped first layers (3 -> 32 Darknet / 3 -> 16 Tiny falls through) on tile-aligned images: straight-line epilogues
+        const int out = (a.y != nullptr ? 1 : 0) | (a.y_pool != nullptr ? 2 : 0) | (a.stats != nullptr ? 4 : 0);
+#define Y2_C0(NB_, OUT_) Y2_LAUNCH("conv0_kernel", flops, (conv0_kernel<3, NB_, OUT_, true>), dim3((unsigned)grid), dim3(256), 0, s, a)
+        bool done = true;
+        if (a.Cout == 32) {
+            if (out == 2) Y2_C0(1, 2); else if (out == 5) Y2_C0(1, 5); else if (out == 1) Y2_C0(1, 1); else if (out == 3) Y2_C0(1, 3); else done = false;
+        } else {
+            if (out == 2) Y2_C0(2, 2); else if (out == 5) Y2_C0(2, 5); else if (out == 1) Y2_C0(2, 1); else done = false;
+        }
+#undef Y2_C0
+        if (done) { Y2_LAUNCH_CHECK(); return Y2_OK; }
+    }
+    if (a.Cout <= 32) Y2_LAUNCH("conv0_kernel", flops, (conv0_kernel<CIN, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else Y2_LAUNCH("conv0_kernel", flops, (conv0_kernel<CIN, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
