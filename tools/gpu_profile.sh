@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.." || exit 1
 R=$PWD; mkdir -p gpurun_out/prof; export TMPDIR=/tmp
 export Y2_TUNE_CACHE=/tmp/y2_tune.json
-CMD="python $R/bench.py --steps ${STEPS:-5} --warmup 2 --cpu-sample 0 --train-steps 0 --no-direct-leg ${BENCH_ARGS}"
+CMD="python $R/bench.py --steps ${STEPS:-8} --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3 ${BENCH_ARGS}"
 $CMD > /dev/null 2>&1   # populate the tile-autotune cache so the profiled runs contain only steady-state launches
 cd /tmp
 rm -rf $R/gpurun_out/prof/*

@@ -26,7 +26,7 @@ for k, c, n, v in rows:
             launches += n
 fetch, write = tot['FETCH_SIZE'] / steps, tot['WRITE_SIZE'] / steps
 print(json.dumps({
-    'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile.sh) on `bench.py --steps 5 --warmup 2 --cpu-sample 0 --train-steps 0` (autotune cache pre-populated); conv_fwd_dma_kernel family + split-K fix-up + Winograd transform kernels',
+    'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile.sh) on `bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3` (autotune cache pre-populated); conv_fwd_dma_kernel family + split-K fix-up + Winograd transform kernels',
     'kernel_launches_profiled': launches, 'steps_profiled': steps,
     'fetch_size_bytes_raw_per_step': fetch, 'write_size_bytes_raw_per_step': write,
     'correction': 'gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE uncorrected; counters are L2 memory-side requests, Infinity-Cache hits included',

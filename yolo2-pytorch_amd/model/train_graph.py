@@ -24,6 +24,18 @@ import torch.distributed as dist
 
 import _hip
 
+BWD_STREAMS = int(os.environ.get('Y2_BWD_STREAMS', '2'))     # 2: weight gradients on a side stream (overlap with the HBM-bound passes); 1: one stream
+_SIDE = {}
+
+
+def _side_stream(dev):
+    s = _SIDE.get(str(dev))
+    if s is None:
+        s = torch.cuda.Stream(device=dev)
+        _SIDE[str(dev)] = s
+    return s
+
+
 SYNC_POSITIVES = True   # data parallel: all-reduce the positive count so the cls mean is over the global batch
 
 # Set by train.DataParallelRCCL: callable(tensor) summing a small tensor over the wrapper's process group, in place (it knows
@@ -301,6 +313,15 @@ class DarknetTrainFn(torch.autograd.Function):
         dcat = None
         sums_arena = torch.zeros(2 * sum(b.cout for b in blocks), dtype=torch.float64, device=dev)     # one fill for all layers
         sums_used = 0
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if (BWD_STREAMS > 1 and not _hip.DETERMINISTIC and not torch.cuda.is_current_stream_capturing()) else None
+        late = []                                         # (parameter, gradient, event) of weight gradients still running on the side stream
+
+        def flush_weight_grads(keep=0):
+            while len(late) > keep:
+                prm, g, evt = late.pop(0)
+                main.wait_event(evt)
+                ready(prm, g)
         for i in order:
             blk = blocks[i]
             L.y2_prof_set_tag(101 + i)                  # backward launches of block i: tag 101 + i
@@ -328,26 +349,47 @@ class DarknetTrainFn(torch.autograd.Function):
                 gb = _new(dev, cout)
                 _hip.check(L.y2_f64_to_f32(_hip.ptr(sums), _hip.ptr(gb), cout, 1.0, st), 'y2_f64_to_f32')
                 ready(blk.mod.conv.bias, gb)
-            # weight gradient
+            # weight gradient: off the critical path (nothing downstream of this layer's backward needs it), so it runs on a SIDE stream
+            # and its MFMA-bound kernel overlaps the HBM-bound passes (y2_bn_act_bwd, Winograd input transforms) of the layers that
+            # follow on the main stream.  The gradient is handed to autograd / the data-parallel hook one layer later, behind an event.
             weight = blk.mod.conv.weight
-            if blk.first and cin <= 3 and cout <= 64:
-                dw0 = torch.zeros(cout, cin, k, k, dtype=torch.float32, device=dev)
-                _hip.check(L.y2_conv0_wgrad(_hip.ptr(ctx.x), _hip.ptr(dz), _hip.ptr(dw0), B, h, w, cin, cout, cop, st), 'y2_conv0_wgrad')
-                ready(weight, dw0)
-            elif blk.first:
-                x4 = torch.zeros(B, h, w, 4, dtype=torch.float32, device=dev)
-                x4[..., :cin] = ctx.x.permute(0, 2, 3, 1)          # layout conversion only (NCHW plugin input -> NHWC, 4th channel zero)
-                dwp = torch.zeros(cop * k * k * 4, dtype=torch.float32, device=dev)
-                _hip.check(L.y2_conv_wgrad(_hip.ptr(x4), _hip.ptr(dz), _hip.ptr(dwp), B, h, w, 4, 4, cop, cop, k, st), 'y2_conv_wgrad')
-                dw4 = _new(dev, cop, 4, k, k)
-                _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw4), cop, 4, k, st), 'y2_unpack_weight_grad')
-                ready(weight, dw4[:cout, :cin].contiguous())
-            else:
+
+            def weight_grad(st_w):
+                if blk.first and cin <= 3 and cout <= 64:
+                    dw0 = torch.zeros(cout, cin, k, k, dtype=torch.float32, device=dev)
+                    _hip.check(L.y2_conv0_wgrad(_hip.ptr(ctx.x), _hip.ptr(dz), _hip.ptr(dw0), B, h, w, cin, cout, cop, st_w), 'y2_conv0_wgrad')
+                    return dw0
+                if blk.first:
+                    x4 = torch.zeros(B, h, w, 4, dtype=torch.float32, device=dev)
+                    x4[..., :cin] = ctx.x.permute(0, 2, 3, 1)          # layout conversion only (NCHW plugin input -> NHWC, 4th channel zero)
+                    dwp = torch.zeros(cop * k * k * 4, dtype=torch.float32, device=dev)
+                    _hip.check(L.y2_conv_wgrad(_hip.ptr(x4), _hip.ptr(dz), _hip.ptr(dwp), B, h, w, 4, 4, cop, cop, k, st_w), 'y2_conv_wgrad')
+                    dw4 = _new(dev, cop, 4, k, k)
+                    _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw4), cop, 4, k, st_w), 'y2_unpack_weight_grad')
+                    return dw4[:cout, :cin].contiguous()
                 dwp = _hip.conv_wgrad(blk.x, dz, B, h, w, cin, blk.ldx, cop, cop, k, v=blk.wino_v)     # direct or Winograd, by measurement
-                blk.wino_v = None
                 dw = _new(dev, cop, cin, k, k)
-                _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cop, cin, k, st), 'y2_unpack_weight_grad')
-                ready(weight, dw if cop == cout else dw[:cout].contiguous())
+                _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cop, cin, k, st_w), 'y2_unpack_weight_grad')
+                return dw if cop == cout else dw[:cout].contiguous()
+
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)                           # dz (and everything before it) is complete on the main stream
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    gw = weight_grad(_hip.stream())
+                    for tns in (dz, blk.x, blk.wino_v, ctx.x):       # read on the side stream: the allocator must not recycle them under it
+                        if tns is not None:
+                            tns.record_stream(side)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                gw.record_stream(main)
+                flush_weight_grads(keep=1)
+                late.append((weight, gw, done))
+            else:
+                ready(weight, weight_grad(st))
+            blk.wino_v = None
+            if not blk.first:
                 # data gradient -> the producer's gradient source
                 dx = _new(dev, B, h, w, cin)
                 ready_ops = ctx.prepared.get(blk.mod)
@@ -379,6 +421,7 @@ class DarknetTrainFn(torch.autograd.Function):
                     else:
                         src_full[prod] = (dx, cin, 0, 0)
             blk.z = None   # free as we go
+        flush_weight_grads()
         L.y2_prof_set_tag(0)
         out = [None, None]
         for pid in ctx.param_ids:
