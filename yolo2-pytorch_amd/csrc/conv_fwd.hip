@@ -73,6 +73,7 @@ struct ConvArgs {
     // y + g*gy (floats).  Tiles are numbered group-major.  Used by the Winograd path (16 transform positions).
     int groups;
     long long gx, gw, gy;
+    int fast_epi, epi_bm, epi_bn;       // straight-line epilogue allowed (host) + the launch's tile size for the per-tile inside test
 };
 
 // pixel index (b*H + y)*W + x and (y, x) of GEMM row m
@@ -95,9 +96,55 @@ __device__ __forceinline__ void decode_row(const ConvArgs& a, int m, int& pix, i
 }
 
 // ------------------------------------------------------------------------------------------------ epilogue
+// Straight-line epilogue for the common cases (decided once per tile, uniformly): no residual, no statistics, plain output
+// addressing, the tile completely inside the problem.  The general epilogue below tests per element what these cases know per
+// launch (measured on the second-generation fused Winograd kernel: control flow and dead arithmetic in an epilogue cost more
+// than its stores); on the short-K layers (1x1 convolutions, K = 128 ... 1024) the epilogue is a visible share of a tile.
+//   non-POOLORD: y[(m) * ldy + coff + n] = act(z * scale + shift)          (also the raw product tensor of the grouped Winograd GEMM)
+//   POOLORD:     y_pool[(m >> 2) * ldp + poff + n] = max over the lane's 2x2 window (pooled output only)
+template <int MB, int NB, int WM, int WN, bool POOLORD>
+__device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&acc)[MB][NB], int m0, int n0, int wm, int wn, int l31, int half) {
+    const bool affine = a.scale != nullptr || a.shift != nullptr || a.slope != 1.f;       // uniform
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        float sc = 1.f, sh = 0.f;
+        if (affine) {
+            if (a.scale != nullptr) sc = a.scale[n];
+            if (a.shift != nullptr) sh = a.shift[n];
+        }
+        const int mrow = m0 + wm * WM + 4 * half;
+        if (!POOLORD) {
+            float* col = a.y + (size_t)mrow * a.ldy + a.coff + n;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
+                    if (affine) { const float u = v * sc + sh; v = u > 0.f ? u : u * a.slope; }
+                    col[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * a.ldy] = v;
+                }
+        } else {
+            float* col = a.y_pool + (size_t)(mrow >> 2) * a.ldp + a.poff + n;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = acc[i][j][4 * g + e] * sc + sh;
+                        v[e] = u > 0.f ? u : u * a.slope;
+                    }
+                    col[(size_t)(i * 8 + 2 * g) * a.ldp] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                }
+        }
+    }
+}
+
 // C layout of v_mfma_f32_32x32x2_f32: lane -> column n = lane&31; register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5)
 template <int MB, int NB, int WM, int WN, bool POOLORD>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MB][NB], int m0, int n0, int wm, int wn, int l31, int half) {
+__device__ __forceinline__ void conv_epilogue_general(const ConvArgs& a, f32x16 (&acc)[MB][NB], int m0, int n0, int wm, int wn, int l31, int half) {
     const bool do_full = a.y != nullptr;
     const bool do_pool = a.y_pool != nullptr;
 #pragma unroll
@@ -170,6 +217,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
             }
         }
     }
+}
+
+template <int MB, int NB, int WM, int WN, bool POOLORD>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MB][NB], int m0, int n0, int wm, int wn, int l31, int half) {
+    // a.fast_epi (host): no residual / statistics, out_mode 0, exactly one output of the kind the layout serves.  Per tile: fully inside.
+    if (a.fast_epi && m0 + a.epi_bm <= a.M && n0 + a.epi_bn <= a.Cout) conv_epilogue_fast<MB, NB, WM, WN, POOLORD>(a, acc, m0, n0, wm, wn, l31, half);
+    else conv_epilogue_general<MB, NB, WM, WN, POOLORD>(a, acc, m0, n0, wm, wn, l31, half);
 }
 
 template <int BM, int BN, int WAVES_M, int BK, bool POOLORD, bool VEC, int ABLATE = 0>
@@ -721,6 +775,7 @@ template <int BM, int BN, int WAVES_M, int BK, bool POOLORD, bool VEC, int ABLAT
 int launch(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_m = y2_cdiv(a.M, BM);
+    a.epi_bm = BM; a.epi_bn = BN;
     a.tiles_n = y2_cdiv(a.Cout, BN);
     size_t lds = 2u * (BM + BN) * (BK + 4) * sizeof(float);
     if (const char* pad = getenv("Y2_CONV_LDS_MIN")) { const size_t m = (size_t)atol(pad); if (lds < m) lds = m; }   // occupancy experiments only
@@ -758,6 +813,7 @@ template <int BM, int BN, int WAVES_M, bool POOLORD, bool GEN = false, int NTH =
 int launch_dma(const ConvArgs& a0, hipStream_t stream, float* ws, size_t ws_bytes, size_t* ws_need) {
     ConvArgs a = a0;
     a.tiles_m = y2_cdiv(a.M, BM);
+    a.epi_bm = BM; a.epi_bn = BN;
     a.tiles_n = y2_cdiv(a.Cout, BN);
     a.cchunks = y2_cdiv(a.Cin, 32);
     size_t lds = 2u * (BM + BN) * 32 * sizeof(float);
@@ -1137,6 +1193,8 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
     a.tiles_m = a.tiles_n = 0;
     a.x_bytes = a.w_bytes = 0;
     a.full_tiles = 0x7fffffff; a.ksplit = 1; a.partial = nullptr;
+    a.fast_epi = (p->residual == nullptr && p->stats == nullptr && p->out_mode == 0 && ((pool && p->y == nullptr) || (!pool && p->y != nullptr))) ? 1 : 0;
+    a.epi_bm = 64; a.epi_bn = 64;      // overwritten by the launcher with its tile size
     a.groups = groups; a.gx = gx; a.gw = gw; a.gy = gy;
     a.d_hw = y2_make_fastdiv((uint32_t)(p->H * p->W)); a.d_w = y2_make_fastdiv((uint32_t)p->W); a.d_w2 = y2_make_fastdiv((uint32_t)(2 * p->W));
     a.stride = stride; a.pad = pad; a.KW = p->ksize; a.Ho = Ho; a.Wo = Wo; a.K = a.taps * p->Cin;
