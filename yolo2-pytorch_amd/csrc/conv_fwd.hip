@@ -96,7 +96,7 @@ __device__ __forceinline__ void decode_row(const ConvArgs& a, int m, int& pix, i
 }
 
 // ------------------------------------------------------------------------------------------------ epilogue
-// Straight-line epilogue for the common cases (decided once per tile, uniformly): no residual, no statistics, plain output
+// Straight-line epilogue for the common cases (decided once per tile, uniformly): no residual, plain output
 // addressing, the tile completely inside the problem.  The general epilogue below tests per element what these cases know per
 // launch (measured on the second-generation fused Winograd kernel: control flow and dead arithmetic in an epilogue cost more
 // than its stores); on the short-K layers (1x1 convolutions, K = 128 ... 1024) the epilogue is a visible share of a tile.
@@ -105,6 +105,7 @@ __device__ __forceinline__ void decode_row(const ConvArgs& a, int m, int& pix, i
 template <int MB, int NB, int WM, int WN, bool POOLORD>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&acc)[MB][NB], int m0, int n0, int wm, int wn, int l31, int half) {
     const bool affine = a.scale != nullptr || a.shift != nullptr || a.slope != 1.f;       // uniform
+    const bool stats = !POOLORD && a.stats != nullptr;                                        // uniform
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int n = n0 + wn * WN + j * 32 + l31;
@@ -116,14 +117,25 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&a
         const int mrow = m0 + wm * WM + 4 * half;
         if (!POOLORD) {
             float* col = a.y + (size_t)mrow * a.ldy + a.coff + n;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[i][j][r];
+                    if (stats) { s1 += v; s2 += v * v; }          // training-mode BatchNorm statistics of the RAW output
                     if (affine) { const float u = v * sc + sh; v = u > 0.f ? u : u * a.slope; }
                     col[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * a.ldy] = v;
                 }
+            if (stats) {
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (half == 0) {
+                    double* st = a.stats + (size_t)((m0 >> 6) % Y2_STATS_REPL) * 2 * a.Cout;
+                    atomicAdd(st + n, (double)s1);
+                    atomicAdd(st + a.Cout + n, (double)s2);
+                }
+            }
         } else {
             float* col = a.y_pool + (size_t)(mrow >> 2) * a.ldp + a.poff + n;
 #pragma unroll
@@ -1193,7 +1205,7 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
     a.tiles_m = a.tiles_n = 0;
     a.x_bytes = a.w_bytes = 0;
     a.full_tiles = 0x7fffffff; a.ksplit = 1; a.partial = nullptr;
-    a.fast_epi = (p->residual == nullptr && p->stats == nullptr && p->out_mode == 0 && ((pool && p->y == nullptr) || (!pool && p->y != nullptr))) ? 1 : 0;
+    a.fast_epi = (p->residual == nullptr && p->out_mode == 0 && ((pool && p->y == nullptr && p->stats == nullptr) || (!pool && p->y != nullptr))) ? 1 : 0;
     a.epi_bm = 64; a.epi_bn = 64;      // overwritten by the launcher with its tile size
     a.groups = groups; a.gx = gx; a.gw = gw; a.gy = gy;
     a.d_hw = y2_make_fastdiv((uint32_t)(p->H * p->W)); a.d_w = y2_make_fastdiv((uint32_t)p->W); a.d_w2 = y2_make_fastdiv((uint32_t)(2 * p->W));
