@@ -99,6 +99,9 @@ class Ctx(object):
         self.local = int(os.environ.get('LOCAL_RANK', '0'))
         self.gpu = torch.cuda.is_available() and not args.dry_run
         if self.gpu:
+            if os.environ.get('Y2_BENCH_DEVICE'):      # test rig only: several ranks on ONE GPU (with Y2_DIST_BACKEND=gloo) to exercise the N > 1 code path
+                self.local = int(os.environ['Y2_BENCH_DEVICE'])
+                os.environ['LOCAL_RANK'] = str(self.local)
             torch.cuda.set_device(self.local)
             self.dev = torch.device('cuda', self.local)
         else:

@@ -226,3 +226,28 @@ def test_wrapped_model_survives_cpu_cuda_round_trip():
             assert (a.grad - b.grad).abs().max().item() <= 1e-5 * b.grad.abs().max().item() + 1e-9, k
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_share_the_one_gpu():
+    """bench.py's N > 1 code path end to end on the real kernels: `--gpus 2` launches the ranks itself; the test rig puts both on
+    cuda:0 (Y2_BENCH_DEVICE) with a gloo group standing in for RCCL (Y2_DIST_BACKEND).  The numbers mean nothing (two ranks share one
+    GPU, gradients staged through the host); the protocol is what is checked: rendezvous, ranks_seen, detect replicas, the
+    no-wrapper training leg beside the data-parallel one, ONE JSON line with the train headline."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(Y2_DIST_BACKEND='gloo', Y2_BENCH_DEVICE='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--train-steps', '3', '--cpu-sample', '0'],
+                         capture_output=True, text=True, timeout=850, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['ranks_seen'] == 2 and rec['headline'] == 'train' and rec['scaling'] == 'weak'
+    assert rec['value'] == rec['train']['images_per_sec'] > 0 and rec['train']['global_batch'] == 128
+    assert rec['train']['single_gpu_images_per_sec'] > 0 and 'dp2' in rec['train']['parallelism']
+    assert rec['detect']['images_per_sec'] > 0 and 'replicas x2' in rec['detect']['parallelism']
+    assert 'roofline' not in rec and 'cpu_baseline' not in rec          # N = 1 only
