@@ -202,6 +202,34 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         for (int j = (TOTAL + EVERY - 1) / EVERY; j < NPIECES; ++j) issue_piece(nbuf, j);
     };
 
+    // MFMA blocks of this wave that lie completely outside the output (the last column tile of a 288-column problem holds 32
+    // valid columns of 128): wave-uniform, so they are skipped instead of multiplied by zeros
+    bool blk_ok[IB][JB];
+    bool all_ok = true;
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            blk_ok[i][j] = (i0 + wm * WI + i * 32) < a.Cout && (j0 + wn * WJ + j * 32) < ncols;
+            all_ok = all_ok && blk_ok[i][j];
+        }
+    auto compute_slab_checked = [&](int buf) {
+        const float* sbuf = smem + buf * STAGE;
+#pragma unroll
+        for (int s = 0; s < KS / 2; ++s) {
+            float av[IB], bv[JB];
+#pragma unroll
+            for (int i = 0; i < IB; ++i) av[i] = sbuf[fa + s * 2 * TI + 32 * i];
+#pragma unroll
+            for (int j = 0; j < JB; ++j) bv[j] = sbuf[fb + s * 256 + 32 * j];
+#pragma unroll
+            for (int i = 0; i < IB; ++i)
+#pragma unroll
+                for (int j = 0; j < JB; ++j)
+                    if (blk_ok[i][j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
     auto compute_slab = [&](int buf) {
         const float* sbuf = smem + buf * STAGE;
 #pragma unroll
@@ -221,10 +249,13 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 
     issue_slab(slab_lo, 0);
     for (int ks = 0; ks < nk - 1; ++ks) {
-        if (Y2_WGRAD_SPREAD) plan_slab(slab_lo + ks + 1);      // VALU only: overlaps the tail of the previous slab's MFMAs
+        if (Y2_WGRAD_SPREAD && all_ok) plan_slab(slab_lo + ks + 1);      // VALU only: overlaps the tail of the previous slab's MFMAs
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (Y2_WGRAD_SPREAD) {
+        if (!all_ok) {                       // ragged tile: plain fetch, MFMAs of the outside blocks skipped
+            issue_slab(slab_lo + ks + 1, (ks + 1) & 1);
+            compute_slab_checked(ks & 1);
+        } else if (Y2_WGRAD_SPREAD) {
             compute_slab_spread(ks & 1, (ks + 1) & 1);
         } else {
             issue_slab(slab_lo + ks + 1, (ks + 1) & 1);
@@ -233,7 +264,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    compute_slab((nk - 1) & 1);
+    if (all_ok) compute_slab((nk - 1) & 1); else compute_slab_checked((nk - 1) & 1);
 
     // ---- epilogue: lane -> column j (l31), register r -> row co = (r&3) + 8*(r>>2) + 4*half
 #pragma unroll
