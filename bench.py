@@ -411,9 +411,18 @@ def train_leg(args, ctx):
     if per_img is not None:
         out['direct_equiv_tflops_per_gpu'] = round(per_img * B * steps / dt / 1e12, 2)
     if ctx.world == 1:
-        table = kernel_table(step, 2)
-        out['roofline'] = roofline_from(table, 'training step, batch %d: fprop / dgrad / wgrad kernels with their executed FLOPs' % B)
-        out['roofline']['step_ms_under_hooks'] = round(sum(e['ms'] for e in table.values()), 3)
+        # per-kernel durations are taken with the weight gradients on the MAIN stream: in the timed two-stream schedule they co-run with
+        # the BatchNorm / transform passes of the next layers and the kernels inflate each other's durations (sum 60 ms in a 40 ms step)
+        from model import train_graph
+        streams, train_graph.BWD_STREAMS = train_graph.BWD_STREAMS, 1
+        try:
+            step(0)
+            table = kernel_table(step, 2)
+        finally:
+            train_graph.BWD_STREAMS = streams
+        out['roofline'] = roofline_from(table, 'training step, batch %d: fprop / dgrad / wgrad kernels with their executed FLOPs; per-kernel durations measured single-stream '
+                                               '(the timed step runs the weight gradients on a side stream, Y2_BWD_STREAMS=%d)' % (B, streams))
+        out['roofline']['kernel_ms_sum_single_stream'] = round(sum(e['ms'] for e in table.values()), 3)
     del step, last, keep
     torch.cuda.empty_cache()
     return out
