@@ -549,8 +549,9 @@ def main():
             traceback.print_exc()
             tr = {'error': '%s: %s' % (type(e).__name__, e)}
     if ctx.rank == 0:
-        det_workload = '%s YOLOv2 %dx%d batch-%d/GPU inference: conv stack + decode + filter + NMS (BASELINE configs[1])' % (label, args.size, args.size, args.batch)
-        tr_workload = '%s YOLOv2 %d-class train %dx%d batch-%d/GPU: fwd + region loss + bwd + SGD (BASELINE configs[2])' % (label, args.classes, args.size, args.size, args.train_batch)
+        ref = {'darknet': (' (BASELINE configs[1])', ' (BASELINE configs[2])')}.get(args.model, (' (plugin swap: forward of BASELINE configs[4])', ' (plugin swap, BASELINE configs[4] per GPU)') if args.model.startswith('resnet') else ('', ''))
+        det_workload = '%s YOLOv2 %dx%d batch-%d/GPU inference: conv stack + decode + filter + NMS%s' % (label, args.size, args.size, args.batch, ref[0])
+        tr_workload = '%s YOLOv2 %d-class train %dx%d batch-%d/GPU: fwd + region loss + bwd + SGD%s' % (label, args.classes, args.size, args.size, args.train_batch, ref[1])
         if headline == 'train':
             value, ms, steps, workload = tr['images_per_sec'], tr['ms_per_step'], tr['steps'], tr_workload
             metric = 'images/sec (%dx%d) train, %s YOLOv2, data parallel' % (args.size, args.size, label)
