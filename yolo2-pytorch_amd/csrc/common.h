@@ -22,6 +22,7 @@ __attribute__((visibility("hidden"))) int y2_internal_conv_grouped(const y2_conv
                                                                     y2_stream_t stream, size_t* ws_need);
 __attribute__((visibility("hidden"))) int y2_internal_wgrad_grouped(const float* x, const float* dz, float* dw, long long M, int Cin, int Cout, int groups,
                                                                      long long gx, long long gz, long long gw, y2_stream_t stream);
+__attribute__((visibility("hidden"))) int y2_internal_wgrad_needs_zero(long long M, int Cin, int Cout, int groups);
 __attribute__((visibility("hidden"))) int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need);
 
 // ---- per-device host-side caches (a process may touch several GPUs; symbol addresses and function attributes are per device)

@@ -294,6 +294,25 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 
 // dW[Cout][k*k][Cin] (packed layout, y2_unpack_weight_grad converts to the state_dict layout) += / = wgrad.
 // dw must be zero-filled by the caller when the kernel decides to split (it always may): zero it unconditionally.
+// K (pixel) splits of one weight-gradient launch: enough workgroups to fill the chip several times over, but >= 8 slabs each so that
+// the atomic epilogue stays small.  1 = every output element is written by exactly one workgroup (plain stores, dw need not be zero).
+static int wgrad_splits(long long M, int ncols, int Cout, int groups, int* slabs_per_split) {
+    const int TI = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
+    const long long tiles = (long long)y2_cdiv(Cout, TI) * y2_cdiv(ncols, TJ);
+    const int slabs = y2_cdiv(M, KS);
+    int splits = y2_cdiv(4 * Y2_NUM_CU, tiles * groups);
+    const int max_splits = slabs / 8 > 0 ? slabs / 8 : 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const int sps = y2_cdiv(slabs, splits);
+    if (slabs_per_split != nullptr) *slabs_per_split = sps;
+    return y2_cdiv(slabs, sps);
+}
+
+int y2_internal_wgrad_needs_zero(long long M, int Cin, int Cout, int groups) {
+    return (wgrad_splits(M, Cin, Cout, groups, nullptr) > 1 && !y2_det.on) ? 1 : 0;      // 1x1 shape of the grouped Winograd reductions
+}
+
 static int wgrad_impl(const float* x, const float* dz, float* dw, int B, int Hi, int Wi, int Cin, int ldx, int Cout, int ldz,
                       int ksize, int stride, int pad, y2_stream_t stream, int groups, long long gx, long long gz, long long gw) {
     if (!x || !dz || !dw || B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0) return Y2_EINVAL;
@@ -316,13 +335,7 @@ static int wgrad_impl(const float* x, const float* dz, float* dw, int B, int Hi,
     a.tiles_j = y2_cdiv(a.taps * Cin, TJ);
     const int tiles = a.tiles_i * a.tiles_j;
     const int slabs = y2_cdiv(M, KS);
-    // enough workgroups to fill the chip several times over, but >= 8 slabs each so the atomic epilogue stays small
-    int splits = y2_cdiv(4 * Y2_NUM_CU, (long long)tiles * groups);
-    const int max_splits = slabs / 8 > 0 ? slabs / 8 : 1;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    a.slabs_per_split = y2_cdiv(slabs, splits);
-    a.splits = y2_cdiv(slabs, a.slabs_per_split);
+    a.splits = wgrad_splits(M, a.taps * Cin, Cout, groups, &a.slabs_per_split);
     a.x_bytes = (unsigned)xb; a.dz_bytes = (unsigned)zb;
     a.partial = nullptr;
     const long long wsize = (long long)Cout * a.taps * Cin;            // floats per group

@@ -939,8 +939,10 @@ extern "C" int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, 
     float* DU = DM + align256((size_t)16 * T * Cout * 4) / 4;
     hipStream_t s = y2_s(stream);
     const size_t du_bytes = (size_t)16 * Cout * Cin * 4;
-    hipError_t e = hipMemsetAsync(DU, 0, du_bytes, s);       // the grouped reduction adds split partial sums atomically
-    if (e != hipSuccess) return -(1000 + (int)e);
+    if (y2_internal_wgrad_needs_zero(T, Cin, Cout, 16)) {      // split partial sums are added atomically; an unsplit launch (the deep layers) stores
+        hipError_t e = hipMemsetAsync(DU, 0, du_bytes, s);
+        if (e != hipSuccess) return -(1000 + (int)e);
+    }
 
     WinoInArgs ia;
     ia.tile_pix = nullptr;
