@@ -85,14 +85,20 @@ def _dp_inputs():
 
 def _dp_rank(rank, world, port, tmp, sync):
     """One data-parallel rank: Darknet (narrow) + model.loss on its shard through train.ensure_model -> DataParallelRCCL.
-    Both ranks share cuda:0 (the test box has one GPU), so the process group is gloo with host-staged buffers; everything
-    else - the grad_ready_hook bucket protocol, the positive-count all-reduce, the HIP kernels - is the product path."""
+    On a box with one GPU both ranks share cuda:0 and the process group is gloo with host-staged buffers; with >= 2 GPUs visible each
+    rank takes its own GPU and the group is RCCL.  Everything else - the grad_ready_hook bucket protocol, the positive-count
+    all-reduce, the HIP kernels - is the product path either way."""
     import sys
     from conftest import APP, ROOT
     for p in (ROOT, APP):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', Y2_DIST_BACKEND='gloo')
+    rccl = torch.cuda.device_count() >= world and os.environ.get('Y2_TEST_DP_BACKEND', 'auto') != 'gloo'
+    if rccl:       # a multi-GPU node: the real thing, one GPU per rank over RCCL
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        os.environ.pop('Y2_DIST_BACKEND', None)
+    else:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', Y2_DIST_BACKEND='gloo')
     import model
     import train
     from model import train_graph
