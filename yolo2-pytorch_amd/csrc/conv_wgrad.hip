@@ -24,7 +24,7 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int TJ = 128, KS = 32;   // tile cols (tap,ci), pixels per slab; tile rows TI (co) is a template parameter
+constexpr int KS = 32;             // pixels per slab; tile rows TI (co) and tile columns TJ ((tap, ci): 128 or 64) are template parameters
 
 struct WgradArgs {
     const float* x;     // [B,H,W,Cin] pixel stride ldx
@@ -40,7 +40,7 @@ struct WgradArgs {
     long long gx, gz, gw;
 };
 
-template <int TI, int WAVES_I>
+template <int TI, int WAVES_I, int TJ = 128>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr unsigned OOB = 0x80000000u;
     constexpr int WAVES_J = 4 / WAVES_I;
@@ -49,6 +49,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int CA = TI / 4;                          // 16-B chunks per A row
     constexpr int RA = NT / CA;                         // A rows per DMA pass
     constexpr int PA = KS / RA;                         // A passes per slab
+    constexpr int CB = TJ / 4, RB = NT / CB, PB = KS / RB;   // the same for B: 32 chunks x 8 rows x 4 passes (TJ = 128), 16 x 16 x 2 (TJ = 64)
+    static_assert(WJ >= 32 && WI >= 32, "a wave owns at least one 32x32 block");
     constexpr int STAGE = KS * TI + KS * TJ;            // floats per stage: A [32][TI] then B [32][128]
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -81,9 +83,9 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     const int nk = slab_hi - slab_lo;
     if (nk <= 0) return;
 
-    // ---- DMA assignment.  B: lane -> 16-B chunk (t&31) of pixel row (t>>5) + 8*p, p = 0..3.  A: chunk t % CA of row t / CA + RA*p
-    const int chunk = t & 31;
-    const int prow = t >> 5;
+    // ---- DMA assignment.  B: lane -> 16-B chunk t % CB of pixel row t / CB + RB*p, p < PB.  A: chunk t % CA of row t / CA + RA*p
+    const int chunk = t % CB;
+    const int prow = t / CB;
     const int chunk_a = t % CA;
     const int prow_a = t / CA;
     // A (dz): column i0 + 4*chunk_a
@@ -97,11 +99,11 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     const int dy = tap / a.KW - a.pad;         // input row = yo*stride + dy
     const int dx = tap % a.KW - a.pad;
     // (image, y, x) of this thread's 4 staged OUTPUT pixels in the first slab; advanced by 32 pixels per slab
-    int pb[4], py[4], px[4];
+    int pb[PB], py[PB], px[PB];
     const int q32 = KS / a.W, r32 = KS % a.W;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int m = slab_lo * KS + prow + 8 * p;
+    for (int p = 0; p < PB; ++p) {
+        const int m = slab_lo * KS + prow + RB * p;
         pb[p] = m / (a.H * a.W);
         const int idx = m - pb[p] * (a.H * a.W);
         py[p] = idx / a.W;
@@ -120,17 +122,17 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (lds_ptr_t)(sa + p * RA * TI), 16, (int)va, 0, 0, 0);
         }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int m = slab * KS + prow + 8 * p;
+        for (int p = 0; p < PB; ++p) {
+            const int m = slab * KS + prow + RB * p;
             const bool mok = m < a.M;
             const int yi = py[p] * a.stride + dy, xi = px[p] * a.stride + dx;
             const bool in = (unsigned)yi < (unsigned)a.Hi && (unsigned)xi < (unsigned)a.Wi;
             const unsigned vb = (mok && b_ok && in) ? (unsigned)(((size_t)((pb[p] * a.Hi + yi) * a.Wi + xi) * a.ldx + ci) * 4) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sb + p * 8 * 128), 16, (int)vb, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sb + p * RB * TJ), 16, (int)vb, 0, 0, 0);
         }
         // advance the pixel coordinates to the next slab (+32 pixels, row-major, wraps at image boundaries)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < PB; ++p) {
             px[p] += r32; py[p] += q32;
             if (px[p] >= a.W) { px[p] -= a.W; py[p] += 1; }
             while (py[p] >= a.H) { py[p] -= a.H; pb[p] += 1; }
@@ -146,12 +148,12 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fa = wm * WI + l31 + half * TI;              // + (2s)*TI + 32*block
-    const int fb = KS * TI + wn * WJ + l31 + half * 128;   // + (2s)*128 + 32*block
+    const int fb = KS * TI + wn * WJ + l31 + half * TJ;    // + (2s)*TJ + 32*block
 
     // The same slab fetch, split: voffsets of the NEXT slab first (VALU), then one DMA instruction at a time between the MFMAs of
     // the current slab (an LDS-DMA issue costs ~60 cycles, an fp32 32x32x2 MFMA keeps the pipe busy for 64): pieces go out in the
     // first half of the slab so that they have landed by the next vmcnt(0).
-    unsigned nva[PA], nvb[4];
+    unsigned nva[PA], nvb[PB];
     auto plan_slab = [&](int slab) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
@@ -159,8 +161,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
             nva[p] = (m < a.M && a_ok) ? (unsigned)(((size_t)m * a.ldz + ca) * 4) : OOB;
         }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int m = slab * KS + prow + 8 * p;
+        for (int p = 0; p < PB; ++p) {
+            const int m = slab * KS + prow + RB * p;
             const bool mok = m < a.M;
             const int yi = py[p] * a.stride + dy, xi = px[p] * a.stride + dx;
             const bool in = (unsigned)yi < (unsigned)a.Hi && (unsigned)xi < (unsigned)a.Wi;
@@ -172,11 +174,11 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     };
     auto issue_piece = [&](int buf, int j) {
         if (j < PA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (lds_ptr_t)(smem + buf * STAGE + wave * 256 + j * RA * TI), 16, (int)nva[j], 0, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + buf * STAGE + KS * TI + wave * 256 + (j - PA) * 8 * 128), 16, (int)nvb[j - PA], 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + buf * STAGE + KS * TI + wave * 256 + (j - PA) * RB * TJ), 16, (int)nvb[j - PA], 0, 0, 0);
     };
     auto compute_slab_spread = [&](int buf, int nbuf) {
         const float* sbuf = smem + buf * STAGE;
-        constexpr int TOTAL = (KS / 2) * IB * JB, NPIECES = PA + 4;
+        constexpr int TOTAL = (KS / 2) * IB * JB, NPIECES = PA + PB;
         constexpr int EVERY = (TOTAL / 2) / NPIECES > 0 ? (TOTAL / 2) / NPIECES : 1;
         int cnt = 0;
 #pragma unroll
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int i = 0; i < IB; ++i) av[i] = sbuf[fa + s * 2 * TI + 32 * i];
 #pragma unroll
-            for (int j = 0; j < JB; ++j) bv[j] = sbuf[fb + s * 256 + 32 * j];
+            for (int j = 0; j < JB; ++j) bv[j] = sbuf[fb + s * 2 * TJ + 32 * j];
 #pragma unroll
             for (int i = 0; i < IB; ++i)
 #pragma unroll
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int i = 0; i < IB; ++i) av[i] = sbuf[fa + s * 2 * TI + 32 * i];
 #pragma unroll
-            for (int j = 0; j < JB; ++j) bv[j] = sbuf[fb + s * 256 + 32 * j];
+            for (int j = 0; j < JB; ++j) bv[j] = sbuf[fb + s * 2 * TJ + 32 * j];
 #pragma unroll
             for (int i = 0; i < IB; ++i)
 #pragma unroll
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int i = 0; i < IB; ++i) av[i] = sbuf[fa + s * 2 * TI + 32 * i];
 #pragma unroll
-            for (int j = 0; j < JB; ++j) bv[j] = sbuf[fb + s * 256 + 32 * j];
+            for (int j = 0; j < JB; ++j) bv[j] = sbuf[fb + s * 2 * TJ + 32 * j];
 #pragma unroll
             for (int i = 0; i < IB; ++i)
 #pragma unroll
@@ -296,8 +298,17 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 // dw must be zero-filled by the caller when the kernel decides to split (it always may): zero it unconditionally.
 // K (pixel) splits of one weight-gradient launch: enough workgroups to fill the chip several times over, but >= 8 slabs each so that
 // the atomic epilogue stays small.  1 = every output element is written by exactly one workgroup (plain stores, dw need not be zero).
+// Column-tile width: 64 instead of 128 when that cuts the padded columns by >= 13 % (288 columns: 320 instead of 384; the 64-column
+// GEMMs of the Winograd gradient of a Cin = 64 layer: 64 instead of 128); needs TI >= 64 (a wave owns at least one 32x32 block).
+static int wgrad_tj(int ncols, int Cout) {
+    if (Cout <= 32) return 128;
+    const long long p128 = (long long)y2_cdiv(ncols, 128) * 128, p64 = (long long)y2_cdiv(ncols, 64) * 64;
+    return (p128 * 100 >= p64 * 115) ? 64 : 128;
+}
+
 static int wgrad_splits(long long M, int ncols, int Cout, int groups, int* slabs_per_split) {
     const int TI = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
+    const int TJ = wgrad_tj(ncols, Cout);
     const long long tiles = (long long)y2_cdiv(Cout, TI) * y2_cdiv(ncols, TJ);
     const int slabs = y2_cdiv(M, KS);
     int splits = y2_cdiv(4 * Y2_NUM_CU, tiles * groups);
@@ -332,6 +343,7 @@ static int wgrad_impl(const float* x, const float* dz, float* dw, int B, int Hi,
     a.groups = groups; a.gx = gx; a.gz = gz; a.gw = gw;
     const int TI = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
     a.tiles_i = y2_cdiv(Cout, TI);
+    const int TJ = wgrad_tj(a.taps * Cin, Cout);
     a.tiles_j = y2_cdiv(a.taps * Cin, TJ);
     const int tiles = a.tiles_i * a.tiles_j;
     const int slabs = y2_cdiv(M, KS);
@@ -347,15 +359,17 @@ static int wgrad_impl(const float* x, const float* dz, float* dw, int B, int Hi,
     if (grid > 0x7fffffffLL) return Y2_EINVAL;
     hipStream_t s = y2_s(stream);
     const size_t lds = 2u * (size_t)(KS * TI + KS * TJ) * sizeof(float);
-#define Y2_WGRAD_LAUNCH(TI_, WI_)                                                                                         \
+#define Y2_WGRAD_LAUNCH(TI_, WI_, TJ_)                                                                                    \
     do {                                                                                                                  \
         static Y2LdsAttr attr;                                                                                            \
-        if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<TI_, WI_>))) return rc_;          \
-        Y2_LAUNCH(a.groups > 1 ? "conv_wgrad_kernel[grouped]" : "conv_wgrad_kernel", 2.0 * (double)a.M * a.Cout * a.taps * a.Cin * (a.groups > 1 ? a.groups : 1), (conv_wgrad_kernel<TI_, WI_>), dim3((unsigned)grid), dim3(NT), lds, s, a);                      \
+        if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<TI_, WI_, TJ_>))) return rc_;     \
+        Y2_LAUNCH(a.groups > 1 ? "conv_wgrad_kernel[grouped]" : "conv_wgrad_kernel", 2.0 * (double)a.M * a.Cout * a.taps * a.Cin * (a.groups > 1 ? a.groups : 1), (conv_wgrad_kernel<TI_, WI_, TJ_>), dim3((unsigned)grid), dim3(NT), lds, s, a);                 \
     } while (0)
-    if (TI == 32) Y2_WGRAD_LAUNCH(32, 1);
-    else if (TI == 64) Y2_WGRAD_LAUNCH(64, 1);
-    else Y2_WGRAD_LAUNCH(128, 2);
+    if (TI == 32) Y2_WGRAD_LAUNCH(32, 1, 128);
+    else if (TI == 64 && TJ == 64) Y2_WGRAD_LAUNCH(64, 2, 64);
+    else if (TI == 64) Y2_WGRAD_LAUNCH(64, 1, 128);
+    else if (TJ == 64) Y2_WGRAD_LAUNCH(128, 2, 64);
+    else Y2_WGRAD_LAUNCH(128, 2, 128);
 #undef Y2_WGRAD_LAUNCH
     Y2_LAUNCH_CHECK();
     if (a.partial != nullptr) {       // fixed-order sum of the K-split partials; group g's result goes to dw + g*gw
