@@ -46,16 +46,30 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepTable tb) {
     float* __restrict__ dst = q.dst;
     const int Cout = q.Cout, Cin = q.Cin, taps = q.ksize * q.ksize;
     if (q.mode == Y2_PREP_FPROP || q.mode == Y2_PREP_DGRAD) {
-        const long long total = (long long)Cout * Cin * taps;
-        for (long long i = (long long)blk * 256 + threadIdx.x; i < total; i += (long long)nblk * 256) {
-            if (q.mode == Y2_PREP_FPROP) {      // dst[co][tap][ci] = w[co][ci][tap]                   (= y2_pack_weight mode 0)
-                const int ci = (int)(i % Cin);
-                const long long r = i / Cin;
-                dst[i] = w[((long long)(r / taps) * Cin + ci) * taps + (int)(r % taps)];
-            } else {                              // dst[ci][taps-1-tap][co] = w[co][ci][tap]           (= y2_pack_weight mode 1)
-                const int co = (int)(i % Cout);
-                const long long r = i / Cout;
-                dst[i] = w[((long long)co * Cin + (int)(r / taps)) * taps + (taps - 1 - (int)(r % taps))];
+        // one thread per (co, ci): its k*k taps are contiguous in the state_dict layout (36 B for a 3x3 filter), and it scatters them
+        // to the k*k tap planes of the GEMM layout.  FPROP walks (co, ci) with ci fastest (stores coalesced over ci), DGRAD with co
+        // fastest (stores coalesced over co; its loads are 36-B segments Cin*36 B apart).  The element-per-thread form of
+        // pack_weight_kernel reads 4 B every 36 B: this kernel runs once per training step over all 22 layers.
+        const long long pairs = (long long)Cout * Cin;
+        for (long long i = (long long)blk * 256 + threadIdx.x; i < pairs; i += (long long)nblk * 256) {
+            int co, ci;
+            if (q.mode == Y2_PREP_FPROP) { ci = (int)(i % Cin); co = (int)(i / Cin); }
+            else { co = (int)(i % Cout); ci = (int)(i / Cout); }
+            const float* src = w + ((long long)co * Cin + ci) * taps;
+            if (taps == 9) {
+                float g[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) g[t] = src[t];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (q.mode == Y2_PREP_FPROP) dst[((long long)co * 9 + t) * Cin + ci] = g[t];
+                    else dst[((long long)ci * 9 + (8 - t)) * Cout + co] = g[t];
+                }
+            } else {
+                for (int t = 0; t < taps; ++t) {
+                    if (q.mode == Y2_PREP_FPROP) dst[((long long)co * taps + t) * Cin + ci] = src[t];
+                    else dst[((long long)ci * taps + (taps - 1 - t)) * Cout + co] = src[t];
+                }
             }
         }
         return;
@@ -211,8 +225,8 @@ extern "C" int y2_prep_weights(const y2_prep_item* items, int32_t count, y2_stre
             const y2_prep_item& q = items[lo + i];
             if (q.src == nullptr || q.dst == nullptr || q.Cout <= 0 || q.Cin <= 0 || q.ksize <= 0 || q.mode < Y2_PREP_FPROP || q.mode > Y2_PREP_WINO_DGRAD) return Y2_EINVAL;
             if ((q.mode == Y2_PREP_WINO_FPROP || q.mode == Y2_PREP_WINO_DGRAD) && q.ksize != 3) return Y2_ENOSUP;
-            const long long n = (q.mode <= Y2_PREP_DGRAD) ? (long long)q.Cout * q.Cin * q.ksize * q.ksize : (long long)q.Cout * q.Cin;
-            long long nb = (n + 1023) / 1024;          // ~4 elements per thread
+            const long long n = (long long)q.Cout * q.Cin;          // one thread per (co, ci) pair in every mode
+            long long nb = (n + 511) / 512;            // ~2 pairs per thread
             if (nb < 1) nb = 1;
             if (nb > 2048) nb = 2048;
             tb.item[i] = q;

@@ -316,6 +316,7 @@ class DarknetTrainFn(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if (BWD_STREAMS > 1 and not _hip.DETERMINISTIC and not torch.cuda.is_current_stream_capturing()) else None
         late = []                                         # (parameter, gradient, event) of weight gradients still running on the side stream
+        affine_grads = []                                 # (parameter, offset into sums_arena, length)
 
         def flush_weight_grads(keep=0):
             while len(late) > keep:
@@ -339,16 +340,13 @@ class DarknetTrainFn(torch.autograd.Function):
                                        _hip.ptr(blk.mod.bn.weight.detach()) if blk.has_bn else None, blk.slope,
                                        _hip.ptr(sf[0]) if sf else None, sf[1] if sf else 0, sf[2] if sf else 0, sf[3] if sf else 0,
                                        _hip.ptr(sp), cout, 0, _hip.ptr(sums), _hip.ptr(dz), cop, B, h, w, cout, cout, int(blk.has_bn), st), 'y2_bn_act_bwd')
-            # parameter gradients of the affine part
+            # parameter gradients of the affine part = the fp64 sums of pass 1: converted for ALL layers by one launch after the loop
+            # (they are a few KB per layer; 23 separate 5-microsecond conversions were pure launch latency)
             if blk.has_bn:
-                gb = _new(dev, 2 * cout)
-                _hip.check(L.y2_f64_to_f32(_hip.ptr(sums), _hip.ptr(gb), 2 * cout, 1.0, st), 'y2_f64_to_f32')
-                ready(blk.mod.bn.bias, gb[:cout])
-                ready(blk.mod.bn.weight, gb[cout:])
+                affine_grads.append((blk.mod.bn.bias, sums_used - 2 * cout, cout))
+                affine_grads.append((blk.mod.bn.weight, sums_used - cout, cout))
             elif blk.mod.conv.bias is not None:
-                gb = _new(dev, cout)
-                _hip.check(L.y2_f64_to_f32(_hip.ptr(sums), _hip.ptr(gb), cout, 1.0, st), 'y2_f64_to_f32')
-                ready(blk.mod.conv.bias, gb)
+                affine_grads.append((blk.mod.conv.bias, sums_used - 2 * cout, cout))
             # weight gradient: off the critical path (nothing downstream of this layer's backward needs it), so it runs on a SIDE stream
             # and its MFMA-bound kernel overlaps the HBM-bound passes (y2_bn_act_bwd, Winograd input transforms) of the layers that
             # follow on the main stream.  The gradient is handed to autograd / the data-parallel hook one layer later, behind an event.
@@ -421,6 +419,10 @@ class DarknetTrainFn(torch.autograd.Function):
                     else:
                         src_full[prod] = (dx, cin, 0, 0)
             blk.z = None   # free as we go
+        gb_all = _new(dev, sums_arena.numel())
+        _hip.check(L.y2_f64_to_f32(_hip.ptr(sums_arena), _hip.ptr(gb_all), sums_arena.numel(), 1.0, st), 'y2_f64_to_f32')
+        for prm, off, ln in affine_grads:
+            ready(prm, gb_all[off:off + ln])
         flush_weight_grads()
         L.y2_prof_set_tag(0)
         out = [None, None]
