@@ -78,7 +78,7 @@ def test_full_batch_matches_fp64_oracle_on_sampled_images(net, batch, truth):
         assert rel(got[j:j + 1], truth[j:j + 1]) <= 2e-5, (i, rel(got[j:j + 1], truth[j:j + 1]))
 
 
-@pytest.mark.parametrize('algo', ['direct', 'winograd', 'fused'])
+@pytest.mark.parametrize('algo', ['direct', 'winograd', 'fused', 'implicit'])
 def test_full_batch_under_each_forced_algorithm(net, batch, truth, algo, monkeypatch):
     """Deterministic algorithm coverage of the whole-model path: with autotune out of the picture every eligible 3x3 layer runs the
     direct implicit GEMM / the three-kernel Winograd / the fused Winograd kernel (the rest stays direct), at the full batch-32
@@ -93,7 +93,7 @@ def test_full_batch_under_each_forced_algorithm(net, batch, truth, algo, monkeyp
             f = inf.dnn.forward_nhwc(x.to(dev())).clone()
         plan = inf.dnn._plan_cache[1]
         algos = [plan['arr'][i].algo for i in range(plan['n'])]
-        want = {'direct': 0, 'winograd': 1, 'fused': 2}[algo]
+        want = {'direct': 0, 'winograd': 1, 'fused': 2, 'implicit': 3}[algo]
         assert (max(algos) == want) and (algo == 'direct' or algos.count(want) >= 10), algos     # 13 eligible layers (Cin >= 64)
     finally:
         inf.dnn._plan_cache = None

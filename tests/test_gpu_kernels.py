@@ -137,14 +137,16 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize('algo', [1, 2])
+@pytest.mark.parametrize('algo', [1, 2, 3])
 @pytest.mark.parametrize('B,cin,cout,H,W,tile,pool,both', WINO_CASES)
 def test_conv_fwd_winograd_matches_fp64_reference(B, cin, cout, H, W, tile, pool, both, algo):
     """algo = Y2_ALGO_WINOGRAD: F(2x2,3x3) input/filter/output transforms around the grouped MFMA GEMM.  Odd sizes (ragged
     last tile row/column), concat-style channel windows, negative scales before the fused pool.  The transforms cost a
     few ulps: tolerance 4x the direct kernel's (still ~1e-5 of the output rms against the fp64 truth)."""
-    if algo == 2 and cin % 32:
+    if algo >= 2 and cin % 32:
         pytest.skip('the fused kernel needs Cin % 32 == 0 (the library answers Y2_ENOSUP; autotune then keeps algo 1)')
+    if algo == 3 and cin < 64:
+        pytest.skip('the implicit-transform kernel needs Cin >= 64 (two K slabs)')
     g = torch.Generator().manual_seed(B * 1000 + cin + cout + H)
     x = torch.randn(B, cin, H, W, generator=g)
     w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
@@ -163,6 +165,59 @@ def test_conv_fwd_winograd_matches_fp64_reference(B, cin, cout, H, W, tile, pool
         if not pool:
             assert torch.all(y[..., :8] == -7.0) and torch.all(y[..., 8 + cout:] == -7.0), 'wrote outside its channel window'
         assert rel_err(y[..., c0:c0 + cout].permute(0, 3, 1, 2), ref) <= 4 * CONV_TOL
+
+
+@pytest.mark.parametrize('B,cin,cout,H,W,pad_ch,pool', [
+    (2, 64, 64, 13, 13, 0, False),        # ragged last tile row / column, 98 tiles: two tile rows of 64, the second mostly empty
+    (3, 64, 96, 26, 26, 32, False),       # input is a channel window of a wider tensor (ldx > Cin), Cout not a multiple of 64
+    (1, 128, 64, 52, 52, 0, True),        # 676 tiles: several tiles per workgroup are NOT reached (grid < CUs) - and pooled output
+    (9, 96, 160, 16, 12, 4, True),        # 3 K slabs, 432 tiles x 3 channel tiles
+    (40, 64, 128, 40, 36, 0, False),      # 14400 tiles x 2 channel tiles on 256 persistent workgroups: the cross-tile fetch stream
+    (1, 256, 64, 1, 1, 0, False),         # a single 1x1 image: every patch row / column but one is padding
+    (2, 64, 64, 2, 7, 0, False),
+])
+def test_conv_fwd_implicit_is_bit_identical_to_fused(B, cin, cout, H, W, pad_ch, pool):
+    """Y2_ALGO_WINOGRAD_IMPLICIT runs the same GEMM and the same output transform as Y2_ALGO_WINOGRAD_FUSED; what changes is where
+    B^T d B is computed (registers of the fused kernel's loader instead of wino_input_kernel + memory), with the same operations in
+    the same order.  So the two must agree bit for bit: output, pooled output and the fp64 statistics up to the order of the atomics."""
+    import _hip
+    L, d = _hip.lib(), dev()
+    g = torch.Generator().manual_seed(B * 131 + cin + cout + H * W)
+    ldx = cin + pad_ch
+    xw = torch.randn(B, H, W, ldx, generator=g).to(d)                  # NHWC; the layer reads channels [pad_ch, pad_ch + cin)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).to(d)
+    sc, sh = torch.randn(cout, generator=g).to(d), (torch.randn(cout, generator=g) * 0.1).to(d)
+    wp = torch.empty(w.numel(), device=d)
+    _hip.check(L.y2_pack_weight(_hip.ptr(w), _hip.ptr(wp), cout, cin, 3, 0, _hip.stream()), 'pack')
+    u = _hip.wino_weight(wp, cout, cin)
+    res = {}
+    for algo in (2, 3):
+        p = _hip.ConvParams()
+        p.x, p.w, p.scale, p.shift = xw.data_ptr() + 4 * pad_ch, u.data_ptr(), sc.data_ptr(), sh.data_ptr()
+        y = torch.full((B, H, W, cout + 4), -7.0, device=d)
+        st = torch.zeros(32 * 2 * cout, dtype=torch.float64, device=d)
+        p.y, p.ldy, p.coff, p.stats = y.data_ptr(), cout + 4, 4, st.data_ptr()
+        yp = None
+        if pool:
+            yp = torch.full((B, H // 2, W // 2, cout), -7.0, device=d)
+            p.y_pool, p.ldp, p.poff = yp.data_ptr(), cout, 0
+        p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize, p.slope, p.algo = B, H, W, cin, ldx, cout, 3, 0.1, algo
+        need = _hip.conv_workspace(p, d)
+        assert need >= 0
+        if algo == 3:
+            assert need < 16 * ((H + 1) // 2) * ((W + 1) // 2) * B * cin * 4 or B * H * W < 64      # no transformed input in the workspace
+        _hip.check(L.y2_conv_fwd(ctypes.byref(p), _hip.stream()), 'conv algo %d' % algo)
+        torch.cuda.synchronize()
+        res[algo] = (y.cpu(), yp.cpu() if yp is not None else None, st.cpu().view(32, -1).sum(0))
+    assert torch.equal(res[2][0], res[3][0])
+    assert torch.all(res[3][0][..., :4] == -7.0)
+    if pool:
+        assert torch.equal(res[2][1], res[3][1])
+    np.testing.assert_allclose(res[3][2].numpy(), res[2][2].numpy(), rtol=1e-12, atol=1e-9)
+    # and it is the right answer (fp64 reference)
+    x_nchw = xw[..., pad_ch:].permute(0, 3, 1, 2).cpu()
+    z, ref = ref_conv(x_nchw, w.cpu(), sc.cpu(), sh.cpu(), 0.1, 3)
+    assert rel_err(res[3][0][..., 4:].permute(0, 3, 1, 2), ref) <= 4 * CONV_TOL
 
 
 @pytest.mark.parametrize('algo', [1, 2])

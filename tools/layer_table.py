@@ -51,9 +51,9 @@ def main():
         ms = e0.elapsed_time(e1) / args.reps
         tot += ms
         eq = 2.0 * p.Cin * p.Cout * p.ksize ** 2 * p.B * p.H * p.W
-        ex = 2.0 * p.Cin * p.Cout * 16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2) else eq
+        ex = 2.0 * p.Cin * p.Cout * 16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2, 3) else eq
         print('%-12s %5d %5d %4d %2d %-9s %-8s %9.4f %8.1f %8.1f' % (names[i] if i < len(names) else '?', p.Cin, p.Cout, p.H, p.ksize,
-              {1: 'winograd', 2: 'wino-fused'}.get(p.algo, 'direct'), TILES.get(p.tile, str(p.tile)), ms, eq / ms / 1e9, ex / ms / 1e9), flush=True)
+              {1: 'winograd', 2: 'wino-fused', 3: 'wino-impl'}.get(p.algo, 'direct'), TILES.get(p.tile, str(p.tile)), ms, eq / ms / 1e9, ex / ms / 1e9), flush=True)
     print('sum of the 22 layers: %.4f ms (B=%d)' % (tot, args.batch))
 
 

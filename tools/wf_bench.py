@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""A/B of the fused Winograd kernels (Y2_WF_VARIANT: -1 = first generation, 0..15 = feature mask of wino_fused2_kernel) on the
+"""A/B of the fused Winograd kernels (Y2_WF_VARIANT: -1 = first generation, 0..3 = feature mask of wino_fused2_kernel, 100 =
+Y2_ALGO_WINOGRAD_IMPLICIT: the same kernel with the input transform in its loader, no wino_input_kernel) on the
 Darknet-19 layer shapes that run it: time per launch (HIP events, best of 3 x reps) and bit-exactness against variant -1.
 
     python tools/wf_bench.py [--batch 32] [--variants -1,0,1,...] [--reps 10] [--pool] [--stats]
@@ -16,7 +17,8 @@ import torch  # noqa: E402
 
 import _hip  # noqa: E402
 
-SHAPES = [(104, 64, 128), (52, 128, 256), (26, 256, 512), (26, 512, 512), (13, 512, 1024)]       # (H = W, Cin, Cout)
+SHAPES = [(104, 64, 128), (52, 128, 256), (26, 256, 512), (26, 512, 512), (13, 512, 1024),       # (H = W, Cin, Cout): fprop ...
+          (104, 128, 64), (52, 256, 128), (26, 512, 256), (208, 64, 32)]                          # ... and data-gradient shapes
 
 
 def main():
@@ -27,6 +29,7 @@ def main():
     ap.add_argument('--pool', action='store_true')
     ap.add_argument('--stats', action='store_true')
     ap.add_argument('--shapes', default='')
+    ap.add_argument('--stamps', action='store_true', help='experiment builds (-DY2_EXP=16): print the per-stage cycle stamps of workgroup 0')
     ap.add_argument('--kernel-only', action='store_true', help='print the fused kernel alone (min over reps, event hooks) instead of the whole y2_conv_fwd')
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(',')]
@@ -58,7 +61,8 @@ def main():
         ref = None
         row = '%-18s' % ('%dx%d %d->%d' % (H, H, cin, cout))
         for v in variants:
-            os.environ['Y2_WF_VARIANT'] = str(v)
+            os.environ['Y2_WF_VARIANT'] = str(v if v != 100 else 3)
+            p.algo = 3 if v == 100 else 2
             y.fill_(float('nan'))
             if yp is not None:
                 yp.fill_(float('nan'))
@@ -69,6 +73,17 @@ def main():
                 row += '%9s' % ('rc%d' % rc)
                 continue
             torch.cuda.synchronize()
+            if args.stamps:
+                T = B * ((H + 1) // 2) ** 2
+                a256 = lambda n: (n + 255) // 256 * 256
+                off = (0 if v == 100 else a256(16 * T * cin * 4)) + a256(T * 4) + 1024
+                raw = ws.view(torch.uint8)[off:off + 8000].cpu().numpy().view('uint64')
+                d = [int(raw[i + 1] - raw[i]) for i in range(0, 160)]
+                nst = 4 * (cin // 32)
+                print('v%d %dx%d %d->%d: stages/tile %d; stamp deltas (cycles):' % (v, H, H, cin, cout, nst))
+                per = nst + 2
+                for r0 in range(0, 160 - per, per):
+                    print('   ', ' '.join('%5d' % x for x in d[r0:r0 + per]))
             out = (y.clone(), yp.clone() if yp is not None else None, stats.clone() if stats is not None else None)
             if v == -1 or ref is None:
                 ref = out

@@ -258,9 +258,10 @@ if TUNE_CACHE and os.path.exists(TUNE_CACHE):
 
 
 WINOGRAD = os.environ.get('Y2_WINOGRAD', '1') != '0'     # 0: never pick the Winograd F(2x2,3x3) algorithm
-FORCE_ALGO = os.environ.get('Y2_FORCE_ALGO') or None     # 'direct' | 'winograd' | 'fused': no autotune, that algorithm wherever the library accepts it
-if FORCE_ALGO not in (None, 'direct', 'winograd', 'fused'):
-    raise ValueError('Y2_FORCE_ALGO must be direct, winograd or fused (got %r)' % FORCE_ALGO)
+FORCE_ALGO = os.environ.get('Y2_FORCE_ALGO') or None     # 'direct' | 'winograd' | 'fused' | 'implicit': no autotune, that algorithm wherever the library accepts it
+if FORCE_ALGO not in (None, 'direct', 'winograd', 'fused', 'implicit'):
+    raise ValueError('Y2_FORCE_ALGO must be direct, winograd, fused or implicit (got %r)' % FORCE_ALGO)
+IMPLICIT = os.environ.get('Y2_WINO_IMPLICIT', '1') != '0'  # 0: never offer Y2_ALGO_WINOGRAD_IMPLICIT (A/B runs)
 WINO_MIN_CIN = 64                                        # below this the transforms cost more than the GEMM saves (measured)
 
 
@@ -289,29 +290,34 @@ def _time_conv(L, params, st):
     return t
 
 
-def autotune_conv(params, dev, wino_w=None):
+def autotune_conv(params, dev, wino_w=None, implicit_ok=True):
     """Measure-don't-guess algorithm + tile selection for one y2_conv_fwd problem: the first time a problem shape is seen,
     every tile configuration of the direct kernel - and, when `wino_w` (y2_wino_weight output) is given, of the Winograd
     path - is timed (HIP events, best of 2 x 3 launches) and the fastest is cached for the process; later calls only
     look the answer up.  Sets params.algo / params.tile / params.w.  The outputs written while timing are real outputs.
-    Never measures while a hipGraph is being captured (plans are built during warm-up)."""
+    Never measures while a hipGraph is being captured (plans are built during warm-up).
+    implicit_ok=False: the caller wants the transformed input left in the workspace (training keeps it for the weight gradient),
+    so the algorithm that never materialises it (3) is not offered."""
     wino_ok = (wino_w is not None and WINOGRAD and params.ksize == 3 and params.stride in (0, 1) and params.pad_plus1 in (0, 2)
                and not params.transposed and not params.residual and params.out_mode == 0)
     key = (params.B, params.H, params.W, params.Cin, params.ldx, params.Cout, params.ksize, bool(params.y), bool(params.y_pool),
            bool(params.stats), params.out_mode, params.stride, params.pad_plus1, bool(params.residual), params.transposed, params.out_h, params.out_w, str(dev),
-           bool(wino_ok))
+           bool(wino_ok), bool(implicit_ok and IMPLICIT))
+    implicit_ok = bool(implicit_ok and IMPLICIT) and params.Cin % 32 == 0 and params.Cin >= 64
     w_direct = params.w
 
     def apply(choice):
         algo, tile = choice
         params.algo, params.tile = algo, tile
-        params.w = wino_w.data_ptr() if algo in (1, 2) else w_direct
+        params.w = wino_w.data_ptr() if algo in (1, 2, 3) else w_direct
         return choice
     if FORCE_ALGO is not None:
         # deterministic algorithm coverage (tests, A/B runs): every eligible layer takes the named algorithm, everything else the
         # direct kernel with the library's own tile choice; no measurement, no cache
-        want = {'direct': None, 'winograd': (1, 5), 'fused': (2, 0)}[FORCE_ALGO]
-        if want is not None and wino_ok and (want[0] != 2 or params.Cin % 32 == 0):
+        want = {'direct': None, 'winograd': (1, 5), 'fused': (2, 0), 'implicit': (3, 0)}[FORCE_ALGO]
+        if want is not None and want[0] == 3 and not implicit_ok:
+            want = (2, 0)               # where the transformed input must stay behind: the fused kernel that reads it
+        if want is not None and wino_ok and (want[0] == 1 or params.Cin % 32 == 0):
             apply(want)
             if lib().y2_conv_fwd_workspace_bytes(ctypes.byref(params)) >= 0:
                 return want
@@ -322,6 +328,8 @@ def autotune_conv(params, dev, wino_w=None):
     if not AUTOTUNE or DETERMINISTIC or torch.cuda.is_current_stream_capturing():
         # no measurement possible (or, deterministic mode: a timed choice may differ from run to run and with it the rounding): the choices the measurements converge to on MI355X (profiles/r01_detect_b32_layer_table.txt)
         prefer = []
+        if wino_ok and implicit_ok and (params.H * params.W >= 52 * 52 or (params.H * params.W >= 26 * 26 and params.Cout <= params.Cin)):
+            prefer.append((3, 0))       # fused Winograd with the input transform in its loader: the large maps and the data gradients
         if wino_ok and params.Cin % 32 == 0 and params.H * params.W >= 26 * 26:
             prefer.append((2, 0))       # fused Winograd on the 104x104 ... 26x26 layers
         if wino_ok and params.Cin >= 128:
@@ -340,6 +348,8 @@ def autotune_conv(params, dev, wino_w=None):
         cands += [(1, t) for t in (5, 3, 2, 1)]
         if params.Cin % 32 == 0:
             cands.append((2, 0))        # fused GEMM + output transform (no product tensor): pays on the 52x52 layers
+        if implicit_ok:
+            cands.append((3, 0))        # ... with the input transform in its loader (no transformed input in memory either)
     best, best_t = (0, 0), float('inf')
     stats_save = params.stats
     params.stats = None          # timing launches must not accumulate statistics twice

@@ -76,6 +76,17 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoInArgs a) {
     }
 }
 
+// The decode table alone (Y2_ALGO_WINOGRAD_IMPLICIT has no input-transform kernel to write it).
+__global__ __launch_bounds__(256) void wino_tile_table_kernel(int32_t* tile_pix, int T, int H, int W, int th, int tw, y2_fastdiv d_tt, y2_fastdiv d_tw) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= (uint32_t)T) return;
+    const int b = (int)y2_div(t, d_tt);
+    const int r = (int)t - b * th * tw;
+    const int ty = (int)y2_div((uint32_t)r, d_tw);
+    const int tx = r - ty * tw;
+    tile_pix[t] = (int32_t)(((uint32_t)((b * H + 2 * ty) * W + 2 * tx)) | (2 * ty + 1 < H ? 0x40000000u : 0u) | (2 * tx + 1 < W ? 0x80000000u : 0u));
+}
+
 struct WinoOutArgs {
     const float* m;
     const float* scale;
@@ -224,6 +235,24 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 //     flight, counted vmcnt + one raw s_barrier per stage; 8 ds_read_b128 + 16 MFMA 32x32x2 per wave per stage.
 //   * epilogue: accumulator register r of the 16 positions belongs to the same (tile, channel): 24 adds give the 2x2 output
 //     pixels, then affine + LeakyReLU, optional 2x2 max-pool (a tile is a pooling window) and BN statistics (valid pixels only).
+// Packed fp32 add / subtract (2 lanes of a register pair per instruction).  The compiler selects v_pk_add_f32 for vector adds only
+// when it feels like it and never for subtracts; inside the MFMA stream of the fused kernel every VALU instruction costs MFMA issue
+// slots (measured: 64 scalar adds per stage = +15 % kernel time), so the in-loader input transform spells them out.  a + (-b) is
+// the same IEEE operation as a - b: bit-identical to the scalar form.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 y2_pk_add(f32x4 a, f32x4 b) {
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(__builtin_shufflevector(b, b, 0, 1)));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(__builtin_shufflevector(b, b, 2, 3)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 y2_pk_sub(f32x4 a, f32x4 b) {
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(__builtin_shufflevector(b, b, 0, 1)));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(__builtin_shufflevector(b, b, 2, 3)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
 constexpr int WF_POS_FLOATS = (64 + 64) * 32;      // one position's A + B slab (16 KB)
 constexpr int WF2_DEFAULT_VARIANT = 3;             // which fused kernel y2_conv_fwd launches by default: -1 = first generation, else the feature mask of wino_fused2_kernel
 
@@ -238,6 +267,9 @@ struct WinoFusedArgs {
     unsigned v_bytes, u_bytes;
     float slope;
     y2_fastdiv d_tt, d_tw;
+    const float* x;       // VAR bit 2 of wino_fused2_kernel: the chunk's NHWC input itself (v unused)
+    int ldx;
+    unsigned x_bytes;
 };
 
 // PG = positions per pipeline stage (one barrier per stage: 16*PG MFMAs per wave between barriers), WF_STAGES = ring depth.
@@ -468,11 +500,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // live VGPRs spill and the VALU/stores delay MFMA issue; (b) exchanging the MFMA operand roles (accumulator rows = channels, so
 // a lane stores 16 bytes) lost 10-30 %: 64 lanes x 16 B to 64 different cache lines per store instruction; (c) skipping the
 // filter-operand DMA altogether (a wrong-result experiment) gains only 2-6 %: the K loop is not LDS-DMA-bandwidth bound.
+//   * implicit input transform (VAR bit 2, Y2_ALGO_WINOGRAD_IMPLICIT): the input operand of a stage is not DMA'd from a transformed
+//     tensor V but built by the loader: a thread owns the same two (tile row, 4-channel chunk) items the DMA lane owned, loads
+//     their 4x4 input pixels with buffer_load_dwordx4 (zero padding = buffer out-of-range), forms row g of B^T d B for the
+//     stage's 4 positions with 16 packed adds per item and ds_writes them where the DMA would have put V.  wino_input_kernel and
+//     the 4x-input tensor V (write + read) disappear; the kernel itself runs 1-11 % slower than with DMA'd V (B=32: 0.310 vs
+//     0.280 ms on 104x104x64->128, 0.276 vs 0.275 on 104x104x128->64), the layer 6-38 % faster.  Schedule of a stage: pixel loads
+//     behind the first 8 MFMAs, filter DMA behind MFMAs 8..39, transform + store behind the last 16.
+//     What was measured on the way (B=32, kernel alone): loading rows per stage instead of keeping rows 1 / 2 in registers across
+//     the K slab: +3 %; scalar instead of packed adds: +-0; fragment double buffering (VAR bit 1) on top: +3-7 % (its 32
+//     registers spill); pixel loads a whole stage ahead (fourth row buffer, 128 registers of pixels): +8-25 % - the tile
+//     transition spills ~100 registers; dword "touch" loads one stage ahead as a cache prefetch: +1-7 % (the exposed part is
+//     bandwidth / issue, not latency: with every load redirected into one 2 KB window the kernel reaches the DMA variant's time).
 template <int VAR, int OUT>     // OUT: bit 0 = full-resolution output y, bit 1 = pooled output, bit 2 = BatchNorm statistics
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fused2_kernel(const WinoFusedArgs a) {
     constexpr bool HAS_Y = (OUT & 1) != 0, HAS_POOL = (OUT & 2) != 0, HAS_STATS = (OUT & 4) != 0;
-    constexpr bool SPREAD = (VAR & 1) != 0, DBUF = (VAR & 2) != 0;
-    constexpr unsigned OOB = 0x80000000u;
+    constexpr bool SPREAD = (VAR & 1) != 0, DBUF = (VAR & 2) != 0, RAWIN = (VAR & 4) != 0;
+    constexpr unsigned OOB = 0x80000000u, OOB_COL = 0x40000000u;
     constexpr int PG = 4;
     constexpr int STAGE_FLOATS = PG * WF_POS_FLOATS;          // 64 KB
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -493,6 +537,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int srow = t >> 3;
     const int lchunk = (lane & 7) ^ ((srow >> 1) & 7);
     unsigned a_off[2], b_off[2];                 // operand row offsets of the tile whose stages are being FETCHED
+    unsigned rowoff[2][4], coloff[2][4];         // RAWIN: byte offsets of the 4 rows / 4 columns of the 4x4 input patch of the thread's two tiles
     int fm0 = 0, fn0 = 0;                        // ... and its origin
     auto place = [&](int tl) {
         fm0 = (tl / a.tiles_n) * 64;
@@ -500,11 +545,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = fm0 + srow + 32 * i, n = fn0 + srow + 32 * i;
-            a_off[i] = m < a.T ? (unsigned)(((size_t)m * a.Cin + 4 * lchunk) * 4) : OOB;
             b_off[i] = n < a.Cout ? (unsigned)(((size_t)n * a.Cin + 4 * lchunk) * 4) : OOB;
+            if (!RAWIN) {
+                a_off[i] = m < a.T ? (unsigned)(((size_t)m * a.Cin + 4 * lchunk) * 4) : OOB;
+            } else {
+                // pixel (y, x) of the patch sits at rowoff[y] + coloff[x]; a row or column outside the image gets a sentinel that
+                // pushes the sum past the buffer's num_records (x_bytes < 2^30, host check), where a buffer load returns zeros:
+                // the zero padding of the convolution and the tiles past T cost no branch
+                const bool mok = m < a.T;
+                const uint32_t mm = mok ? (uint32_t)m : 0u;
+                const int b = (int)y2_div(mm, a.d_tt);
+                const int rr = (int)mm - b * a.th * a.tw;
+                const int ty = (int)y2_div((uint32_t)rr, a.d_tw);
+                const int tx = rr - ty * a.tw;
+                const unsigned pix_bytes = (unsigned)a.ldx * 4u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int yy = 2 * ty - 1 + r, xx = 2 * tx - 1 + r;
+                    rowoff[i][r] = (mok && (unsigned)yy < (unsigned)a.H) ? (unsigned)((b * a.H + yy) * a.W) * pix_bytes : OOB;
+                    coloff[i][r] = (unsigned)xx < (unsigned)a.W ? (unsigned)xx * pix_bytes + 16u * (unsigned)lchunk : OOB_COL;
+                }
+            }
         }
     };
     place(tile);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RAWIN ? a.x : a.v), 0, RAWIN ? a.x_bytes : a.v_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.v), 0, a.v_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
     const unsigned v_plane = (unsigned)((size_t)a.T * a.Cin * 4), u_plane = (unsigned)((size_t)a.Cout * a.Cin * 4);
@@ -524,13 +589,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int q = 0; q < 4; ++q) foff[q] = l31 * 32 + (((2 * q + half) ^ sw) << 2);
     const int fa = wm * 32 * 32, fb = 64 * 32 + wn * 32 * 32;
 
-    // ---- one pipeline stage: consume ring slot SLOT into the 4 accumulators c[0..3];  FETCH: also issue the 16 DMA pieces of
-    //      stage (fk, fg) into the other slot
-    auto stage = [&](auto SLOT, f32x16* c, auto FETCH, int fk, int fg) {
+    // RAWIN: one pixel chunk (4 channels) of input row `row` / column `col` of the 4x4 patch of the thread's tile i, K slab `kslab`
+    auto raw_px = [&](int i, int row, int col, int kslab) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(rowoff[i][row] + coloff[i][col]), kslab * 128, 0));
+    };
+    // RAWIN: positions 4*g .. 4*g+3 are row g of B^T d B: s = d0 - d2 | d1 + d2 | d2 - d1 | d1 - d3 per column (g = 0..3), then the
+    // same column combination as wino_input_kernel (same operations in the same order: bit-identical V).  Patch rows 1 and 2 feed
+    // three position rows each: they stay in registers across the stages of a K slab (pr1, pr2; pr0 holds row 0, later row 3), so a
+    // K slab loads every input pixel of the tile once - 32 loads per thread, the same bytes the DMA of V moved.
+    f32x4 pr0[2][4], pr1[2][4], pr2[2][4];
+    auto col_combine = [&](const f32x4* sv, int j) -> f32x4 {
+        return j == 0 ? y2_pk_sub(sv[0], sv[2]) : (j == 1 ? y2_pk_add(sv[1], sv[2]) : (j == 2 ? y2_pk_sub(sv[2], sv[1]) : y2_pk_sub(sv[1], sv[3])));
+    };
+
+    // ---- one pipeline stage: consume ring slot SLOT into the 4 accumulators c[0..3];  FETCH: also fetch stage (fk, FG) into the
+    //      other slot: 16 DMA pieces, or (RAWIN) 8 filter DMA pieces + the thread's 2 x 8 input pixels, transformed in registers
+    auto stage = [&](auto SLOT, f32x16* c, auto FETCH, int fk, auto FG) {
         constexpr int slot = decltype(SLOT)::value;
         constexpr bool fetch = decltype(FETCH)::value;
+        constexpr int fg = decltype(FG)::value;
         const float* sbuf = smem + slot * STAGE_FLOATS;
+        float* const wbuf = smem + (slot ^ 1) * STAGE_FLOATS + t * 4;      // RAWIN: where this thread's V chunks go (position 0, tile 0)
         f32x4 av[2][PG], bv[2][PG];
+        f32x4 sv[4];
         auto reads = [&](int q, int buf) {
 #pragma unroll
             for (int pp = 0; pp < PG; ++pp) {
@@ -538,7 +619,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 bv[buf][pp] = *reinterpret_cast<const f32x4*>(sbuf + pp * WF_POS_FLOATS + fb + foff[q]);
             }
         };
-        if (fetch && !SPREAD) {
+        if (fetch && !SPREAD && !RAWIN) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) dma_piece(fk, fg, slot ^ 1, j);
         }
@@ -553,8 +634,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int pp = 0; pp < PG; ++pp) {
                     c[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][pp][e], bv[cb][pp][e], c[pp], 0, 0, 0);
-                    // two DMA pieces per slot in the first 8 slots, behind MFMAs 0 and 2 of the slot
-                    if (SPREAD && fetch && sl < 8 && (pp == 0 || pp == 2)) dma_piece(fk, fg, slot ^ 1, 2 * sl + (pp >> 1));
+                    if (!RAWIN) {
+                        // two DMA pieces per slot in the first 8 slots, behind MFMAs 0 and 2 of the slot
+                        if (SPREAD && fetch && sl < 8 && (pp == 0 || pp == 2)) dma_piece(fk, fg, slot ^ 1, 2 * sl + (pp >> 1));
+                    } else if (fetch) {
+                        if (sl < 2) {                     // slots 0, 1: the pixel loads of tile 0 / tile 1 (rows 0 + 2 | 1 | none | 3)
+                            if (fg == 0) { pr0[sl][pp] = raw_px(sl, 0, pp, fk); pr2[sl][pp] = raw_px(sl, 2, pp, fk); }
+                            else if (fg == 1) pr1[sl][pp] = raw_px(sl, 1, pp, fk);
+                            else if (fg == 3) pr0[sl][pp] = raw_px(sl, 3, pp, fk);
+                        } else if (sl < 10) {             // slots 2..9: the 8 filter DMA pieces
+                            if (pp == 0) dma_piece(fk, fg, slot ^ 1, 4 * ((sl - 2) >> 1) + 2 + ((sl - 2) & 1));
+                        } else if (sl >= 12) {            // slots 12, 13: tile 0, slots 14, 15: tile 1 (>= 12 slots = 3k cycles after the loads)
+                            const int i = (sl - 12) >> 1;
+                            if (((sl - 12) & 1) == 0)
+                                sv[pp] = fg == 0 ? y2_pk_sub(pr0[i][pp], pr2[i][pp]) : (fg == 1 ? y2_pk_add(pr1[i][pp], pr2[i][pp]) : (fg == 2 ? y2_pk_sub(pr2[i][pp], pr1[i][pp]) : y2_pk_sub(pr1[i][pp], pr0[i][pp])));
+                            else *reinterpret_cast<f32x4*>(wbuf + pp * WF_POS_FLOATS + i * 32 * 32) = col_combine(sv, pp);
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -565,13 +661,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     using F_ = std::false_type;
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
+    using G0 = std::integral_constant<int, 0>;
+    using G1 = std::integral_constant<int, 1>;
+    using G2 = std::integral_constant<int, 2>;
+    using G3 = std::integral_constant<int, 3>;
 
     float* const dump = a.dump + t;
     const size_t row_stride = (size_t)a.W * a.ldy;
     const int nks = a.Cin / 32;                  // host guarantees nks >= 2: every tile runs 4 * nks stages, an even number, so a
     // prologue: the first stage of the first tile     // tile always starts in ring slot 0 and stage g of a K slab sits in slot g & 1
+    if (!RAWIN) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dma_piece(0, 0, 0, j);
+        for (int j = 0; j < 16; ++j) dma_piece(0, 0, 0, j);
+    } else {
+#pragma unroll
+        for (int pp = 0; pp < PG; ++pp) {
+            dma_piece(0, 0, 0, 4 * pp + 2);
+            dma_piece(0, 0, 0, 4 * pp + 3);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x4 sv[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                pr2[i][cc] = raw_px(i, 2, cc, 0);
+                sv[cc] = y2_pk_sub(raw_px(i, 0, cc, 0), pr2[i][cc]);
+            }
+#pragma unroll
+            for (int pp = 0; pp < PG; ++pp) *reinterpret_cast<f32x4*>(smem + t * 4 + pp * WF_POS_FLOATS + i * 32 * 32) = col_combine(sv, pp);
+        }
+    }
     for (;;) {
         const int em0 = fm0, en0 = fn0;           // this tile's origin (the fetch cursor is still on this tile)
 #pragma unroll
@@ -579,40 +698,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 #define Y2_WF2_SYNC()                                              \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           \
+        if (RAWIN) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   /* + this wave's ds_write of V */ \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
         __builtin_amdgcn_s_barrier()
         for (int ks = 0; ks < nks - 1; ++ks) {
             Y2_WF2_SYNC();
-            stage(S0{}, &acc[0], T_{}, ks, 1);
+            stage(S0{}, &acc[0], T_{}, ks, G1{});
             Y2_WF2_SYNC();
-            stage(S1{}, &acc[4], T_{}, ks, 2);
+            stage(S1{}, &acc[4], T_{}, ks, G2{});
             Y2_WF2_SYNC();
-            stage(S0{}, &acc[8], T_{}, ks, 3);
+            stage(S0{}, &acc[8], T_{}, ks, G3{});
             Y2_WF2_SYNC();
-            stage(S1{}, &acc[12], T_{}, ks + 1, 0);
+            stage(S1{}, &acc[12], T_{}, ks + 1, G0{});
         }
         // ---- last K slab; its last stage fetches the first stage of the workgroup's next tile
         Y2_WF2_SYNC();
-        stage(S0{}, &acc[0], T_{}, nks - 1, 1);
+        stage(S0{}, &acc[0], T_{}, nks - 1, G1{});
         Y2_WF2_SYNC();
-        stage(S1{}, &acc[4], T_{}, nks - 1, 2);
+        stage(S1{}, &acc[4], T_{}, nks - 1, G2{});
         Y2_WF2_SYNC();
-        stage(S0{}, &acc[8], T_{}, nks - 1, 3);
+        stage(S0{}, &acc[8], T_{}, nks - 1, G3{});
         tile += wgs_per_xcd;
         const bool more = tile < xcd_end;
-        // decode-table entries of this tile's 16 rows (two distinct addresses per wave: broadcast loads), in flight during the last stage
+        Y2_WF2_SYNC();
+        // decode-table entries of this tile's 16 rows (two distinct addresses per wave: broadcast loads), in flight during the last
+        // stage (issued in front of the barrier above, their latency - ~2k cycles per tile - was exposed)
         int prow[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int tt = em0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            prow[r] = tt < a.T ? a.tile_pix[tt] : -1;
+            const int e = a.tile_pix[min(tt, a.T - 1)];
+            prow[r] = tt < a.T ? e : -1;
         }
-        Y2_WF2_SYNC();
         if (more) {
             place(tile);
-            stage(S1{}, &acc[12], T_{}, 0, 0);
+            stage(S1{}, &acc[12], T_{}, 0, G0{});
         } else {
-            stage(S1{}, &acc[12], F_{}, 0, 0);
+            stage(S1{}, &acc[12], F_{}, 0, G0{});
         }
 #undef Y2_WF2_SYNC
         // ---- epilogue: output transform A^T M A in registers (accumulator register r of the 16 positions belongs to the same
@@ -781,21 +903,26 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     if (p->y_pool != nullptr && ((p->H & 1) || (p->W & 1) || p->ldp < p->poff + p->Cout)) return Y2_EINVAL;
     if (p->y_pool != nullptr && ((p->ldp % 4) != 0 || (p->poff % 4) != 0 || !y2_aligned16(p->y_pool))) return Y2_ENOSUP;
     if ((p->scale != nullptr && !y2_aligned16(p->scale)) || (p->shift != nullptr && !y2_aligned16(p->shift))) return Y2_ENOSUP;
-    const bool fused = p->algo == Y2_ALGO_WINOGRAD_FUSED;
+    const bool implicit = p->algo == Y2_ALGO_WINOGRAD_IMPLICIT;      // fused, and the input transform happens in the fused kernel's loader
+    const bool fused = p->algo == Y2_ALGO_WINOGRAD_FUSED || implicit;
     if (fused && (p->Cin % 32) != 0) return Y2_ENOSUP;
+    if (implicit && p->Cin < 64) return Y2_ENOSUP;
     const int th = (p->H + 1) / 2, tw = (p->W + 1) / 2;
     // Batch chunks bound the workspace (V = 4x the input, M = 4x the output of a chunk); see wino_chunk_bytes().
-    const size_t img_bytes = (size_t)16 * th * tw * ((size_t)p->Cin + (fused ? 0 : p->Cout)) * sizeof(float);
+    const size_t img_bytes = implicit ? (size_t)th * tw * sizeof(int32_t) : (size_t)16 * th * tw * ((size_t)p->Cin + (fused ? 0 : p->Cout)) * sizeof(float);
     int cb = (int)(wino_chunk_bytes() / (img_bytes > 0 ? img_bytes : 1));
     if (cb < 1) cb = 1;
     if (cb > p->B) cb = p->B;
     // the fused kernel addresses V through one 32-bit buffer descriptor: keep a chunk's V below 2 GB
-    while (fused && cb > 1 && (size_t)16 * cb * th * tw * p->Cin * sizeof(float) >= 0x7fffffffull) cb = (cb + 1) / 2;
+    while (fused && !implicit && cb > 1 && (size_t)16 * cb * th * tw * p->Cin * sizeof(float) >= 0x7fffffffull) cb = (cb + 1) / 2;
+    // the implicit kernel addresses the chunk's input through one buffer descriptor with 2^30 / 2^31 as out-of-image sentinels
+    while (implicit && cb > 1 && (size_t)cb * p->H * p->W * p->ldx * sizeof(float) >= 0x40000000ull) cb = (cb + 1) / 2;
+    if (implicit && (size_t)cb * p->H * p->W * p->ldx * sizeof(float) >= 0x40000000ull) return Y2_ENOSUP;
     const int nchunks = y2_cdiv(p->B, cb);
     cb = y2_cdiv(p->B, nchunks);                     // equal chunks
     const long long T = (long long)cb * th * tw;    // tiles of a full chunk
     if (T * (p->Cin / 4) >= 0xffffffffLL || T * (p->Cout / 4) >= 0xffffffffLL || T > 0x7fffffff) return Y2_ENOSUP;
-    const size_t vbytes = align256((size_t)16 * T * p->Cin * sizeof(float));
+    const size_t vbytes = implicit ? 0 : align256((size_t)16 * T * p->Cin * sizeof(float));
     const size_t mbytes = fused ? align256((size_t)T * sizeof(int32_t)) + 1024 : align256((size_t)16 * T * p->Cout * sizeof(float));   // fused: tile decode table + 1 KB dump area
     if (fused && (vbytes >= 0x7fffffffull || (size_t)16 * p->Cout * p->Cin * 4 >= 0x7fffffffull)) return Y2_ENOSUP;
 
@@ -830,16 +957,18 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
         ia.T = (int)Tc; ia.c4n = p->Cin / 4;
         ia.d_c4 = y2_make_fastdiv((uint32_t)ia.c4n); ia.d_tt = d_tt; ia.d_tw = d_tw;
         ia.tile_pix = fused ? reinterpret_cast<int32_t*>(M) : nullptr;      // the fused path has no product tensor: the table sits behind V
-        Y2_LAUNCH("wino_input_kernel", 0.0, wino_input_kernel, dim3((unsigned)y2_cdiv(Tc * ia.c4n, 256)), dim3(256), 0, s, ia);
+        if (implicit) Y2_LAUNCH("wino_tile_table_kernel", 0.0, wino_tile_table_kernel, dim3((unsigned)y2_cdiv(Tc, 256)), dim3(256), 0, s, ia.tile_pix, ia.T, ia.H, ia.W, th, tw, d_tt, d_tw);
+        else Y2_LAUNCH("wino_input_kernel", 0.0, wino_input_kernel, dim3((unsigned)y2_cdiv(Tc * ia.c4n, 256)), dim3(256), 0, s, ia);
 
         if (fused) {
             WinoFusedArgs fa;
+            fa.x = ia.x; fa.ldx = p->ldx; fa.x_bytes = (unsigned)((size_t)nb * p->H * p->W * p->ldx * sizeof(float));
             fa.v = V; fa.u = p->w; fa.tile_pix = ia.tile_pix; fa.dump = M + (mbytes - 1024) / sizeof(float); fa.scale = p->scale; fa.shift = p->shift; fa.stats = p->stats;
             fa.y = p->y != nullptr ? p->y + in_off * p->ldy : nullptr;
             fa.y_pool = p->y_pool != nullptr ? p->y_pool + (size_t)b0 * th * tw * p->ldp : nullptr;
             fa.H = p->H; fa.W = p->W; fa.Cin = p->Cin; fa.Cout = p->Cout; fa.ldy = p->ldy; fa.coff = p->coff; fa.ldp = p->ldp; fa.poff = p->poff;
             fa.th = th; fa.tw = tw; fa.T = (int)Tc; fa.tiles_m = y2_cdiv(Tc, 64); fa.tiles_n = y2_cdiv(p->Cout, 64);
-            fa.v_bytes = (unsigned)((size_t)16 * Tc * p->Cin * 4); fa.u_bytes = (unsigned)((size_t)16 * p->Cout * p->Cin * 4);
+            fa.v_bytes = implicit ? 0u : (unsigned)((size_t)16 * Tc * p->Cin * 4); fa.u_bytes = (unsigned)((size_t)16 * p->Cout * p->Cin * 4);
             fa.slope = p->slope; fa.d_tt = d_tt; fa.d_tw = d_tw;
             const long long ntiles = (long long)fa.tiles_m * fa.tiles_n;
             if (ntiles > 0x7fffffffLL) return Y2_EINVAL;
@@ -858,7 +987,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
                 const size_t lds = (size_t)2 * 4 * WF_POS_FLOATS * sizeof(float);                                                  \
                 static Y2LdsAttr attr;                                                                                             \
                 if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(kern))) return rc_;                                  \
-                Y2_LAUNCH("wino_fused2_kernel", 2.0 * 16.0 * (double)fa.T * fa.Cout * fa.Cin, kern, dim3((unsigned)grid), dim3(256), lds, s, fa); \
+                Y2_LAUNCH(((VAR_) & 4) ? "wino_fused2_kernel[implicit]" : "wino_fused2_kernel", 2.0 * 16.0 * (double)fa.T * fa.Cout * fa.Cin, kern, dim3((unsigned)grid), dim3(256), lds, s, fa); \
             } while (0)
 #define Y2_WF2_LAUNCH(VAR_)                                                                                                        \
             do {                                                                                                                   \
@@ -874,6 +1003,11 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
             const char* ve = getenv("Y2_WF_VARIANT");           // read per call (experiments / tests switch it at run time)
             const int variant = ve != nullptr ? atoi(ve) : WF2_DEFAULT_VARIANT;
             const bool small_out = (unsigned long long)p->B * p->H * p->W * (unsigned long long)(p->ldy > p->ldp ? p->ldy : p->ldp) < 0x7fffffffull;
+            if (implicit) {
+                if (!small_out) return Y2_ENOSUP;
+                Y2_WF2_LAUNCH(5);           // no fragment double buffering: its 32 registers hold patch rows (with it: spills, 3-7 % slower)
+                continue;
+            }
             if (variant >= 0 && p->Cin >= 64 && small_out) {
                 switch (variant) {
                     case 0: Y2_WF2_LAUNCH(0); break;       // branch-free epilogue only

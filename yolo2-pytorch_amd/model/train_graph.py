@@ -87,7 +87,7 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
         u = _hip.wino_weight(wp, cout, cin) if (out_mode == 0 and _hip.wino_eligible(cout, cin, k)) else None
     elif out_mode != 0:
         u = None
-    _hip.autotune_conv(p, x.device, wino_w=u)
+    _hip.autotune_conv(p, x.device, wino_w=u, implicit_ok=not keep_v)
     kept = None
     if keep_v and p.algo in (1, 2):
         T = B * ((H + 1) // 2) * ((W + 1) // 2)

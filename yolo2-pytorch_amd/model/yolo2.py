@@ -275,7 +275,7 @@ class Darknet(nn.Module):
             p.workspace, p.workspace_bytes = (ws.data_ptr(), ws.numel() * 4) if ws is not None else (None, 0)
         arr = (_hip.ConvParams * len(plist))(*plist)
         # multiply-adds the MFMA pipe really executes: a Winograd layer runs 16 GEMMs over ceil(H/2)*ceil(W/2) tiles per image
-        executed = sum(2.0 * p.Cin * p.Cout * (16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2) else p.ksize ** 2 * p.B * p.H * p.W)
+        executed = sum(2.0 * p.Cin * p.Cout * (16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2, 3) else p.ksize ** 2 * p.B * p.H * p.W)
                        for p in plist)
         plan = dict(arr=arr, n=len(plist), first=first, head_index=head_index, head_shape=head_shape, flops=flops, flops_executed=executed,
                     algos=[int(p.algo != 0) for p in plist],
