@@ -29,7 +29,7 @@ def main():
     ap.add_argument('--pool', action='store_true')
     ap.add_argument('--stats', action='store_true')
     ap.add_argument('--shapes', default='')
-    ap.add_argument('--stamps', action='store_true', help='experiment builds (-DY2_EXP=16): print the per-stage cycle stamps of workgroup 0')
+    ap.add_argument('--stamps', action='store_true', help='builds with Y2_EXTRA_FLAGS=-DY2_STAMPS (Y2_LIB=...): print the per-stage cycle stamps of workgroup 0')
     ap.add_argument('--kernel-only', action='store_true', help='print the fused kernel alone (min over reps, event hooks) instead of the whole y2_conv_fwd')
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(',')]
@@ -78,7 +78,7 @@ def main():
                 a256 = lambda n: (n + 255) // 256 * 256
                 off = (0 if v == 100 else a256(16 * T * cin * 4)) + a256(T * 4) + 1024
                 raw = ws.view(torch.uint8)[off:off + 8000].cpu().numpy().view('uint64')
-                d = [int(raw[i + 1] - raw[i]) for i in range(0, 160)]
+                d = [int(raw[i + 1]) - int(raw[i]) if raw[i + 1] and raw[i] else 0 for i in range(0, 160)]
                 nst = 4 * (cin // 32)
                 print('v%d %dx%d %d->%d: stages/tile %d; stamp deltas (cycles):' % (v, H, H, cin, cout, nst))
                 per = nst + 2

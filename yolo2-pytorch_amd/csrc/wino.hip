@@ -253,6 +253,11 @@ __device__ __forceinline__ f32x4 y2_pk_sub(f32x4 a, f32x4 b) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
+#ifdef Y2_STAMPS
+constexpr size_t WF_DUMP_BYTES = 1024 + 8192;
+#else
+constexpr size_t WF_DUMP_BYTES = 1024;      // where the lanes of pixels / tiles / channels that do not exist store (branch-free epilogue)
+#endif
 constexpr int WF_POS_FLOATS = (64 + 64) * 32;      // one position's A + B slab (16 KB)
 constexpr int WF2_DEFAULT_VARIANT = 3;             // which fused kernel y2_conv_fwd launches by default: -1 = first generation, else the feature mask of wino_fused2_kernel
 
@@ -511,7 +516,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //     the K slab: +3 %; scalar instead of packed adds: +-0; fragment double buffering (VAR bit 1) on top: +3-7 % (its 32
 //     registers spill); pixel loads a whole stage ahead (fourth row buffer, 128 registers of pixels): +8-25 % - the tile
 //     transition spills ~100 registers; dword "touch" loads one stage ahead as a cache prefetch: +1-7 % (the exposed part is
-//     bandwidth / issue, not latency: with every load redirected into one 2 KB window the kernel reaches the DMA variant's time).
+//     bandwidth / issue, not latency: with every load redirected into one 2 KB window the kernel reaches the DMA variant's time);
+//     every row loaded as early as its register frees (rows 1, 2, 3 one or two stages ahead, same 96 registers): +4-24 % (the
+//     pixel cursor of the next tile then lives across two more stages and the tile transition spills).  Per-stage stamps
+//     (-DY2_STAMPS): a stage costs 4.45k cycles with DMA'd V, 4.55k with the transform's adds and stores but no pixel loads, 5.0k
+//     with 8 pixel loads, and the stages that wait for a new K slab's 16 loads are the slow ones.
 template <int VAR, int OUT>     // OUT: bit 0 = full-resolution output y, bit 1 = pooled output, bit 2 = BatchNorm statistics
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fused2_kernel(const WinoFusedArgs a) {
     constexpr bool HAS_Y = (OUT & 1) != 0, HAS_POOL = (OUT & 2) != 0, HAS_STATS = (OUT & 4) != 0;
@@ -691,6 +700,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int pp = 0; pp < PG; ++pp) *reinterpret_cast<f32x4*>(smem + t * 4 + pp * WF_POS_FLOATS + i * 32 * 32) = col_combine(sv, pp);
         }
     }
+    // -DY2_STAMPS (tools/wf_bench.py --stamps): wave 0 of workgroup 0 records s_memtime behind every stage barrier and around the
+    // epilogue (in LDS - a global store would sit in the vmcnt queue of the loads being timed - copied out behind the dump area at
+    // the end; the host side reserves the room in the same build).  Caveat: the extra state changes the register allocation of the
+    // tile transition; the steady-state stages are what these stamps are good for.
+#ifdef Y2_STAMPS
+    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(smem + 2 * STAGE_FLOATS);
+    int nstamp = 0;
+#define Y2_STAMP() do { if (blockIdx.x == 0 && wave == 0 && nstamp < 1000) { const unsigned long long tm_ = __builtin_amdgcn_s_memtime(); if (lane == 0) stamps[nstamp] = tm_; ++nstamp; } } while (0)
+#else
+#define Y2_STAMP() do {} while (0)
+#endif
     for (;;) {
         const int em0 = fm0, en0 = fn0;           // this tile's origin (the fetch cursor is still on this tile)
 #pragma unroll
@@ -700,7 +720,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define Y2_WF2_SYNC()                                              \
         if (RAWIN) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   /* + this wave's ds_write of V */ \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
-        __builtin_amdgcn_s_barrier()
+        __builtin_amdgcn_s_barrier();                              \
+        Y2_STAMP()
         for (int ks = 0; ks < nks - 1; ++ks) {
             Y2_WF2_SYNC();
             stage(S0{}, &acc[0], T_{}, ks, G1{});
@@ -737,6 +758,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             stage(S1{}, &acc[12], F_{}, 0, G0{});
         }
 #undef Y2_WF2_SYNC
+        Y2_STAMP();
         // ---- epilogue: output transform A^T M A in registers (accumulator register r of the 16 positions belongs to the same
         //      (tile row, channel)), then affine + LeakyReLU, pooling, statistics, stores - branch-free
         const int pn = en0 + wn * 32 + l31;
@@ -789,8 +811,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 atomicAdd(st + a.Cout + pn, (double)s2);
             }
         }
+        Y2_STAMP();
         if (!more) break;
     }
+#ifdef Y2_STAMPS
+    if (blockIdx.x == 0 && wave == 0)
+        for (int i = lane; i < 1000; i += 64) reinterpret_cast<unsigned long long*>(a.dump + 256)[i] = i < nstamp ? stamps[i] : 0ull;
+#endif
+#undef Y2_STAMP
 }
 
 // ---- weight gradient:  dU[p][co][ci] = sum_t dM[p][t][co] * V[p][t][ci],   dM = A dz A^T (4x4 from the 2x2 gradient tile),
@@ -923,7 +951,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     const long long T = (long long)cb * th * tw;    // tiles of a full chunk
     if (T * (p->Cin / 4) >= 0xffffffffLL || T * (p->Cout / 4) >= 0xffffffffLL || T > 0x7fffffff) return Y2_ENOSUP;
     const size_t vbytes = implicit ? 0 : align256((size_t)16 * T * p->Cin * sizeof(float));
-    const size_t mbytes = fused ? align256((size_t)T * sizeof(int32_t)) + 1024 : align256((size_t)16 * T * p->Cout * sizeof(float));   // fused: tile decode table + 1 KB dump area
+    const size_t mbytes = fused ? align256((size_t)T * sizeof(int32_t)) + WF_DUMP_BYTES : align256((size_t)16 * T * p->Cout * sizeof(float));   // fused: tile decode table + 1 KB dump area
     if (fused && (vbytes >= 0x7fffffffull || (size_t)16 * p->Cout * p->Cin * 4 >= 0x7fffffffull)) return Y2_ENOSUP;
 
     // stage 2 as a grouped 1x1 "convolution" over an image of 1 x T pixels
@@ -963,7 +991,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
         if (fused) {
             WinoFusedArgs fa;
             fa.x = ia.x; fa.ldx = p->ldx; fa.x_bytes = (unsigned)((size_t)nb * p->H * p->W * p->ldx * sizeof(float));
-            fa.v = V; fa.u = p->w; fa.tile_pix = ia.tile_pix; fa.dump = M + (mbytes - 1024) / sizeof(float); fa.scale = p->scale; fa.shift = p->shift; fa.stats = p->stats;
+            fa.v = V; fa.u = p->w; fa.tile_pix = ia.tile_pix; fa.dump = M + (mbytes - WF_DUMP_BYTES) / sizeof(float); fa.scale = p->scale; fa.shift = p->shift; fa.stats = p->stats;
             fa.y = p->y != nullptr ? p->y + in_off * p->ldy : nullptr;
             fa.y_pool = p->y_pool != nullptr ? p->y_pool + (size_t)b0 * th * tw * p->ldp : nullptr;
             fa.H = p->H; fa.W = p->W; fa.Cin = p->Cin; fa.Cout = p->Cout; fa.ldy = p->ldy; fa.coff = p->coff; fa.ldp = p->ldp; fa.poff = p->poff;
@@ -984,7 +1012,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
 #define Y2_WF2_LAUNCH_(VAR_, OUT_)                                                                                                 \
             do {                                                                                                                   \
                 auto kern = wino_fused2_kernel<VAR_, OUT_>;                                                                        \
-                const size_t lds = (size_t)2 * 4 * WF_POS_FLOATS * sizeof(float);                                                  \
+                const size_t lds = (size_t)2 * 4 * WF_POS_FLOATS * sizeof(float) + (WF_DUMP_BYTES - 1024);                         \
                 static Y2LdsAttr attr;                                                                                             \
                 if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(kern))) return rc_;                                  \
                 Y2_LAUNCH(((VAR_) & 4) ? "wino_fused2_kernel[implicit]" : "wino_fused2_kernel", 2.0 * 16.0 * (double)fa.T * fa.Cout * fa.Cin, kern, dim3((unsigned)grid), dim3(256), lds, s, fa); \
