@@ -10,7 +10,7 @@ import json
 import re
 import sys
 
-FAMILY = re.compile(r'conv_fwd_dma_kernel|conv_splitk_fixup_kernel|wino_(input|output|fused)_kernel')
+FAMILY = re.compile(r'conv_fwd_dma_kernel|conv_splitk_fixup_kernel|wino_(input|output|fused2?|tile_table)_kernel|conv0_kernel')
 rows = []
 for line in open(sys.argv[1]):
     m = re.match(r'(\S+)\s+(\S+)\s+dispatches=\s*(\d+)\s+mean_per_dispatch=([0-9.eE+-]+)', line)
@@ -26,7 +26,7 @@ for k, c, n, v in rows:
             launches += n
 fetch, write = tot['FETCH_SIZE'] / steps, tot['WRITE_SIZE'] / steps
 print(json.dumps({
-    'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile.sh) on `bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3` (autotune cache pre-populated); conv_fwd_dma_kernel family + split-K fix-up + Winograd transform kernels',
+    'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile.sh) on `bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3` (autotune cache pre-populated); conv0 + conv_fwd_dma_kernel family + split-K fix-up + all Winograd kernels',
     'kernel_launches_profiled': launches, 'steps_profiled': steps,
     'fetch_size_bytes_raw_per_step': fetch, 'write_size_bytes_raw_per_step': write,
     'correction': 'gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE uncorrected; counters are L2 memory-side requests, Infinity-Cache hits included',
