@@ -55,6 +55,7 @@ def main():
         p.y_pool = yp.data_ptr() if yp is not None else None
         p.stats = stats.data_ptr() if stats is not None else None
         p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize, p.ldy, p.ldp, p.slope, p.algo = B, H, H, cin, cin, cout, 3, cout, cout, 0.1, 2
+        p.algo, p.tile = 1, 5
         need = L.y2_conv_fwd_workspace_bytes(ctypes.byref(p))
         ws = torch.empty(need // 4 + 4, device=dev)
         p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -62,7 +63,9 @@ def main():
         row = '%-18s' % ('%dx%d %d->%d' % (H, H, cin, cout))
         for v in variants:
             os.environ['Y2_WF_VARIANT'] = str(v if v != 100 else 3)
-            p.algo = 3 if v == 100 else 2
+            p.algo = 3 if v == 100 else (1 if v == 200 else (0 if v == 300 else 2))      # 200: three-kernel Winograd (64x128 GEMM tiles), 300: direct
+            p.tile = 5 if v == 200 else 0
+            p.w = wp.data_ptr() if v == 300 else u.data_ptr()
             y.fill_(float('nan'))
             if yp is not None:
                 yp.fill_(float('nan'))
