@@ -15,6 +15,7 @@
 // lane (i = l&31, k = 2s + (l>>5)) reads one dword at [k][i] — 32 consecutive banks per half-wave, conflict-free.
 // Workgroup = 4 waves (2x2), tile 128 (co) x 128 (j), wave tile 64x64 = 2x2 MFMA 32x32x2 blocks; 64 MFMAs per slab per
 // wave against 16 KB + 16 KB of DMA: the same MFMA-bound balance as the forward kernel.
+#include <stdlib.h>
 #include "common.h"
 
 #ifndef Y2_WGRAD_SPREAD
@@ -311,7 +312,13 @@ static int wgrad_splits(long long M, int ncols, int Cout, int groups, int* slabs
     const int TJ = wgrad_tj(ncols, Cout);
     const long long tiles = (long long)y2_cdiv(Cout, TI) * y2_cdiv(ncols, TJ);
     const int slabs = y2_cdiv(M, KS);
-    int splits = y2_cdiv(4 * Y2_NUM_CU, tiles * groups);
+    // workgroups per CU the split aims at = what is resident at once (2 of the 64 KB 128x128 tiles, 3 of 128x64, 4+ of the smaller
+    // ones): one full wave of workgroups.  More splits only add atomic epilogues (measured, B=64: the 1x1 layers 0.130 -> 0.120 ms and
+    // the 52x52 / 26x26 grouped reductions 0.43 -> 0.41 with 2 instead of 4 for the 128x128 tile; the 64x64-tile 208x208 layer
+    // 1.02 -> 1.50 the other way)
+    static const int fill_env = getenv("Y2_WGRAD_FILL") != nullptr ? atoi(getenv("Y2_WGRAD_FILL")) : 0;
+    const int fill = fill_env > 0 ? fill_env : (TI * TJ >= 128 * 128 ? 2 : (TI * TJ >= 128 * 64 ? 3 : 4));
+    int splits = y2_cdiv(fill * Y2_NUM_CU, tiles * groups);
     const int max_splits = slabs / 8 > 0 ? slabs / 8 : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

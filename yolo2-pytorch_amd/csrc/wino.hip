@@ -240,6 +240,9 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 // slots (measured: 64 scalar adds per stage = +15 % kernel time), so the in-loader input transform spells them out.  a + (-b) is
 // the same IEEE operation as a - b: bit-identical to the scalar form.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 y2_pk_add2(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 y2_pk_sub2(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 y2_pk_mul2(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ f32x4 y2_pk_add(f32x4 a, f32x4 b) {
     f32x2 lo, hi;
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(__builtin_shufflevector(b, b, 0, 1)));
@@ -275,6 +278,7 @@ struct WinoFusedArgs {
     const float* x;       // VAR bit 2 of wino_fused2_kernel: the chunk's NHWC input itself (v unused)
     int ldx;
     unsigned x_bytes;
+    unsigned y_bytes, yp_bytes;      // wino_fused2_kernel stores through buffer descriptors (< 2^31 bytes each, host check)
 };
 
 // PG = positions per pipeline stage (one barrier per stage: 16*PG MFMAs per wave between barriers), WF_STAGES = ring depth.
@@ -494,9 +498,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //     left for them to land before the next vmcnt(0) (one piece per slot over the whole stage measured 4-8 % slower).  The fetch
 //     stream runs ACROSS tiles: the last stage of a tile fetches the first stage of the workgroup's next tile.
 //   * fragment double buffering (VAR bit 1): the 8 ds_read_b128 of k-group q+1 are issued before the 16 MFMAs of group q.
-//   * branch-free epilogue with compile-time output set (OUT): pixels / tiles / channels that do not exist store to a dump area
-//     instead of being predicated off, the tile row -> pixel decode comes from a table wino_input_kernel writes (one entry per
-//     tile), and y / pooled output / statistics are template flags.  No control flow, ~40 instead of ~190 instructions per row.
+//   * branch-free epilogue with compile-time output set (OUT): stores go through buffer descriptors and the lanes of pixels /
+//     tiles / channels that do not exist get the out-of-range offset (dropped by the hardware) instead of being predicated off,
+//     the tile row -> pixel decode comes from a table (one entry per tile), y / pooled output / statistics are template flags.
+//     No control flow.  (Spelling the transform out as packed adds on two tile rows at a time made the epilogue LONGER: the asm
+//     operands cost more register moves than the packing saves.)  The accumulators of a tile start from the zero C operand of its first MFMAs instead of 256 v_accvgpr_write.
 //   Every MFMA "slot" ends with a scheduling barrier so that the compiler keeps the hand-placed DMA interleave.
 // Measured B=32 (kernel alone, first generation -> this): 104x104 Cin 64 0.319 -> 0.243 ms, 52x52 Cin 128 0.272 -> 0.211,
 // 26x26 Cin 256 0.250 -> 0.196, 26x26 Cin 512 0.457 -> 0.371, 13x13 Cin 512 0.310 -> 0.251 (93 / 108 / 116 / 122 / 105 TF/s).
@@ -600,7 +606,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // RAWIN: one pixel chunk (4 channels) of input row `row` / column `col` of the 4x4 patch of the thread's tile i, K slab `kslab`
     auto raw_px = [&](int i, int row, int col, int kslab) -> f32x4 {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(rowoff[i][row] + coloff[i][col]), kslab * 128, 0));
+        // the sum is formed here, at the load (volatile: left to itself the compiler hoists all 32 row + column sums of a tile into
+        // registers of their own, which is what tips the kernel into spilling inside the K loop)
+        unsigned voff;
+        asm volatile("v_add_u32 %0, %1, %2" : "=v"(voff) : "v"(rowoff[i][row]), "v"(coloff[i][col]));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff, kslab * 128, 0));
     };
     // RAWIN: positions 4*g .. 4*g+3 are row g of B^T d B: s = d0 - d2 | d1 + d2 | d2 - d1 | d1 - d3 per column (g = 0..3), then the
     // same column combination as wino_input_kernel (same operations in the same order: bit-identical V).  Patch rows 1 and 2 feed
@@ -613,10 +623,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- one pipeline stage: consume ring slot SLOT into the 4 accumulators c[0..3];  FETCH: also fetch stage (fk, FG) into the
     //      other slot: 16 DMA pieces, or (RAWIN) 8 filter DMA pieces + the thread's 2 x 8 input pixels, transformed in registers
-    auto stage = [&](auto SLOT, f32x16* c, auto FETCH, int fk, auto FG) {
+    auto stage = [&](auto SLOT, f32x16* c, auto FETCH, int fk, auto FG, auto ZC) {      // ZC: the accumulators START here (first K slab of a tile)
         constexpr int slot = decltype(SLOT)::value;
         constexpr bool fetch = decltype(FETCH)::value;
         constexpr int fg = decltype(FG)::value;
+        constexpr bool zc = decltype(ZC)::value;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float* sbuf = smem + slot * STAGE_FLOATS;
         float* const wbuf = smem + (slot ^ 1) * STAGE_FLOATS + t * 4;      // RAWIN: where this thread's V chunks go (position 0, tile 0)
         f32x4 av[2][PG], bv[2][PG];
@@ -642,7 +654,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const int sl = q * 4 + e;                 // MFMA slot 0..15 of the stage
 #pragma unroll
                 for (int pp = 0; pp < PG; ++pp) {
-                    c[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][pp][e], bv[cb][pp][e], c[pp], 0, 0, 0);
+                    // the first MFMA of a tile's chain takes the inline constant 0 as its C operand: no 256 v_accvgpr_write per tile
+                    c[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][pp][e], bv[cb][pp][e], (zc && sl == 0) ? zero16 : c[pp], 0, 0, 0);
                     if (!RAWIN) {
                         // two DMA pieces per slot in the first 8 slots, behind MFMAs 0 and 2 of the slot
                         if (SPREAD && fetch && sl < 8 && (pp == 0 || pp == 2)) dma_piece(fk, fg, slot ^ 1, 2 * sl + (pp >> 1));
@@ -674,9 +687,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     using G1 = std::integral_constant<int, 1>;
     using G2 = std::integral_constant<int, 2>;
     using G3 = std::integral_constant<int, 3>;
+    using Z0 = std::false_type;
+#if defined(Y2_EXP) && (Y2_EXP & 1)
+    using Z1 = std::integral_constant<bool, !RAWIN>;
+#else
+    using Z1 = std::true_type;
+#endif
 
-    float* const dump = a.dump + t;
-    const size_t row_stride = (size_t)a.W * a.ldy;
+    // output stores go through buffer descriptors: a lane whose pixel / tile / channel does not exist gets the out-of-range offset
+    // and the hardware drops its store (no branch, no 64-bit address arithmetic); the 2x2 pixels of a tile differ in the scalar offset
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, HAS_Y ? a.y_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ryp = __builtin_amdgcn_make_buffer_rsrc(a.y_pool, 0, HAS_POOL ? a.yp_bytes : 0, 0x00020000);
+    const int so_x = a.ldy * 4, so_y = a.W * a.ldy * 4;
     const int nks = a.Cin / 32;                  // host guarantees nks >= 2: every tile runs 4 * nks stages, an even number, so a
     // prologue: the first stage of the first tile     // tile always starts in ring slot 0 and stage g of a K slab sits in slot g & 1
     if (!RAWIN) {
@@ -713,32 +735,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
     for (;;) {
         const int em0 = fm0, en0 = fn0;           // this tile's origin (the fetch cursor is still on this tile)
+        if (!Z1::value) {
 #pragma unroll
-        for (int p = 0; p < 16; ++p)
+            for (int p = 0; p < 16; ++p)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+        }
 #define Y2_WF2_SYNC()                                              \
         if (RAWIN) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   /* + this wave's ds_write of V */ \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
         __builtin_amdgcn_s_barrier();                              \
         Y2_STAMP()
-        for (int ks = 0; ks < nks - 1; ++ks) {
+        // first K slab (nks >= 2: never the last one): the four accumulator groups start from the MFMA's zero operand
+        Y2_WF2_SYNC();
+        stage(S0{}, &acc[0], T_{}, 0, G1{}, Z1{});
+        Y2_WF2_SYNC();
+        stage(S1{}, &acc[4], T_{}, 0, G2{}, Z1{});
+        Y2_WF2_SYNC();
+        stage(S0{}, &acc[8], T_{}, 0, G3{}, Z1{});
+        Y2_WF2_SYNC();
+        stage(S1{}, &acc[12], T_{}, 1, G0{}, Z1{});
+        for (int ks = 1; ks < nks - 1; ++ks) {
             Y2_WF2_SYNC();
-            stage(S0{}, &acc[0], T_{}, ks, G1{});
+            stage(S0{}, &acc[0], T_{}, ks, G1{}, Z0{});
             Y2_WF2_SYNC();
-            stage(S1{}, &acc[4], T_{}, ks, G2{});
+            stage(S1{}, &acc[4], T_{}, ks, G2{}, Z0{});
             Y2_WF2_SYNC();
-            stage(S0{}, &acc[8], T_{}, ks, G3{});
+            stage(S0{}, &acc[8], T_{}, ks, G3{}, Z0{});
             Y2_WF2_SYNC();
-            stage(S1{}, &acc[12], T_{}, ks + 1, G0{});
+            stage(S1{}, &acc[12], T_{}, ks + 1, G0{}, Z0{});
         }
         // ---- last K slab; its last stage fetches the first stage of the workgroup's next tile
         Y2_WF2_SYNC();
-        stage(S0{}, &acc[0], T_{}, nks - 1, G1{});
+        stage(S0{}, &acc[0], T_{}, nks - 1, G1{}, Z0{});
         Y2_WF2_SYNC();
-        stage(S1{}, &acc[4], T_{}, nks - 1, G2{});
+        stage(S1{}, &acc[4], T_{}, nks - 1, G2{}, Z0{});
         Y2_WF2_SYNC();
-        stage(S0{}, &acc[8], T_{}, nks - 1, G3{});
+        stage(S0{}, &acc[8], T_{}, nks - 1, G3{}, Z0{});
         tile += wgs_per_xcd;
         const bool more = tile < xcd_end;
         Y2_WF2_SYNC();
@@ -753,9 +786,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         if (more) {
             place(tile);
-            stage(S1{}, &acc[12], T_{}, 0, G0{});
+            stage(S1{}, &acc[12], T_{}, 0, G0{}, Z0{});
         } else {
-            stage(S1{}, &acc[12], F_{}, 0, G0{});
+            stage(S1{}, &acc[12], F_{}, 0, G0{}, Z0{});
         }
 #undef Y2_WF2_SYNC
         Y2_STAMP();
@@ -766,6 +799,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float psc = (a.scale != nullptr && nok) ? a.scale[pn] : 1.f;
         const float psh = (a.shift != nullptr && nok) ? a.shift[pn] : 0.f;
         float s1 = 0.f, s2 = 0.f;
+        const unsigned chan_off = (unsigned)(a.coff + pn) * 4u, pool_off = (unsigned)(a.poff + pn) * 4u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float sm[2][4];
@@ -783,7 +817,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int e = prow[r];
             const bool ok = e != -1 && nok;                   // (a real entry is never -1: bits 30 and 31 set would need a pixel index of 2^30 - 1)
             const bool y1 = ok && (e & 0x40000000) != 0, x1 = ok && e < 0;
-            float* const dst = HAS_Y ? a.y + (size_t)((unsigned)e & 0x3fffffffu) * a.ldy + a.coff + pn : nullptr;
+            const unsigned voff = ((unsigned)e & 0x3fffffffu) * (unsigned)so_x + chan_off;
             float v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -791,15 +825,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (HAS_STATS) { const float m = valid ? o[k] : 0.f; s1 += m; s2 += m * m; }
                 const float uu = o[k] * psc + psh;
                 v[k] = uu > 0.f ? uu : uu * a.slope;
-                if (HAS_Y) {
-                    float* p = dst + ((k & 1) ? a.ldy : 0) + ((k >> 1) ? row_stride : 0);
-                    *(valid ? p : dump) = v[k];
-                }
+                if (HAS_Y) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k]), ry, (int)(valid ? voff : OOB), ((k & 1) ? so_x : 0) + ((k >> 1) ? so_y : 0), 0);
             }
             if (HAS_POOL) {                                   // H, W even (host check): the pooled pixel index IS the tile index
                 const int tt = em0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float* p = a.y_pool + (size_t)tt * a.ldp + a.poff + pn;
-                *(ok ? p : dump) = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mx), ryp, (int)(ok ? (unsigned)tt * (unsigned)(a.ldp * 4) + pool_off : OOB), 0, 0);
             }
         }
         if (HAS_STATS) {
@@ -990,6 +1021,8 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
 
         if (fused) {
             WinoFusedArgs fa;
+            fa.y_bytes = (unsigned)((size_t)nb * p->H * p->W * (p->y != nullptr ? p->ldy : 0) * sizeof(float));
+            fa.yp_bytes = (unsigned)((size_t)nb * th * tw * (p->y_pool != nullptr ? p->ldp : 0) * sizeof(float));
             fa.x = ia.x; fa.ldx = p->ldx; fa.x_bytes = (unsigned)((size_t)nb * p->H * p->W * p->ldx * sizeof(float));
             fa.v = V; fa.u = p->w; fa.tile_pix = ia.tile_pix; fa.dump = M + (mbytes - WF_DUMP_BYTES) / sizeof(float); fa.scale = p->scale; fa.shift = p->shift; fa.stats = p->stats;
             fa.y = p->y != nullptr ? p->y + in_off * p->ldy : nullptr;
@@ -1027,10 +1060,10 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
             } while (0)
             const int out_mask = (p->y != nullptr ? 1 : 0) | (p->y_pool != nullptr ? 2 : 0) | (p->stats != nullptr ? 4 : 0);
             // second-generation instruction stream (see wino_fused2_kernel); Y2_WF_VARIANT = -1 selects the first generation, 0 / 1 / 3 a
-            // feature mask (A/B runs).  Its 32-bit output offsets need the output tensors below 2^31 elements.
+            // feature mask (A/B runs).  Its buffer-descriptor stores need the output tensors below 2^31 bytes.
             const char* ve = getenv("Y2_WF_VARIANT");           // read per call (experiments / tests switch it at run time)
             const int variant = ve != nullptr ? atoi(ve) : WF2_DEFAULT_VARIANT;
-            const bool small_out = (unsigned long long)p->B * p->H * p->W * (unsigned long long)(p->ldy > p->ldp ? p->ldy : p->ldp) < 0x7fffffffull;
+            const bool small_out = (unsigned long long)p->B * p->H * p->W * (unsigned long long)(p->ldy > p->ldp ? p->ldy : p->ldp) * 4ull < 0x80000000ull;      // bytes: 2^31 is the dropped-store offset
             if (implicit) {
                 if (!small_out) return Y2_ENOSUP;
                 Y2_WF2_LAUNCH(5);           // no fragment double buffering: its 32 registers hold patch rows (with it: spills, 3-7 % slower)
