@@ -79,7 +79,7 @@ def main():
             if args.stamps:
                 T = B * ((H + 1) // 2) ** 2
                 a256 = lambda n: (n + 255) // 256 * 256
-                off = (0 if v == 100 else a256(16 * T * cin * 4)) + a256(T * 4) + 1024
+                off = (0 if v == 100 else a256(16 * T * cin * 4)) + a256((T + 63) * 4) + 1024
                 raw = ws.view(torch.uint8)[off:off + 8000].cpu().numpy().view('uint64')
                 d = [int(raw[i + 1]) - int(raw[i]) if raw[i + 1] and raw[i] else 0 for i in range(0, 160)]
                 nst = 4 * (cin // 32)

@@ -777,13 +777,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         Y2_WF2_SYNC();
         // decode-table entries of this tile's 16 rows (two distinct addresses per wave: broadcast loads), in flight during the last
         // stage (issued in front of the barrier above, their latency - ~2k cycles per tile - was exposed)
-        int prow[16];
+        int prow[16];                              // (the table is padded to whole 64-tile blocks: one base address, immediate offsets)
+        const int32_t* const pbase = a.tile_pix + (em0 + wm * 32 + 4 * half);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tt = em0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int e = a.tile_pix[min(tt, a.T - 1)];
-            prow[r] = tt < a.T ? e : -1;
-        }
+        for (int r = 0; r < 16; ++r) prow[r] = pbase[(r & 3) + 8 * (r >> 2)];
         if (more) {
             place(tile);
             stage(S1{}, &acc[12], T_{}, 0, G0{}, Z0{});
@@ -815,7 +812,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 o[2 * i + 1] = sm[i][1] - sm[i][2] - sm[i][3];
             }
             const int e = prow[r];
-            const bool ok = e != -1 && nok;                   // (a real entry is never -1: bits 30 and 31 set would need a pixel index of 2^30 - 1)
+            const bool ok = nok && em0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < a.T;
             const bool y1 = ok && (e & 0x40000000) != 0, x1 = ok && e < 0;
             const unsigned voff = ((unsigned)e & 0x3fffffffu) * (unsigned)so_x + chan_off;
             float v[4];
@@ -982,7 +979,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     const long long T = (long long)cb * th * tw;    // tiles of a full chunk
     if (T * (p->Cin / 4) >= 0xffffffffLL || T * (p->Cout / 4) >= 0xffffffffLL || T > 0x7fffffff) return Y2_ENOSUP;
     const size_t vbytes = implicit ? 0 : align256((size_t)16 * T * p->Cin * sizeof(float));
-    const size_t mbytes = fused ? align256((size_t)T * sizeof(int32_t)) + WF_DUMP_BYTES : align256((size_t)16 * T * p->Cout * sizeof(float));   // fused: tile decode table + 1 KB dump area
+    const size_t mbytes = fused ? align256((size_t)(T + 63) * sizeof(int32_t)) + WF_DUMP_BYTES : align256((size_t)16 * T * p->Cout * sizeof(float));   // fused: tile decode table + 1 KB dump area
     if (fused && (vbytes >= 0x7fffffffull || (size_t)16 * p->Cout * p->Cin * 4 >= 0x7fffffffull)) return Y2_ENOSUP;
 
     // stage 2 as a grouped 1x1 "convolution" over an image of 1 x T pixels
