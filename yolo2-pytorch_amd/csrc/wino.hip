@@ -777,6 +777,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         Y2_WF2_SYNC();
         // decode-table entries of this tile's 16 rows (two distinct addresses per wave: broadcast loads), in flight during the last
         // stage (issued in front of the barrier above, their latency - ~2k cycles per tile - was exposed)
+        // ... and the channel's affine parameters: loaded here, right behind the barrier's vmcnt(0) - at the top of the epilogue the
+        // compiler guarded them with a vmcnt(0) of its own, which waited for the next tile's first fetch (~1.7k cycles per tile)
+        const int pn = en0 + wn * 32 + l31;
+        const bool nok = pn < a.Cout;
+        const float psc = (a.scale != nullptr && nok) ? a.scale[pn] : 1.f;
+        const float psh = (a.shift != nullptr && nok) ? a.shift[pn] : 0.f;
         int prow[16];                              // (the table is padded to whole 64-tile blocks: one base address, immediate offsets)
         const int32_t* const pbase = a.tile_pix + (em0 + wm * 32 + 4 * half);
 #pragma unroll
@@ -791,10 +797,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         Y2_STAMP();
         // ---- epilogue: output transform A^T M A in registers (accumulator register r of the 16 positions belongs to the same
         //      (tile row, channel)), then affine + LeakyReLU, pooling, statistics, stores - branch-free
-        const int pn = en0 + wn * 32 + l31;
-        const bool nok = pn < a.Cout;
-        const float psc = (a.scale != nullptr && nok) ? a.scale[pn] : 1.f;
-        const float psh = (a.shift != nullptr && nok) ? a.shift[pn] : 0.f;
         float s1 = 0.f, s2 = 0.f;
         const unsigned chan_off = (unsigned)(a.coff + pn) * 4u, pool_off = (unsigned)(a.poff + pn) * 4u;
 #pragma unroll
