@@ -121,7 +121,7 @@ typedef struct y2_conv_params {
 #define Y2_ALGO_WINOGRAD 1
 #define Y2_ALGO_WINOGRAD_FUSED 2   /* same transforms, but GEMM + output transform in ONE kernel (no product tensor in memory); Cin % 32 == 0 */
 #define Y2_ALGO_WINOGRAD_IMPLICIT 3 /* as FUSED, and the input transform B^T d B happens in that kernel's operand loader: the transformed input
-                                      (4x the input) never goes to memory either.  Cin % 32 == 0, Cin >= 64, a batch chunk's input < 1 GB.
+                                      (4x the input) never goes to memory either.  Cin % 32 == 0, a batch chunk's input < 1 GB.
                                       Bit-identical results to FUSED.  (Leaves no transformed input behind for y2_wino_wgrad.) */
 
 /* Winograd F(2x2,3x3) filter transform U[p][co][ci] = (G g G^T)[p], p = 4*xi + nu, from a packed 3x3 weight

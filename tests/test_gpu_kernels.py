@@ -145,8 +145,6 @@ def test_conv_fwd_winograd_matches_fp64_reference(B, cin, cout, H, W, tile, pool
     few ulps: tolerance 4x the direct kernel's (still ~1e-5 of the output rms against the fp64 truth)."""
     if algo >= 2 and cin % 32:
         pytest.skip('the fused kernel needs Cin % 32 == 0 (the library answers Y2_ENOSUP; autotune then keeps algo 1)')
-    if algo == 3 and cin < 64:
-        pytest.skip('the implicit-transform kernel needs Cin >= 64 (two K slabs)')
     g = torch.Generator().manual_seed(B * 1000 + cin + cout + H)
     x = torch.randn(B, cin, H, W, generator=g)
     w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
@@ -175,6 +173,8 @@ def test_conv_fwd_winograd_matches_fp64_reference(B, cin, cout, H, W, tile, pool
     (40, 64, 128, 40, 36, 0, False),      # 14400 tiles x 2 channel tiles on 256 persistent workgroups: the cross-tile fetch stream
     (1, 256, 64, 1, 1, 0, False),         # a single 1x1 image: every patch row / column but one is padding
     (2, 64, 64, 2, 7, 0, False),
+    (3, 32, 64, 30, 26, 0, True),         # Cin = 32: a tile is a single K slab (the 208x208 layer of Darknet-19), pooled output
+    (2, 32, 40, 13, 9, 32, False),        # ... ragged map, channel window, Cout not a multiple of 64
 ])
 def test_conv_fwd_implicit_is_bit_identical_to_fused(B, cin, cout, H, W, pad_ch, pool):
     """Y2_ALGO_WINOGRAD_IMPLICIT runs the same GEMM and the same output transform as Y2_ALGO_WINOGRAD_FUSED; what changes is where

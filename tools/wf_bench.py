@@ -17,7 +17,7 @@ import torch  # noqa: E402
 
 import _hip  # noqa: E402
 
-SHAPES = [(104, 64, 128), (52, 128, 256), (26, 256, 512), (26, 512, 512), (13, 512, 1024),       # (H = W, Cin, Cout): fprop ...
+SHAPES = [(208, 32, 64), (104, 64, 128), (52, 128, 256), (26, 256, 512), (26, 512, 512), (13, 512, 1024),       # (H = W, Cin, Cout): fprop ...
           (104, 128, 64), (52, 256, 128), (26, 512, 256), (208, 64, 32)]                          # ... and data-gradient shapes
 
 

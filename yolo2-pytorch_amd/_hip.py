@@ -262,7 +262,7 @@ FORCE_ALGO = os.environ.get('Y2_FORCE_ALGO') or None     # 'direct' | 'winograd'
 if FORCE_ALGO not in (None, 'direct', 'winograd', 'fused', 'implicit'):
     raise ValueError('Y2_FORCE_ALGO must be direct, winograd, fused or implicit (got %r)' % FORCE_ALGO)
 IMPLICIT = os.environ.get('Y2_WINO_IMPLICIT', '1') != '0'  # 0: never offer Y2_ALGO_WINOGRAD_IMPLICIT (A/B runs)
-WINO_MIN_CIN = 64                                        # below this the transforms cost more than the GEMM saves (measured)
+WINO_MIN_CIN = 32                                        # below this the transforms cost more than the GEMM saves (measured; 32: the 208x208 layer, one K slab per tile of the fused kernels)
 
 
 def wino_eligible(cout, cin, k, stride=1):
@@ -303,7 +303,7 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True):
     key = (params.B, params.H, params.W, params.Cin, params.ldx, params.Cout, params.ksize, bool(params.y), bool(params.y_pool),
            bool(params.stats), params.out_mode, params.stride, params.pad_plus1, bool(params.residual), params.transposed, params.out_h, params.out_w, str(dev),
            bool(wino_ok), bool(implicit_ok and IMPLICIT))
-    implicit_ok = bool(implicit_ok and IMPLICIT) and params.Cin % 32 == 0 and params.Cin >= 64
+    implicit_ok = bool(implicit_ok and IMPLICIT) and params.Cin % 32 == 0
     w_direct = params.w
 
     def apply(choice):

@@ -531,6 +531,7 @@ template <int VAR, int OUT>     // OUT: bit 0 = full-resolution output y, bit 1 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fused2_kernel(const WinoFusedArgs a) {
     constexpr bool HAS_Y = (OUT & 1) != 0, HAS_POOL = (OUT & 2) != 0, HAS_STATS = (OUT & 4) != 0;
     constexpr bool SPREAD = (VAR & 1) != 0, DBUF = (VAR & 2) != 0, RAWIN = (VAR & 4) != 0;
+    constexpr bool ONE = (VAR & 8) != 0;         // Cin == 32: a tile is ONE K slab (4 stages); its last-slab stages start the accumulators
     constexpr unsigned OOB = 0x80000000u, OOB_COL = 0x40000000u;
     constexpr int PG = 4;
     constexpr int STAGE_FLOATS = PG * WF_POS_FLOATS;          // 64 KB
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, HAS_Y ? a.y_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t ryp = __builtin_amdgcn_make_buffer_rsrc(a.y_pool, 0, HAS_POOL ? a.yp_bytes : 0, 0x00020000);
     const int so_x = a.ldy * 4, so_y = a.W * a.ldy * 4;
-    const int nks = a.Cin / 32;                  // host guarantees nks >= 2: every tile runs 4 * nks stages, an even number, so a
+    const int nks = ONE ? 1 : a.Cin / 32;        // (host: nks >= 2 unless ONE) every tile runs 4 * nks stages, an even number, so a
     // prologue: the first stage of the first tile     // tile always starts in ring slot 0 and stage g of a K slab sits in slot g & 1
     if (!RAWIN) {
 #pragma unroll
@@ -746,7 +747,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
         __builtin_amdgcn_s_barrier();                              \
         Y2_STAMP()
-        // first K slab (nks >= 2: never the last one): the four accumulator groups start from the MFMA's zero operand
+        // first K slab (never the last one unless ONE): the four accumulator groups start from the MFMA's zero operand
+        using ZL = std::integral_constant<bool, ONE>;
+        if (!ONE) {
         Y2_WF2_SYNC();
         stage(S0{}, &acc[0], T_{}, 0, G1{}, Z1{});
         Y2_WF2_SYNC();
@@ -755,6 +758,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         stage(S0{}, &acc[8], T_{}, 0, G3{}, Z1{});
         Y2_WF2_SYNC();
         stage(S1{}, &acc[12], T_{}, 1, G0{}, Z1{});
+        }
         for (int ks = 1; ks < nks - 1; ++ks) {
             Y2_WF2_SYNC();
             stage(S0{}, &acc[0], T_{}, ks, G1{}, Z0{});
@@ -767,11 +771,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         // ---- last K slab; its last stage fetches the first stage of the workgroup's next tile
         Y2_WF2_SYNC();
-        stage(S0{}, &acc[0], T_{}, nks - 1, G1{}, Z0{});
+        stage(S0{}, &acc[0], T_{}, nks - 1, G1{}, ZL{});
         Y2_WF2_SYNC();
-        stage(S1{}, &acc[4], T_{}, nks - 1, G2{}, Z0{});
+        stage(S1{}, &acc[4], T_{}, nks - 1, G2{}, ZL{});
         Y2_WF2_SYNC();
-        stage(S0{}, &acc[8], T_{}, nks - 1, G3{}, Z0{});
+        stage(S0{}, &acc[8], T_{}, nks - 1, G3{}, ZL{});
         tile += wgs_per_xcd;
         const bool more = tile < xcd_end;
         Y2_WF2_SYNC();
@@ -789,9 +793,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int r = 0; r < 16; ++r) prow[r] = pbase[(r & 3) + 8 * (r >> 2)];
         if (more) {
             place(tile);
-            stage(S1{}, &acc[12], T_{}, 0, G0{}, Z0{});
+            stage(S1{}, &acc[12], T_{}, 0, G0{}, ZL{});
         } else {
-            stage(S1{}, &acc[12], F_{}, 0, G0{}, Z0{});
+            stage(S1{}, &acc[12], F_{}, 0, G0{}, ZL{});
         }
 #undef Y2_WF2_SYNC
         Y2_STAMP();
@@ -964,7 +968,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     const bool implicit = p->algo == Y2_ALGO_WINOGRAD_IMPLICIT;      // fused, and the input transform happens in the fused kernel's loader
     const bool fused = p->algo == Y2_ALGO_WINOGRAD_FUSED || implicit;
     if (fused && (p->Cin % 32) != 0) return Y2_ENOSUP;
-    if (implicit && p->Cin < 64) return Y2_ENOSUP;
+    if (implicit && p->Cin < 32) return Y2_ENOSUP;
     const int th = (p->H + 1) / 2, tw = (p->W + 1) / 2;
     // Batch chunks bound the workspace (V = 4x the input, M = 4x the output of a chunk); see wino_chunk_bytes().
     const size_t img_bytes = implicit ? (size_t)th * tw * sizeof(int32_t) : (size_t)16 * th * tw * ((size_t)p->Cin + (fused ? 0 : p->Cout)) * sizeof(float);
@@ -1065,7 +1069,12 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
             const bool small_out = (unsigned long long)p->B * p->H * p->W * (unsigned long long)(p->ldy > p->ldp ? p->ldy : p->ldp) * 4ull < 0x80000000ull;      // bytes: 2^31 is the dropped-store offset
             if (implicit) {
                 if (!small_out) return Y2_ENOSUP;
+                if (p->Cin == 32) { Y2_WF2_LAUNCH(13); continue; }      // a tile is one K slab
                 Y2_WF2_LAUNCH(5);           // no fragment double buffering: its 32 registers hold patch rows (with it: spills, 3-7 % slower)
+                continue;
+            }
+            if (variant >= 0 && p->Cin == 32 && small_out) {
+                Y2_WF2_LAUNCH(11);
                 continue;
             }
             if (variant >= 0 && p->Cin >= 64 && small_out) {
