@@ -337,7 +337,7 @@ def conv3x3_leg(args, ctx):
             ms += e0.elapsed_time(e1) / reps
             a = 2.0 * p.Cin * p.Cout * 9 * p.B * p.H * p.W
             alg += a
-            exe += 2.0 * p.Cin * p.Cout * 16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2) else a
+            exe += 2.0 * p.Cin * p.Cout * 16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2, 3) else a
             layers += 1
         return {'layers': layers, 'ms': round(ms, 4), 'executed_tflops': round(exe / ms / 1e9, 2), 'mfma_utilisation': round(exe / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
                 'direct_equiv_tflops': round(alg / ms / 1e9, 2), 'algorithmic_gflop': round(alg / 1e9, 1), 'executed_gflop': round(exe / 1e9, 1)}
