@@ -41,7 +41,11 @@ struct WgradArgs {
     long long gx, gz, gw;
 };
 
-template <int TI, int WAVES_I, int TJ = 128>
+// LIN: 1x1 / stride 1 / no padding (every grouped Winograd reduction and the 1x1 layers): input pixel = output pixel, so the operand
+// offsets of the next slab are the current ones + 32 rows (one v_add per DMA instruction) and the buffer's num_records supplies the
+// zeros past the last pixel.  The general form recomputes (image, y, x) -> address per piece: ~100 VALU instructions per slab next to
+// 64 MFMAs per wave (PMC: twice the VALU activity of the forward GEMM kernel at 0.69 instead of 0.81 MFMA-busy).
+template <int TI, int WAVES_I, int TJ = 128, bool LIN = false>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr unsigned OOB = 0x80000000u;
     constexpr int WAVES_J = 4 / WAVES_I;
@@ -155,7 +159,21 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     // the current slab (an LDS-DMA issue costs ~60 cycles, an fp32 32x32x2 MFMA keeps the pipe busy for 64): pieces go out in the
     // first half of the slab so that they have landed by the next vmcnt(0).
     unsigned nva[PA], nvb[PB];
+    if (LIN) {          // offsets of slab slab_lo (the first compute_slab_spread issues slab_lo + 1: plan_slab adds one step before)
+#pragma unroll
+        for (int p = 0; p < PA; ++p) nva[p] = a_ok ? (unsigned)(((size_t)(slab_lo * KS + prow_a + RA * p) * a.ldz + ca) * 4) : OOB;
+#pragma unroll
+        for (int p = 0; p < PB; ++p) nvb[p] = b_ok ? (unsigned)(((size_t)(slab_lo * KS + prow + RB * p) * a.ldx + ci) * 4) : OOB;
+    }
+    const unsigned step_a = a_ok ? (unsigned)(KS * a.ldz * 4) : 0u, step_b = b_ok ? (unsigned)(KS * a.ldx * 4) : 0u;
     auto plan_slab = [&](int slab) {
+        if (LIN) {
+#pragma unroll
+            for (int p = 0; p < PA; ++p) nva[p] += step_a;
+#pragma unroll
+            for (int p = 0; p < PB; ++p) nvb[p] += step_b;
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             const int m = slab * KS + prow_a + RA * p;
@@ -366,11 +384,16 @@ static int wgrad_impl(const float* x, const float* dz, float* dw, int B, int Hi,
     if (grid > 0x7fffffffLL) return Y2_EINVAL;
     hipStream_t s = y2_s(stream);
     const size_t lds = 2u * (size_t)(KS * TI + KS * TJ) * sizeof(float);
-#define Y2_WGRAD_LAUNCH(TI_, WI_, TJ_)                                                                                    \
+    const bool lin = ksize == 1 && stride == 1 && pad == 0;
+#define Y2_WGRAD_LAUNCH_(TI_, WI_, TJ_, LIN_)                                                                             \
     do {                                                                                                                  \
         static Y2LdsAttr attr;                                                                                            \
-        if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<TI_, WI_, TJ_>))) return rc_;     \
-        Y2_LAUNCH(a.groups > 1 ? "conv_wgrad_kernel[grouped]" : "conv_wgrad_kernel", 2.0 * (double)a.M * a.Cout * a.taps * a.Cin * (a.groups > 1 ? a.groups : 1), (conv_wgrad_kernel<TI_, WI_, TJ_>), dim3((unsigned)grid), dim3(NT), lds, s, a);                 \
+        if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<TI_, WI_, TJ_, LIN_>))) return rc_;     \
+        Y2_LAUNCH(a.groups > 1 ? "conv_wgrad_kernel[grouped]" : "conv_wgrad_kernel", 2.0 * (double)a.M * a.Cout * a.taps * a.Cin * (a.groups > 1 ? a.groups : 1), (conv_wgrad_kernel<TI_, WI_, TJ_, LIN_>), dim3((unsigned)grid), dim3(NT), lds, s, a);                 \
+    } while (0)
+#define Y2_WGRAD_LAUNCH(TI_, WI_, TJ_)                                                                                    \
+    do {                                                                                                                  \
+        if (lin) Y2_WGRAD_LAUNCH_(TI_, WI_, TJ_, true); else Y2_WGRAD_LAUNCH_(TI_, WI_, TJ_, false);                      \
     } while (0)
     if (TI == 32) Y2_WGRAD_LAUNCH(32, 1, 128);
     else if (TI == 64 && TJ == 64) Y2_WGRAD_LAUNCH(64, 2, 64);
@@ -378,6 +401,7 @@ static int wgrad_impl(const float* x, const float* dz, float* dw, int B, int Hi,
     else if (TJ == 64) Y2_WGRAD_LAUNCH(128, 2, 64);
     else Y2_WGRAD_LAUNCH(128, 2, 128);
 #undef Y2_WGRAD_LAUNCH
+#undef Y2_WGRAD_LAUNCH_
     Y2_LAUNCH_CHECK();
     if (a.partial != nullptr) {       // fixed-order sum of the K-split partials; group g's result goes to dw + g*gw
         for (int g = 0; g < groups; ++g) {
