@@ -592,7 +592,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // one of the 16 DMA instructions of stage (kslab, g) into ring slot `slot`: j = 4*pp + w, w = 0,1: A rows, 2,3: B rows
     auto dma_piece = [&](int kslab, int g, int slot, int j) {
-        const int pp = j >> 2, w = j & 3, p = g * PG + pp;
+        const int pp = j >> 2, w = j & 3;
+        int p = g * PG + pp;
+        asm volatile("" : "+s"(p));          // opaque: p * plane is formed here (one s_mul), not hoisted into 32 SGPRs that spill to VGPR lanes
         float* sa = smem + slot * STAGE_FLOATS + pp * WF_POS_FLOATS + wave * (8 * 32);
         if (w < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(sa + w * 32 * 32), 16, (int)a_off[w], (int)((unsigned)p * v_plane + (unsigned)kslab * 128u), 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(sa + 64 * 32 + (w - 2) * 32 * 32), 16, (int)b_off[w - 2], (int)((unsigned)p * u_plane + (unsigned)kslab * 128u), 0, 0);
