@@ -85,6 +85,17 @@ def worker(rank, world, port, tmp):
         ((ref(x) - y) ** 2).mean().backward()
         for (n, a), b in zip(m.named_parameters(), ref.parameters()):
             assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6), (n, step)
+    # gradient accumulation (no zero_grad between two backward passes) through both hook paths: grad = avg(step 1) + avg(step 2)
+    for p in dp.parameters():
+        p.grad = None
+    for p in ref.parameters():
+        p.grad = None
+    for rep in range(2):
+        sh = slice(rank * 4, rank * 4 + 4) if rep == 0 else slice(4 - rank * 4, 8 - rank * 4)
+        ((dp(x[sh]) - y[sh]) ** 2).mean().backward()
+        ((ref(x) - y) ** 2).mean().backward()
+    for (n, a), b in zip(m.named_parameters(), ref.parameters()):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6), ('accumulate', n)
     if rank == 0:
         open(os.path.join(tmp, 'ok'), 'w').write('ok')
     dist.barrier()

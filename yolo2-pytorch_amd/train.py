@@ -117,7 +117,12 @@ class DataParallelRCCL(nn.Module):
             self._flat.append(torch.zeros(off + len(bucket), dtype=bucket[0].dtype, device=bucket[0].device))
         self._reset()
 
+    _views = None
+    _had = frozenset()
+
     def _reset(self):
+        if self._views is None:
+            self._views = {}
         self._ready = [0] * len(self._buckets)
         self._done = set()
         self._works = [None] * len(self._buckets)
@@ -161,6 +166,8 @@ class DataParallelRCCL(nn.Module):
         if id(p) not in self._where or id(p) in self._done:
             return
         self._start()
+        if id(p) in self._had and p.grad is not None:
+            g = p.grad + g          # the caller accumulates: autograd will add g to p.grad AFTER this backward function returns; reduce kept + g
         self._fill(p, g)
 
     def _late_hook(self, p):
@@ -189,10 +196,14 @@ class DataParallelRCCL(nn.Module):
                 for k, p in enumerate(bucket):
                     _, off = self._where[id(p)]
                     avg = flat[off:off + p.numel()].view_as(p)
-                    if p.grad is not None:
-                        p.grad.copy_(avg)
-                    elif flags is not None and flags[k] > 0:      # another rank produced a gradient for it
-                        p.grad = avg.clone()
+                    # the averaged gradient IS the bucket slice (no copy back: ~70 launches and 2 x 200 MB per step).  The slice is
+                    # rewritten by the next backward's _fill; optimizer.zero_grad() has dropped this reference by then, and a caller
+                    # that keeps it (gradient accumulation) gets a private copy at the next forward()
+                    if p.grad is not None and id(p) in self._had:
+                        p.grad.copy_(avg)                 # accumulating caller: the bucket held kept + this step's gradient (see _early_hook)
+                    elif p.grad is not None or (flags is not None and flags[k] > 0):      # (second case: only another rank produced a gradient for it)
+                        p.grad = avg
+                        self._views[id(p)] = avg
         finally:
             self._pending = False
             self._reset()
@@ -201,6 +212,15 @@ class DataParallelRCCL(nn.Module):
         # a backward that raised leaves the bookkeeping half-filled: start every step from a clean slate
         self._pending = False
         self._reset()
+        # gradients the caller kept from earlier steps (accumulation: no zero_grad): a kept gradient that is a bucket slice (see
+        # _finalize) becomes a private copy before this step's _fill rewrites the bucket, and _had remembers who accumulates
+        self._had = set()
+        for q in self._params:
+            if q.grad is not None:
+                if q.grad is self._views.get(id(q)):
+                    q.grad = q.grad.clone()
+                self._had.add(id(q))
+        self._views = {}
         return self.module(*args, **kwargs)
 
 
