@@ -388,8 +388,6 @@ def train_leg(args, ctx):
     out = {'per_gpu_batch': B, 'global_batch': B * ctx.world, 'steps': steps, 'resident_batches_rotated': nbatch,
            'optimizer': 'utils.optim.SGD(lr=1e-3, momentum=0.9): fused multi-tensor HIP kernel, torch.optim.SGD semantics',
            'parallelism': 'dp%d: one process per GPU, bucketed RCCL all-reduce from inside backward + positive-count all-reduce' % ctx.world if ctx.world > 1 else 'single GPU'}
-    if ctx.world > 1:
-        out['rccl_max_nchannels'] = os.environ.get('NCCL_MAX_NCHANNELS')      # train.init_distributed caps it (Y2_RCCL_CHANNELS, default 8)
     single = None
     if ctx.world > 1:
         # the same step without the wrapper, every rank at once: per-GPU rate with zero communication (DP efficiency denominator)

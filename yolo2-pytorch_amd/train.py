@@ -229,13 +229,6 @@ def init_distributed():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # RCCL's all-reduce kernels run for the length of a bucket and hold one CU per channel; the fused Winograd kernels are
-        # persistent (one workgroup per CU, the whole register file), so every CU RCCL holds costs them a second pass over their
-        # tail.  The gradient traffic needs little bandwidth to stay hidden (202.6 MB per ~37 ms step = 10 GB/s of bus bandwidth),
-        # so the channel count is capped; Y2_RCCL_CHANNELS=0 leaves RCCL's default, NCCL_MAX_NCHANNELS set by the caller wins.
-        ch = os.environ.get('Y2_RCCL_CHANNELS', '8')
-        if ch not in ('', '0'):
-            os.environ.setdefault('NCCL_MAX_NCHANNELS', ch)
         backend = os.environ.get('Y2_DIST_BACKEND')      # tests: "gloo" with GPU tensors staged through the host (two ranks on ONE GPU)
         if torch.cuda.is_available():
             local = int(os.environ.get('LOCAL_RANK', '0'))
