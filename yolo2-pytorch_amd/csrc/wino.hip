@@ -28,12 +28,15 @@ struct WinoInArgs {
     const float* x;
     float* v;
     int32_t* tile_pix;     // optional [T]: output pixel index (b*H + 2*ty)*W + 2*tx of tile t | (2*ty+1 < H) << 30 | (2*tx+1 < W) << 31
+    int32_t* sched;        // optional [8]: per-XCD tile counters of the fused kernel that follows, set to sched_init here
+    int sched_init;
     int B, H, W, Cin, ldx, th, tw, T, c4n;
     y2_fastdiv d_c4, d_tt, d_tw;
 };
 
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoInArgs a) {
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (a.sched != nullptr && idx < (uint32_t)Y2_NUM_XCD) a.sched[idx] = a.sched_init;
     const uint32_t t = y2_div(idx, a.d_c4);
     if (t >= (uint32_t)a.T) return;
     const int c4 = (int)(idx - t * (uint32_t)a.c4n);
@@ -77,8 +80,9 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoInArgs a) {
 }
 
 // The decode table alone (Y2_ALGO_WINOGRAD_IMPLICIT has no input-transform kernel to write it).
-__global__ __launch_bounds__(256) void wino_tile_table_kernel(int32_t* tile_pix, int T, int H, int W, int th, int tw, y2_fastdiv d_tt, y2_fastdiv d_tw) {
+__global__ __launch_bounds__(256) void wino_tile_table_kernel(int32_t* tile_pix, int T, int H, int W, int th, int tw, y2_fastdiv d_tt, y2_fastdiv d_tw, int32_t* sched, int sched_init) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (sched != nullptr && t < (uint32_t)Y2_NUM_XCD) sched[t] = sched_init;
     if (t >= (uint32_t)T) return;
     const int b = (int)y2_div(t, d_tt);
     const int r = (int)t - b * th * tw;
@@ -279,6 +283,7 @@ struct WinoFusedArgs {
     int ldx;
     unsigned x_bytes;
     unsigned y_bytes, yp_bytes;      // wino_fused2_kernel stores through buffer descriptors (< 2^31 bytes each, host check)
+    int32_t* sched;                  // wino_fused2_kernel: per-XCD counters of the next unclaimed tile (set by the kernel launched in front of it)
 };
 
 // PG = positions per pipeline stage (one barrier per stage: 16*PG MFMAs per wave between barriers), WF_STAGES = ring depth.
@@ -699,6 +704,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // output stores go through buffer descriptors: a lane whose pixel / tile / channel does not exist gets the out-of-range offset
     // and the hardware drops its store (no branch, no 64-bit address arithmetic); the 2x2 pixels of a tile differ in the scalar offset
+    volatile int* const sched_lds = reinterpret_cast<volatile int*>(smem + 2 * STAGE_FLOATS + (WF_DUMP_BYTES - 1024) / sizeof(float));
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, HAS_Y ? a.y_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t ryp = __builtin_amdgcn_make_buffer_rsrc(a.y_pool, 0, HAS_POOL ? a.yp_bytes : 0, 0x00020000);
     const int so_x = a.ldy * 4, so_y = a.W * a.ldy * 4;
@@ -771,14 +777,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             Y2_WF2_SYNC();
             stage(S1{}, &acc[12], T_{}, ks + 1, G0{}, Z0{});
         }
-        // ---- last K slab; its last stage fetches the first stage of the workgroup's next tile
+        // ---- last K slab; its last stage fetches the first stage of the workgroup's next tile.  Which tile that is, is claimed
+        // from the XCD's counter (one atomic by thread 0, handed to the other waves through LDS across the stage barriers): a
+        // workgroup's FIRST tile is its static one, the rest go to whoever is running.  With a static stride a workgroup that
+        // could not start with the others (RCCL's all-reduce kernels hold CUs while the data-parallel backward runs, and this
+        // kernel needs a whole CU) kept its full share of tiles for a second pass; now it costs one tile.
+        int claimed = 0;
+        if (t == 0) claimed = atomicAdd(a.sched + xcd, 1);
         Y2_WF2_SYNC();
         stage(S0{}, &acc[0], T_{}, nks - 1, G1{}, ZL{});
         Y2_WF2_SYNC();
+        if (t == 0) *sched_lds = claimed;
         stage(S1{}, &acc[4], T_{}, nks - 1, G2{}, ZL{});
         Y2_WF2_SYNC();
         stage(S0{}, &acc[8], T_{}, nks - 1, G3{}, ZL{});
-        tile += wgs_per_xcd;
+        tile = xcd * per_xcd + __builtin_amdgcn_readfirstlane(*sched_lds);
         const bool more = tile < xcd_end;
         Y2_WF2_SYNC();
         // decode-table entries of this tile's 16 rows (two distinct addresses per wave: broadcast loads), in flight during the last
@@ -987,7 +1000,8 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     const long long T = (long long)cb * th * tw;    // tiles of a full chunk
     if (T * (p->Cin / 4) >= 0xffffffffLL || T * (p->Cout / 4) >= 0xffffffffLL || T > 0x7fffffff) return Y2_ENOSUP;
     const size_t vbytes = implicit ? 0 : align256((size_t)16 * T * p->Cin * sizeof(float));
-    const size_t mbytes = fused ? align256((size_t)(T + 63) * sizeof(int32_t)) + WF_DUMP_BYTES : align256((size_t)16 * T * p->Cout * sizeof(float));   // fused: tile decode table + 1 KB dump area
+    const size_t mbytes = fused ? align256((size_t)(T + 63) * sizeof(int32_t)) + WF_DUMP_BYTES + 256 :      // ... + the 8 tile counters
+                                 align256((size_t)16 * T * p->Cout * sizeof(float));   // fused: tile decode table + 1 KB dump area
     if (fused && (vbytes >= 0x7fffffffull || (size_t)16 * p->Cout * p->Cin * 4 >= 0x7fffffffull)) return Y2_ENOSUP;
 
     // stage 2 as a grouped 1x1 "convolution" over an image of 1 x T pixels
@@ -1021,7 +1035,13 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
         ia.T = (int)Tc; ia.c4n = p->Cin / 4;
         ia.d_c4 = y2_make_fastdiv((uint32_t)ia.c4n); ia.d_tt = d_tt; ia.d_tw = d_tw;
         ia.tile_pix = fused ? reinterpret_cast<int32_t*>(M) : nullptr;      // the fused path has no product tensor: the table sits behind V
-        if (implicit) Y2_LAUNCH("wino_tile_table_kernel", 0.0, wino_tile_table_kernel, dim3((unsigned)y2_cdiv(Tc, 256)), dim3(256), 0, s, ia.tile_pix, ia.T, ia.H, ia.W, th, tw, d_tt, d_tw);
+        // persistent fused kernel: one workgroup per CU; the kernel launched in front of it also sets the per-XCD tile counters to
+        // "every workgroup has taken its first tile"
+        const long long fused_tiles = (long long)y2_cdiv(Tc, 64) * y2_cdiv(p->Cout, 64);
+        const long long fused_grid = fused_tiles < Y2_NUM_CU ? ((fused_tiles + Y2_NUM_XCD - 1) / Y2_NUM_XCD) * Y2_NUM_XCD : Y2_NUM_CU;
+        ia.sched = fused ? reinterpret_cast<int32_t*>(M + (mbytes - 256) / sizeof(float)) : nullptr;
+        ia.sched_init = (int)(fused_grid / Y2_NUM_XCD);
+        if (implicit) Y2_LAUNCH("wino_tile_table_kernel", 0.0, wino_tile_table_kernel, dim3((unsigned)y2_cdiv(Tc, 256)), dim3(256), 0, s, ia.tile_pix, ia.T, ia.H, ia.W, th, tw, d_tt, d_tw, ia.sched, ia.sched_init);
         else Y2_LAUNCH("wino_input_kernel", 0.0, wino_input_kernel, dim3((unsigned)y2_cdiv(Tc * ia.c4n, 256)), dim3(256), 0, s, ia);
 
         if (fused) {
@@ -1029,7 +1049,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
             fa.y_bytes = (unsigned)((size_t)nb * p->H * p->W * (p->y != nullptr ? p->ldy : 0) * sizeof(float));
             fa.yp_bytes = (unsigned)((size_t)nb * th * tw * (p->y_pool != nullptr ? p->ldp : 0) * sizeof(float));
             fa.x = ia.x; fa.ldx = p->ldx; fa.x_bytes = (unsigned)((size_t)nb * p->H * p->W * p->ldx * sizeof(float));
-            fa.v = V; fa.u = p->w; fa.tile_pix = ia.tile_pix; fa.dump = M + (mbytes - WF_DUMP_BYTES) / sizeof(float); fa.scale = p->scale; fa.shift = p->shift; fa.stats = p->stats;
+            fa.v = V; fa.u = p->w; fa.tile_pix = ia.tile_pix; fa.dump = M + (mbytes - 256 - WF_DUMP_BYTES) / sizeof(float); fa.sched = ia.sched; fa.scale = p->scale; fa.shift = p->shift; fa.stats = p->stats;
             fa.y = p->y != nullptr ? p->y + in_off * p->ldy : nullptr;
             fa.y_pool = p->y_pool != nullptr ? p->y_pool + (size_t)b0 * th * tw * p->ldp : nullptr;
             fa.H = p->H; fa.W = p->W; fa.Cin = p->Cin; fa.Cout = p->Cout; fa.ldy = p->ldy; fa.coff = p->coff; fa.ldp = p->ldp; fa.poff = p->poff;
@@ -1038,7 +1058,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
             fa.slope = p->slope; fa.d_tt = d_tt; fa.d_tw = d_tw;
             const long long ntiles = (long long)fa.tiles_m * fa.tiles_n;
             if (ntiles > 0x7fffffffLL) return Y2_EINVAL;
-            const long long grid = ntiles < Y2_NUM_CU ? ((ntiles + Y2_NUM_XCD - 1) / Y2_NUM_XCD) * Y2_NUM_XCD : Y2_NUM_CU;   // persistent: one per CU
+            const long long grid = fused_grid;
 #define Y2_WF_LAUNCH(PG_, NST_)                                                                                                    \
             do {                                                                                                                   \
                 auto kern = wino_fused_kernel<PG_, NST_>;                                                                          \
@@ -1050,7 +1070,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
 #define Y2_WF2_LAUNCH_(VAR_, OUT_)                                                                                                 \
             do {                                                                                                                   \
                 auto kern = wino_fused2_kernel<VAR_, OUT_>;                                                                        \
-                const size_t lds = (size_t)2 * 4 * WF_POS_FLOATS * sizeof(float) + (WF_DUMP_BYTES - 1024);                         \
+                const size_t lds = (size_t)2 * 4 * WF_POS_FLOATS * sizeof(float) + (WF_DUMP_BYTES - 1024) + 16;                    \
                 static Y2LdsAttr attr;                                                                                             \
                 if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(kern))) return rc_;                                  \
                 Y2_LAUNCH(((VAR_) & 4) ? "wino_fused2_kernel[implicit]" : "wino_fused2_kernel", 2.0 * 16.0 * (double)fa.T * fa.Cout * fa.Cin, kern, dim3((unsigned)grid), dim3(256), lds, s, fa); \
@@ -1150,7 +1170,7 @@ extern "C" int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, 
     }
 
     WinoInArgs ia;
-    ia.tile_pix = nullptr;
+    ia.tile_pix = nullptr; ia.sched = nullptr; ia.sched_init = 0;
     ia.x = x; ia.v = V; ia.B = B; ia.H = H; ia.W = W; ia.Cin = Cin; ia.ldx = ldx; ia.th = th; ia.tw = tw; ia.T = (int)T; ia.c4n = Cin / 4;
     ia.d_c4 = y2_make_fastdiv((uint32_t)ia.c4n); ia.d_tt = y2_make_fastdiv((uint32_t)(th * tw)); ia.d_tw = y2_make_fastdiv((uint32_t)tw);
     if (v_transformed == nullptr) Y2_LAUNCH("wino_input_kernel", 0.0, wino_input_kernel, dim3((unsigned)y2_cdiv(T * ia.c4n, 256)), dim3(256), 0, s, ia);
