@@ -401,9 +401,11 @@ def train_leg(args, ctx):
         del step, last, keep
         torch.cuda.empty_cache()
     step, last, keep = make(True)
-    for i in range(3):
+    for i in range(5):          # untimed: autotune, allocator, and (N > 1) the wrapper's one-time adoption of rank 0's algorithm choices at its 4th call
         step(i)
     dt, host = ctx.timed(step, steps)
+    if ctx.world > 1:
+        out['autotune_choices_synced'] = getattr(keep[1], 'tune_synced', None)
     out.update({'images_per_sec': round(B * steps * ctx.world / dt, 2), 'ms_per_step': round(dt / steps * 1e3, 3), 'host_ms_per_step': round(host / steps * 1e3, 3),
                 'loss_total': float(last['r']['loss_total'].detach())})
     if single:

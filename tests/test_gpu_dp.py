@@ -257,3 +257,4 @@ def test_bench_two_ranks_share_the_one_gpu():
     assert rec['train']['single_gpu_images_per_sec'] > 0 and 'dp2' in rec['train']['parallelism']
     assert rec['detect']['images_per_sec'] > 0 and 'replicas x2' in rec['detect']['parallelism']
     assert 'roofline' not in rec and 'cpu_baseline' not in rec          # N = 1 only
+    assert rec['train']['autotune_choices_synced'] and rec['train']['autotune_choices_synced'] > 10      # rank 1 adopted rank 0's algorithm table

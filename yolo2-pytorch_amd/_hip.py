@@ -369,6 +369,23 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True):
     return best
 
 
+def export_tune():
+    """The measured choices of this process as a picklable list of (key, choice); device names replaced by a placeholder."""
+    out = []
+    for k, v in _TUNE.items():
+        out.append((tuple('@dev' if isinstance(e, str) and e.startswith(('cuda', 'cpu')) else e for e in k), v))
+    return out
+
+
+def import_tune(items, dev):
+    """Adopt another process's choices (export_tune) for device `dev`: every rank of a data-parallel job then runs the same
+    algorithms (same rounding, no straggler that measured a worse plan).  Plans built on the old choices are invalidated."""
+    _TUNE.clear()
+    for k, v in items:
+        _TUNE[tuple(str(dev) if e == '@dev' else e for e in k)] = v
+    mutated()
+
+
 def _tune_save():
     if TUNE_CACHE:
         try:

@@ -81,6 +81,31 @@ class DataParallelRCCL(nn.Module):
         from model import train_graph
         train_graph.DP_ALL_REDUCE = self._sum_small
 
+    tune_synced = None
+    SYNC_TUNE_AT = 4        # forward call at which every rank adopts rank 0's measured algorithm choices (after 3 whole steps)
+    _calls = 0
+
+    def _sync_tune(self):
+        """Each rank times its kernels itself during the first steps; near-ties resolve differently from rank to rank, and the step
+        time of the job is the slowest rank's.  One broadcast of rank 0's table makes the plans identical."""
+        try:
+            import _hip
+            dev = next((p.device for p in self._params if p.is_cuda), None)
+            if dev is None:
+                return
+            first = dist.get_rank(self.pg) == 0
+            src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0      # (None = the default group: rank 0 is rank 0)
+            box = [_hip.export_tune() if first else None]
+            if self._staged:
+                dist.broadcast_object_list(box, src=src, group=self.pg)
+            else:
+                dist.broadcast_object_list(box, src=src, group=self.pg, device=dev)
+            if not first:
+                _hip.import_tune(box[0], dev)
+            self.tune_synced = len(box[0])
+        except Exception as e:      # never fatal: the ranks keep their own choices
+            logging.warning('autotune choices not synchronised: %s' % e)
+
     def _all_reduce(self, t):
         if t.is_cuda and self._staged:
             return _HostStagedWork(t, self.pg)
@@ -212,6 +237,9 @@ class DataParallelRCCL(nn.Module):
         # a backward that raised leaves the bookkeeping half-filled: start every step from a clean slate
         self._pending = False
         self._reset()
+        self._calls += 1
+        if self._calls == self.SYNC_TUNE_AT and self.world > 1:
+            self._sync_tune()
         # gradients the caller kept from earlier steps (accumulation: no zero_grad): a kept gradient that is a bucket slice (see
         # _finalize) becomes a private copy before this step's _fill rewrites the bucket, and _had remembers who accumulates
         self._had = set()
