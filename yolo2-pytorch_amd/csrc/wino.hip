@@ -507,31 +507,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //     tiles / channels that do not exist get the out-of-range offset (dropped by the hardware) instead of being predicated off,
 //     the tile row -> pixel decode comes from a table (one entry per tile), y / pooled output / statistics are template flags.
 //     No control flow.  (Spelling the transform out as packed adds on two tile rows at a time made the epilogue LONGER: the asm
-//     operands cost more register moves than the packing saves.)  The accumulators of a tile start from the zero C operand of its first MFMAs instead of 256 v_accvgpr_write.
+//     operands cost more register moves than the packing saves.)
+//   * the accumulators of a tile start from the zero C operand of its first MFMAs instead of 256 v_accvgpr_write.
+//   * tiles beyond a workgroup's first are claimed from a per-XCD counter (see the tile loop).
+//   * DMA plane offsets are formed at the instruction (one s_mul) - hoisted, their 32 SGPRs spilled to VGPR lanes.
 //   Every MFMA "slot" ends with a scheduling barrier so that the compiler keeps the hand-placed DMA interleave.
-// Measured B=32 (kernel alone, first generation -> this): 104x104 Cin 64 0.319 -> 0.243 ms, 52x52 Cin 128 0.272 -> 0.211,
-// 26x26 Cin 256 0.250 -> 0.196, 26x26 Cin 512 0.457 -> 0.371, 13x13 Cin 512 0.310 -> 0.251 (93 / 108 / 116 / 122 / 105 TF/s).
+// Measured B=32 (kernel alone, first generation -> this): 104x104 Cin 64 0.319 -> 0.249 ms, 52x52 Cin 128 0.270 -> 0.230,
+// 26x26 Cin 512 0.443 -> 0.397, 13x13 Cin 512 0.305 -> 0.271.
 // Negative results kept out of the code: (a) deferring the output rows into the next tile's first stages (interleaved row by row,
 // or phase by phase behind single MFMAs) was 8-25 % SLOWER than this stand-alone epilogue once it was branch-free - the extra 64
 // live VGPRs spill and the VALU/stores delay MFMA issue; (b) exchanging the MFMA operand roles (accumulator rows = channels, so
 // a lane stores 16 bytes) lost 10-30 %: 64 lanes x 16 B to 64 different cache lines per store instruction; (c) skipping the
 // filter-operand DMA altogether (a wrong-result experiment) gains only 2-6 %: the K loop is not LDS-DMA-bandwidth bound.
-//   * implicit input transform (VAR bit 2, Y2_ALGO_WINOGRAD_IMPLICIT): the input operand of a stage is not DMA'd from a transformed
-//     tensor V but built by the loader: a thread owns the same two (tile row, 4-channel chunk) items the DMA lane owned, loads
-//     their 4x4 input pixels with buffer_load_dwordx4 (zero padding = buffer out-of-range), forms row g of B^T d B for the
-//     stage's 4 positions with 16 packed adds per item and ds_writes them where the DMA would have put V.  wino_input_kernel and
-//     the 4x-input tensor V (write + read) disappear; the kernel itself runs 1-11 % slower than with DMA'd V (B=32: 0.310 vs
-//     0.280 ms on 104x104x64->128, 0.276 vs 0.275 on 104x104x128->64), the layer 6-38 % faster.  Schedule of a stage: pixel loads
-//     behind the first 8 MFMAs, filter DMA behind MFMAs 8..39, transform + store behind the last 16.
-//     What was measured on the way (B=32, kernel alone): loading rows per stage instead of keeping rows 1 / 2 in registers across
-//     the K slab: +3 %; scalar instead of packed adds: +-0; fragment double buffering (VAR bit 1) on top: +3-7 % (its 32
-//     registers spill); pixel loads a whole stage ahead (fourth row buffer, 128 registers of pixels): +8-25 % - the tile
-//     transition spills ~100 registers; dword "touch" loads one stage ahead as a cache prefetch: +1-7 % (the exposed part is
-//     bandwidth / issue, not latency: with every load redirected into one 2 KB window the kernel reaches the DMA variant's time);
-//     every row loaded as early as its register frees (rows 1, 2, 3 one or two stages ahead, same 96 registers): +4-24 % (the
-//     pixel cursor of the next tile then lives across two more stages and the tile transition spills).  Per-stage stamps
-//     (-DY2_STAMPS): a stage costs 4.45k cycles with DMA'd V, 4.55k with the transform's adds and stores but no pixel loads, 5.0k
-//     with 8 pixel loads, and the stages that wait for a new K slab's 16 loads are the slow ones.
+//
+// Implicit input transform (VAR bit 2, Y2_ALGO_WINOGRAD_IMPLICIT): the input operand of a stage is not DMA'd from a transformed
+// tensor V but built by the loader: a thread owns the same two (tile row, 4-channel chunk) items the DMA lane owned, loads their
+// 4x4 input pixels with buffer_load_dwordx4 (zero padding = buffer out-of-range), forms row g of B^T d B for the stage's 4
+// positions with 16 packed adds per item and ds_writes them where the DMA would have put V.  wino_input_kernel and the 4x-input
+// tensor V (write + read) disappear; the kernel itself runs 0-9 % slower than with DMA'd V (B=32: 0.258 vs 0.249 ms on
+// 104x104x64->128, 0.254 vs 0.256 on 104x104x128->64, 0.251 vs 0.230 on 52x52x128->256), the layer 5-40 % faster.  Schedule
+// of a stage: pixel loads behind the first 8 MFMAs, filter DMA behind MFMAs 8..39, transform + store behind the last 16.
+// What was measured on the way (B=32, kernel alone): loading rows per stage instead of keeping rows 1 / 2 in registers across
+// the K slab: +3 %; scalar instead of packed adds: +-0; fragment double buffering (VAR bit 1) on top: +3-7 % (its 32 registers
+// spill); pixel loads a whole stage ahead (fourth row buffer, 128 registers of pixels): +8-25 % - the tile transition spills
+// ~100 registers; dword "touch" loads one stage ahead as a cache prefetch: +1-7 %; pixels by LDS-DMA into a scratch area and read
+// back: -1-3 % (not worth 32 KB of LDS); every row loaded as early as its register frees: +4-24 % (tile-transition spills).
+// What DID help were registers: pixel offsets formed at the load instead of 32 hoisted sums, the decode-table loads from one
+// base address, the DMA plane offsets as s_mul - each 3-8 %.  Per-stage stamps (-DY2_STAMPS): a stage costs 4.45k cycles with
+// DMA'd V, 4.55k with the transform's adds and stores but no pixel loads, 5.0k with 8 pixel loads.
+// VAR bit 3: Cin == 32, one K slab per tile (the 208x208 layer).
 template <int VAR, int OUT>     // OUT: bit 0 = full-resolution output y, bit 1 = pooled output, bit 2 = BatchNorm statistics
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fused2_kernel(const WinoFusedArgs a) {
     constexpr bool HAS_Y = (OUT & 1) != 0, HAS_POOL = (OUT & 2) != 0, HAS_STATS = (OUT & 4) != 0;
