@@ -268,24 +268,36 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         }
     };
 
+    // One loop per case (the case is fixed for the workgroup): with the branch INSIDE the loop the accumulators of the two paths
+    // met in phi nodes and the compiler paid 64 v_accvgpr_mov per slab - one per MFMA - to bring them back to one register set
+    // (PMC: VALU activity 6.3 against the forward GEMM's 3.8 even with linear offsets).
     issue_slab(slab_lo, 0);
-    for (int ks = 0; ks < nk - 1; ++ks) {
-        if (Y2_WGRAD_SPREAD && all_ok) plan_slab(slab_lo + ks + 1);      // VALU only: overlaps the tail of the previous slab's MFMAs
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (!all_ok) {                       // ragged tile: plain fetch, MFMAs of the outside blocks skipped
+    if (!all_ok) {                           // ragged tile: plain fetch, MFMAs of the outside blocks skipped
+        for (int ks = 0; ks < nk - 1; ++ks) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             issue_slab(slab_lo + ks + 1, (ks + 1) & 1);
             compute_slab_checked(ks & 1);
-        } else if (Y2_WGRAD_SPREAD) {
-            compute_slab_spread(ks & 1, (ks + 1) & 1);
-        } else {
-            issue_slab(slab_lo + ks + 1, (ks + 1) & 1);
-            compute_slab(ks & 1);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        compute_slab_checked((nk - 1) & 1);
+    } else {
+        for (int ks = 0; ks < nk - 1; ++ks) {
+            if (Y2_WGRAD_SPREAD) plan_slab(slab_lo + ks + 1);      // VALU only: overlaps the tail of the previous slab's MFMAs
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (Y2_WGRAD_SPREAD) {
+                compute_slab_spread(ks & 1, (ks + 1) & 1);
+            } else {
+                issue_slab(slab_lo + ks + 1, (ks + 1) & 1);
+                compute_slab(ks & 1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        compute_slab((nk - 1) & 1);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (all_ok) compute_slab((nk - 1) & 1); else compute_slab_checked((nk - 1) & 1);
 
     // ---- epilogue: lane -> column j (l31), register r -> row co = (r&3) + 8*(r>>2) + 4*half
 #pragma unroll
