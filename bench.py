@@ -64,6 +64,12 @@ def parse_args():
     ap.add_argument('--no-conv3', action='store_true', help='skip the batch-64 conv3x3 leg')
     ap.add_argument('--settle', type=float, default=2.0, help='idle seconds between the inference legs and the train leg (outside timed regions)')
     ap.add_argument('--cpu-sample', type=int, default=192, help='images for the CPU baseline (0 = skip)')
+    ap.add_argument('--multiscale', action='store_true', help='only the multi-scale training leg (BASELINE configs[3]) at full length')
+    ap.add_argument('--no-multiscale', action='store_true', help='skip the multi-scale training leg')
+    ap.add_argument('--ms-classes', type=int, default=80, help='classes of the multi-scale leg (COCO-80)')
+    ap.add_argument('--ms-sizes', default='320,352,384,416,448,480,512,544,576,608', help='input sizes of the multi-scale schedule (config.ini:39-40: 320..608 step 32)')
+    ap.add_argument('--ms-maintain', type=int, default=10, help='batches per size before the next resize (config.ini [data] maintain, utils/data.py:135-141)')
+    ap.add_argument('--ms-cycles', type=int, default=1, help='timed passes over the whole size schedule')
     ap.add_argument('--dry-run', action='store_true', help='no GPU: exercise launch / rendezvous / DP wrapper / timing protocol with a stand-in CPU workload (gloo); the numbers mean nothing')
     return ap.parse_args()
 
@@ -430,6 +436,85 @@ def train_leg(args, ctx):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------- multi-scale train leg
+def multiscale_leg(args, ctx):
+    """BASELINE configs[3]: COCO-80 Darknet-19, batch 64 per GPU, the input size changes every `maintain` batches over 320..608 step 32
+    (config.ini:39-40, utils/data.py:135-141: the collate function resizes the whole batch, so every rank switches at the same step).
+    Protocol: one untimed pass over the schedule (first visit of every size: algorithm selection per new problem shape, allocator growth,
+    under N > 1 the adoption of rank 0's algorithm table per new shape) whose per-size cost is REPORTED as first_visit_ms; then the timed
+    region = `cycles` passes over the schedule (barrier + sync | sizes x maintain steps | barrier + sync, MAX over ranks); then one more
+    pass with a synchronisation after every step for the per-size table and the cost of a size switch (first step at a size minus the
+    median of the other steps at that size)."""
+    import torch
+
+    import bench_data
+    import train as y2train
+    import utils
+    sizes = [int(v) for v in args.ms_sizes.split(',') if v]
+    B, C, maintain = args.train_batch, args.ms_classes, max(2, args.ms_maintain)
+    data = {}
+    for S in sizes:
+        d = {k: v.to(ctx.dev) for k, v in bench_data.labels(B, S, C, seed=2 + ctx.rank * 16 + S).items()}
+        d['tensor'] = bench_data.images(B, S, seed=11 + ctx.rank * 16 + S).to(ctx.dev)
+        data[S] = d
+    inf, anchors = bench_data.build_model(C, ctx.dev, args.model)
+    inf.train()
+    m = y2train.ensure_model(inf) if ctx.world > 1 else inf
+    opt = utils.optim.SGD(m.parameters(), 1e-3, momentum=0.9)
+    last = {}
+
+    def step(S):
+        last['r'] = y2train.iterate(m, opt, data[S], bench_data.HPARAM, bench_data.THRESHOLD, anchors)
+
+    first_visit = {}
+    for S in sizes:                      # untimed: first visit of every size
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(max(5, maintain // 2)):
+            step(S)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step(S)
+        ctx.sync()
+        steady = (time.perf_counter() - t1) / 3
+        first_visit[S] = max(0.0, (t1 - t0) - max(5, maintain // 2) * steady)
+    schedule = [S for _ in range(max(1, args.ms_cycles)) for S in sizes for _ in range(maintain)]
+    dt, host = ctx.timed(lambda i: step(schedule[i]), len(schedule))
+    images = B * len(schedule) * ctx.world
+    # per-step table (synchronised after every step: NOT the throughput number)
+    per = {S: [] for S in sizes}
+    for S in sizes:
+        for _ in range(maintain):
+            ctx.sync()
+            t0 = time.perf_counter()
+            step(S)
+            ctx.sync()
+            per[S].append((time.perf_counter() - t0) * 1e3)
+    table, switch = [], []
+    for S in sizes:
+        rest = sorted(per[S][1:])
+        med = rest[len(rest) // 2]
+        switch.append(max(0.0, per[S][0] - med))
+        table.append({'size': S, 'ms_per_step': round(med, 3), 'images_per_sec': round(B * ctx.world / med * 1e3, 1), 'first_step_after_switch_ms': round(per[S][0], 3),
+                      'switch_cost_ms': round(max(0.0, per[S][0] - med), 3), 'first_visit_ms': round(first_visit[S] * 1e3, 1)})
+    per_img = FLOPS_TRAIN_PER_IMG * sum((S / 416.0) ** 2 for S in sizes) / len(sizes) if args.model == 'darknet' else None
+    out = {'workload': '%s YOLOv2 %d-class multi-scale train, batch-%d/GPU, sizes %s, resize every %d batches: fwd + region loss + bwd + SGD (BASELINE configs[3] per GPU)'
+                       % (args.model, C, B, '..'.join(str(v) for v in (sizes[0], sizes[-1])) + ' step %d' % (sizes[1] - sizes[0] if len(sizes) > 1 else 0), maintain),
+           'images_per_sec': round(images / dt, 2), 'steps': len(schedule), 'ms_per_step_mean': round(dt / len(schedule) * 1e3, 3), 'host_ms_per_step_mean': round(host / len(schedule) * 1e3, 3),
+           'switch_cost_ms_mean': round(sum(switch) / len(switch), 3), 'switch_cost_ms_max': round(max(switch), 3),
+           'first_visit_ms_mean': round(sum(first_visit.values()) / len(first_visit) * 1e3, 1), 'first_visit_ms_total': round(sum(first_visit.values()) * 1e3, 1),
+           'per_gpu_batch': B, 'global_batch': B * ctx.world, 'loss_total': float(last['r']['loss_total'].detach()),
+           'parallelism': 'dp%d' % ctx.world if ctx.world > 1 else 'single GPU', 'per_size': table}
+    if per_img is not None:
+        out['direct_equiv_tflops_per_gpu'] = round(per_img * B * len(schedule) / dt / 1e12, 2)
+    if ctx.world > 1:
+        out['autotune_choices_synced'] = getattr(m, 'tune_synced', None)
+    del m, inf, opt, data
+    torch.cuda.empty_cache()
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(sd, anchors, size, sample):
     """Oracle (port of the reference path) on the host cores: conv stack + decode + filter + NMS on `sample` images.  The ONLY
@@ -528,6 +613,9 @@ def main():
     assert ctx.gpu, 'bench.py needs an MI355X (use --dry-run to exercise the launch path without one)'
 
     det = roof = state = anchors = None
+    if args.multiscale:
+        args.no_detect = args.no_train = args.no_conv3 = True
+        args.cpu_sample = 0
     if not args.no_detect:
         det, roof, state, anchors = detect_leg(args, ctx)
     conv3 = None
@@ -550,33 +638,89 @@ def main():
             import traceback
             traceback.print_exc()
             tr = {'error': '%s: %s' % (type(e).__name__, e)}
+    ms = None
+    if args.multiscale or (not args.no_multiscale and not args.no_train and args.model == 'darknet'):
+        ctx.sync()
+        time.sleep(args.settle)
+        try:
+            ms = multiscale_leg(args, ctx)
+        except Exception as e:
+            if args.multiscale:
+                raise
+            import traceback
+            traceback.print_exc()
+            ms = {'error': '%s: %s' % (type(e).__name__, e)}
     if ctx.rank == 0:
         ref = {'darknet': (' (BASELINE configs[1])', ' (BASELINE configs[2])')}.get(args.model, (' (plugin swap: forward of BASELINE configs[4])', ' (plugin swap, BASELINE configs[4] per GPU)') if args.model.startswith('resnet') else ('', ''))
         det_workload = '%s YOLOv2 %dx%d batch-%d/GPU inference: conv stack + decode + filter + NMS%s' % (label, args.size, args.size, args.batch, ref[0])
         tr_workload = '%s YOLOv2 %d-class train %dx%d batch-%d/GPU: fwd + region loss + bwd + SGD%s' % (label, args.classes, args.size, args.size, args.train_batch, ref[1])
-        if headline == 'train':
-            value, ms, steps, workload = tr['images_per_sec'], tr['ms_per_step'], tr['steps'], tr_workload
-            metric = 'images/sec (%dx%d) train, %s YOLOv2, data parallel' % (args.size, args.size, label)
+        if args.multiscale:
+            value, msps, steps, workload = ms['images_per_sec'], ms['ms_per_step_mean'], ms['steps'], ms['workload']
+            metric = 'images/sec (320..608 multi-scale) train, %s YOLOv2 (BASELINE configs[3] per GPU)' % label
+            headline = 'multiscale'
+        elif headline == 'train':
+            value, msps, steps, workload = tr['images_per_sec'], tr['ms_per_step'], tr['steps'], tr_workload
+            metric = 'images/sec (%dx%d) train+detect, %s YOLOv2: value = data-parallel TRAIN step; detect beside it in summary' % (args.size, args.size, label)
         else:
-            value, ms, steps, workload = det['images_per_sec'], det['ms_per_step'], det['steps'], det_workload
-            metric = 'images/sec (%dx%d) detect, %s YOLOv2' % (args.size, args.size, label)
-        out = {'metric': metric, 'value': value, 'unit': 'images/sec', 'n_gpus': ctx.world, 'ranks_seen': ctx.ranks_seen, 'steps': steps, 'warmup': args.warmup,
-               'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'headline': headline,
-               'config': {'workload': workload, 'classes': args.classes, 'global_batch': (args.train_batch if headline == 'train' else args.batch) * ctx.world,
-                          'parallelism': (tr if headline == 'train' else det)['parallelism'], 'weights': 'random-init seed 0 (bench_data.randomize)'}}
+            value, msps, steps, workload = det['images_per_sec'], det['ms_per_step'], det['steps'], det_workload
+            metric = 'images/sec (%dx%d) train+detect, %s YOLOv2: value = DETECT (configs[1]); train (configs[2]) = roofline.train_images_per_sec' % (args.size, args.size, label)
+        ok = lambda d: d is not None and 'error' not in d
+        # ---- scalars the driver's record keeps (it preserves the scalar members of `roofline`, `config`, `cpu_baseline`)
+        extra = {}
+        if ok(tr):
+            extra.update(train_images_per_sec=tr['images_per_sec'], train_ms_per_step=tr['ms_per_step'], train_host_ms_per_step=tr['host_ms_per_step'])
+            r = tr.get('roofline')
+            if r:
+                extra.update(train_mfma_frac=r['all_mfma_kernels']['frac'], train_mfma_ms_per_step=r['all_mfma_kernels']['ms_per_step'],
+                             train_kernel_ms_sum_single_stream=r.get('kernel_ms_sum_single_stream'), train_dominant_kernel=r['kernel'], train_dominant_frac=r['frac'],
+                             train_dominant_avg_launch_us=r['avg_launch_us'])
+        if ok(conv3):
+            extra['conv3x3_b64_mfma_util'] = conv3['autotuned']['mfma_utilisation']
+            extra['conv3x3_b64_ms'] = conv3['autotuned']['ms']
+            if 'direct_only' in conv3:
+                extra['conv3x3_b64_direct_only_util'] = conv3['direct_only']['mfma_utilisation']
+        if ok(ms):
+            extra.update(multiscale_images_per_sec=ms['images_per_sec'], multiscale_ms_per_step_mean=ms['ms_per_step_mean'], multiscale_switch_cost_ms_mean=ms['switch_cost_ms_mean'],
+                         multiscale_switch_cost_ms_max=ms['switch_cost_ms_max'], multiscale_first_visit_ms_mean=ms['first_visit_ms_mean'])
+        if ok(det):
+            extra.update(detect_images_per_sec=det['images_per_sec'], detect_ms_per_step=det['ms_per_step'])
         if roof is not None:
-            out['roofline'] = roof
+            if 'conv_chain' in roof:
+                extra.update(conv_chain_ms_per_step=roof['conv_chain']['ms_per_step'], conv_chain_frac=roof['conv_chain']['frac'])
+            if isinstance(roof.get('direct_only'), dict) and 'frac' in roof['direct_only']:
+                extra['detect_direct_only_frac'] = roof['direct_only']['all_mfma_kernels']['frac']
+            for r in roof.get('top_kernels', []):
+                if r['frac'] is not None:       # one scalar per MFMA kernel of the detect step: frac_<kernel>
+                    extra['frac_' + r['kernel'].replace('[', '_').replace(']', '').replace('<', '_').replace('>', '').replace(',', '_')] = r['frac']
+        if roof is None and ok(tr) and tr.get('roofline'):
+            r = tr['roofline']
+            roof = {'bound': 'mfma', 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'what': r['what'], 'kernel': r['kernel'], 'achieved': r['achieved'], 'frac': r['frac'], 'traffic': None}
+        out = {'metric': metric, 'value': value, 'unit': 'images/sec', 'n_gpus': ctx.world, 'ranks_seen': ctx.ranks_seen, 'steps': steps, 'warmup': args.warmup,
+               'ms_per_step': msps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'headline': headline,
+               'config': {'workload': workload, 'classes': args.classes, 'global_batch': (args.batch if headline == 'detect' else args.train_batch) * ctx.world,
+                          'parallelism': (ms if args.multiscale else tr if headline == 'train' else det)['parallelism'], 'weights': 'random-init seed 0 (bench_data.randomize)'}}
+        # the long per-kernel tables first, the compact records the driver keeps LAST (its log keeps the tail of this line)
         if conv3 is not None:
             out['conv3x3_b64'] = conv3
         if det is not None:
             out['detect'] = dict(det, workload=det_workload)
         if tr is not None:
             out['train'] = dict(tr, workload=tr_workload)
+        if ms is not None:
+            out['multiscale'] = ms
+        if roof is not None:
+            tables = {k: roof.pop(k) for k in ('top_kernels', 'definition') if k in roof}
+            out['detect_kernel_table'] = tables
+            roof.update(extra)
+            out['roofline'] = roof
         if state is not None:
             try:
                 out['cpu_baseline'] = cpu_baseline(state, anchors, args.size, args.cpu_sample)
             except Exception as e:
                 out['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        out['summary'] = dict(extra, headline=headline, value=value, unit='images/sec', n_gpus=ctx.world,
+                              roofline_kernel=(roof or {}).get('kernel'), roofline_frac=(roof or {}).get('frac'),
+                              cpu_baseline_images_per_sec=(out.get('cpu_baseline') or {}).get('value'))
         print(json.dumps(out))
     if ctx.world > 1:
         ctx.dist.destroy_process_group()

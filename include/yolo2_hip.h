@@ -71,6 +71,26 @@ typedef struct {
 } y2_prep_item;
 int y2_prep_weights(const y2_prep_item* items, int32_t count, y2_stream_t stream);
 
+/* Many small range operations in ONE launch (table in the kernel arguments): the zero fills of a training step's accumulation
+ * buffers (autograd's zeros, train.py:350), the fp64 -> fp32 hand-out of the affine-parameter gradients, plain copies.
+ * n counts ELEMENTS of dst (fp32); src is const double* for Y2_MULTI_F64_TO_F32, const float* for Y2_MULTI_COPY, ignored for ZERO. */
+#define Y2_MULTI_ZERO 0
+#define Y2_MULTI_F64_TO_F32 1
+#define Y2_MULTI_COPY 2
+#define Y2_MULTI_MAX_ITEMS 96
+typedef struct {
+    const void* src;
+    float* dst;
+    int64_t n;
+    int32_t op, reserved;
+} y2_multi_item;
+int y2_multi(const y2_multi_item* items, int32_t count, y2_stream_t stream);
+
+/* The weighted loss sum of train.py:348-349, `sum(loss[key] * hparam[key] for key in loss)`, over the n <= 64 loss terms in
+ * device memory: out[0] = sum_k v[k]*w[k] (left to right); and its gradient out[k] = g[0]*w[k]. */
+int y2_small_dot(const float* v, const float* w, int32_t n, float* out, y2_stream_t stream);
+int y2_small_scale(const float* g, const float* w, int32_t n, float* out, y2_stream_t stream);
+
 /* Inverse of mode 0 for a weight GRADIENT: src[co][tap][ci] -> dst[Cout][Cin][k][k]. */
 int y2_unpack_weight_grad(const float* src, float* dst, int Cout, int Cin, int ksize, y2_stream_t stream);
 
@@ -282,10 +302,11 @@ int y2_conv0_wgrad(const float* x_nchw, const float* dz, float* dw, int B, int H
 /* Training-mode nn.BatchNorm2d(momentum 0.01, eps 1e-5) statistics (model/yolo2.py:58): stats = Y2_STATS_REPL copies of
  * [sum z | sum z^2] per channel (fp64, accumulated by y2_conv_fwd / y2_conv0_fwd), count = B*H*W.  Writes the affine (scale, shift) used for
  * normalisation (biased variance), saves mean / invstd for backward and updates the running statistics in place
- * (unbiased variance) when running_mean != NULL. */
+ * (unbiased variance) when running_mean != NULL; num_batches_tracked (int64 scalar in device memory, may be NULL) is the module's
+ * step counter, incremented by one (torch/nn/modules/batchnorm.py, as called at model/yolo2.py:58). */
 int y2_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps,
-                   float* scale, float* shift, float* mean, float* invstd, int C, y2_stream_t stream);
+                   float* scale, float* shift, float* mean, float* invstd, int C, long long* num_batches_tracked, y2_stream_t stream);
 
 /* y = LeakyReLU(z*scale + shift) on NHWC (scale/shift NULL = identity), optionally with the following MaxPool2d(2)
  * (y_pool) and/or the reorg/concat output addressing of y2_conv_params (out_mode, ldy, coff). */
@@ -296,7 +317,8 @@ int y2_bn_act_fwd(const float* z, const float* scale, const float* shift, float 
  * fmode 1: stored reorg'ed in a [B,H/2,W/2,ldf] buffer at channel foff) and/or dy_pool (gradient of the pooled
  * activation, routed to the first maximal window element like nn.MaxPool2d) to dz (gradient of the raw conv output).
  * sums [2C] (pre-zeroed fp64) receives sum(g) = d beta (or d bias) and sum(g*zhat) = d gamma.  has_bn = 0: plain
- * bias + LeakyReLU block (dz = g). */
+ * bias + LeakyReLU block (dz = g); has_bn = 2: BatchNorm with FROZEN statistics (eval()-mode module with autograd recording,
+ * receptive_field_analyzer.py:67,87): mean / invstd are the running statistics, dz = g * gamma * invstd. */
 int y2_bn_act_bwd(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,
                   float slope, const float* dy_full, int ldf, int foff, int fmode, const float* dy_pool, int ldp, int poff,
                   double* sums, float* dz, int ldd, int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream);

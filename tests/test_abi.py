@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(built):
 
 def test_version_and_build_info(built):
     l = _hip.lib()
-    assert l.y2_abi_version() == 1
+    assert l.y2_abi_version() == 2
     assert b'gfx950' in l.y2_build_info()
 
 

@@ -31,6 +31,8 @@ class EarlyLinear(nn.Module):
         self.weight = nn.Parameter(torch.randn(o, i) * 0.3)
         self.bias = nn.Parameter(torch.zeros(o))
         self.grad_ready_hook = None
+        self.grad_buffer_hook = None       # the wrapper's offer to write gradients straight into its flat buckets
+        self.in_place = 0                  # how many gradients this module wrote into a bucket slice
 
     def forward(self, x):
         mod = self
@@ -45,6 +47,12 @@ class EarlyLinear(nn.Module):
             def backward(ctx, g):
                 x, w = ctx.saved_tensors
                 gw, gb = g.t() @ x, g.sum(0)
+                if mod.grad_buffer_hook is not None:      # the Darknet backward's protocol: ask for the destination first
+                    slot = mod.grad_buffer_hook(mod.weight)
+                    if slot is not None:
+                        assert slot.shape == gw.shape
+                        gw = slot.copy_(gw)
+                        mod.in_place += 1
                 if mod.grad_ready_hook is not None:
                     mod.grad_ready_hook(mod.bias, gb)
                     mod.grad_ready_hook(mod.weight, gw)
@@ -96,6 +104,28 @@ def worker(rank, world, port, tmp):
         ((ref(x) - y) ** 2).mean().backward()
     for (n, a), b in zip(m.named_parameters(), ref.parameters()):
         assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6), ('accumulate', n)
+    assert m[2].in_place >= 2, m[2].in_place            # the zero_grad'ed steps wrote the early layer's weight gradient in place
+    # two backward passes WITHOUT a forward in between (two outputs of one step): the first pass's averaged gradients are bucket
+    # slices; the second pass must not overwrite them in place: grad = avg(pass 1) + avg(pass 2)
+    for p in dp.parameters():
+        p.grad = None
+    for p in ref.parameters():
+        p.grad = None
+    o1 = dp(x[shard])
+    l1, l2 = ((o1 - y[shard]) ** 2).mean(), (o1 ** 2).mean()
+    l1.backward(retain_graph=True)
+    l2.backward()
+    r1 = ref(x)
+    (((r1 - y) ** 2).mean() + (r1 ** 2).mean()).backward()
+    for (n, a), b in zip(m.named_parameters(), ref.parameters()):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6), ('two backwards', n)
+    # the reducer of the region loss travels with the wrapper's outputs
+    from model import train_graph
+    out = dp(x[shard])
+    red = getattr(out, train_graph.DP_TAG)
+    cnt = torch.tensor([float(rank + 1)])
+    assert red(cnt) and cnt.item() == 3.0
+    assert getattr(m(x[shard]), train_graph.DP_TAG, None) is None       # the bare module's outputs carry none
     if rank == 0:
         open(os.path.join(tmp, 'ok'), 'w').write('ok')
     dist.barrier()

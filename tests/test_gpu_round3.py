@@ -1,0 +1,267 @@
+"""GPU tests of round 3: training at channel counts that are not multiples of 4 (pruned checkpoints, model/__init__.py:29-43),
+differentiable eval() mode (frozen BatchNorm, receptive_field_analyzer.py:67,87), several train-mode forwards before a backward,
+the launch-saving utility kernels (y2_multi, y2_small_dot / _scale, the step counter in y2_bn_finalize), the per-shape plan LRU
+of the multi-scale schedule, and the fused weighted loss total of train.py:348-349."""
+import configparser
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import darknet as odark
+from oracle import head as ohead
+from oracle import loss as oloss
+from oracle import synth
+from oracle.make_golden import NARROW
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rel(got, ref):
+    ref = ref.double()
+    rms = ref.pow(2).mean().sqrt().item()
+    return (got.double().cpu() - ref).abs().max().item() / max(rms, 1e-30)
+
+
+def build(sd, num_cls=20, bn=True):
+    import model
+    import model.yolo2
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1' if bn else '0'}})
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, num_cls)
+    dnn.load_state_dict(sd, strict=False)
+    return model.Inference(cfg, dnn, anchors).to(dev()), anchors
+
+
+def oracle_step(sd, x, data, anchors, training):
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    stats = {}
+    f = odark.forward(x.double(), sd64, training=training, stats=stats if training else None)
+    lo, _ = oloss.loss(anchors.double(), {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}, ohead.decode(f, anchors.double()), 0.6)
+    oloss.total(lo).backward()
+    return sd64, lo, stats, f
+
+
+def check_grads(inf, sd64, tol=2e-3):
+    ours = dict(inf.dnn.named_parameters())
+    worst = 0.0
+    for k, v in sd64.items():
+        if v.requires_grad:
+            assert ours[k].grad is not None, k
+            assert ours[k].grad.shape == v.grad.shape, k
+            e = rel(ours[k].grad, v.grad)
+            worst = max(worst, e)
+            assert e <= tol, (k, e)
+    return worst
+
+
+UNALIGNED = [
+    {'layers1.5': 6},                                               # the reference fixture's own width (oracle/make_golden.py: NARROW)
+    {'layers1.0': 6, 'layers1.2': 10, 'layers1.5': 6, 'layers1.16': 30},     # first layer, a pooled layer and the route layer unaligned
+    {'passthrough': 6, 'layers2.7': 62, 'layers3.0': 66},          # the concat buffer interleaves the padding of the reorg'ed copies
+]
+
+
+@pytest.mark.parametrize('widths', UNALIGNED, ids=['fixture', 'early', 'concat'])
+@pytest.mark.parametrize('bn', [True, False])
+def test_training_step_at_unaligned_channel_counts(widths, bn):
+    """"kernels must accept arbitrary channel counts" - in training too.  Every gradient (in the parameters' own
+    shapes), the loss terms and the running statistics against the oracle's fp64 autograd."""
+    import model
+    w = dict(NARROW)
+    w['layers1.5'] = 8
+    w.update(widths)
+    sd = odark.init_state_dict(5, 20, seed=0, channels=w, head_scale=1 / 8.0, bn=bn)
+    inf, anchors = build(sd, bn=bn)
+    inf.train()
+    S, B = 96, 3
+    x = synth.images(B, S, seed=1)
+    data = synth.norm_data(synth.labels(B, S, 20, seed=2), S, S, S // 32, S // 32)
+    pred = model._inference(inf, x.to(dev()))
+    loss, _ = model.loss(anchors, data, pred, 0.6)
+    model.weighted_total(loss, oloss.HPARAM).backward()
+    sd64, lo, stats, f = oracle_step(sd, x, data, anchors, True)
+    assert rel(pred['feature'], f.detach()) <= 10 * TOL
+    for k in lo:
+        np.testing.assert_allclose(loss[k].item(), lo[k].item(), rtol=1e-4)
+    check_grads(inf, sd64)
+    bufs = dict(inf.dnn.named_buffers())
+    for prefix, (rm, rv) in stats.items():
+        np.testing.assert_allclose(bufs[prefix + '.bn.running_mean'].cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(bufs[prefix + '.bn.running_var'].cpu().numpy(), rv.numpy(), rtol=1e-4)
+        assert int(bufs[prefix + '.bn.num_batches_tracked']) == 1
+
+
+@pytest.mark.parametrize('widths', [{}, {'layers1.5': 6}], ids=['aligned', 'unaligned'])
+def test_eval_mode_forward_is_differentiable_with_frozen_batchnorm(widths):
+    """nn.Module semantics the reference relies on (receptive_field_analyzer.py:67,87; frozen-BN fine-tuning): eval() mode with autograd
+    recording returns a graph; its gradients are those of the network with the RUNNING statistics, and nothing is updated."""
+    import model
+    w = dict(NARROW)
+    w['layers1.5'] = 8
+    w.update(widths)
+    sd = odark.init_state_dict(5, 20, seed=0, channels=w, head_scale=1 / 8.0)
+    inf, anchors = build(sd)
+    inf.eval()
+    S, B = 96, 2
+    x = synth.images(B, S, seed=1)
+    data = synth.norm_data(synth.labels(B, S, 20, seed=2), S, S, S // 32, S // 32)
+    before = {k: v.clone() for k, v in inf.dnn.named_buffers()}
+    pred = model._inference(inf, x.to(dev()))
+    assert pred['feature'].requires_grad
+    with torch.no_grad():
+        plain = inf.dnn(x.to(dev()))
+    assert torch.equal(plain, pred['feature'].detach())          # same inference chain, only taped
+    loss, _ = model.loss(anchors, data, pred, 0.6)
+    model.weighted_total(loss, oloss.HPARAM).backward()
+    sd64, lo, _, f = oracle_step(sd, x, data, anchors, False)
+    assert rel(pred['feature'], f.detach()) <= TOL
+    for k in lo:
+        np.testing.assert_allclose(loss[k].item(), lo[k].item(), rtol=1e-4)
+    check_grads(inf, sd64, tol=2e-4)
+    for k, v in inf.dnn.named_buffers():
+        assert torch.equal(v, before[k]), k
+    with pytest.raises(RuntimeError, match='input image'):
+        inf.dnn(x.to(dev()).requires_grad_(True))
+
+
+def test_two_training_forwards_before_one_backward():
+    """loss(model(a)) + loss(model(b)) - the second train-mode forward must not invalidate the first graph (its
+    BatchNorm buffer updates are not weight changes); a no_grad forward in train() mode in between is harmless too; an optimizer step
+    between forward and backward still raises."""
+    import model
+    import utils
+    w = dict(NARROW)
+    w['layers1.5'] = 8
+    sd = odark.init_state_dict(5, 20, seed=0, channels=w, head_scale=1 / 8.0)
+    inf, anchors = build(sd)
+    inf.train()
+    S = 96
+    xa, xb = synth.images(2, S, seed=1), synth.images(2, S, seed=5)
+    da = synth.norm_data(synth.labels(2, S, 20, seed=2), S, S, 3, 3)
+    db = synth.norm_data(synth.labels(2, S, 20, seed=6), S, S, 3, 3)
+
+    def total(x, d):
+        pred = model._inference(inf, x.to(dev()))
+        l, _ = model.loss(anchors, d, pred, 0.6)
+        return model.weighted_total(l, oloss.HPARAM)
+    ta = total(xa, da)
+    with torch.no_grad():
+        inf.dnn(xa.to(dev()))
+    tb = total(xb, db)
+    (ta + tb).backward()
+    both = {k: p.grad.clone() for k, p in inf.dnn.named_parameters()}
+    # reference: the two gradients one at a time on a fresh copy (running statistics do not enter a train-mode gradient)
+    inf2, _ = build(sd)
+    inf2.train()
+    acc = {}
+    for x, d in ((xa, da), (xb, db)):
+        for p in inf2.parameters():
+            p.grad = None
+        pred = model._inference(inf2, x.to(dev()))
+        l, _ = model.loss(anchors, d, pred, 0.6)
+        model.weighted_total(l, oloss.HPARAM).backward()
+        for k, p in inf2.dnn.named_parameters():
+            acc[k] = p.grad.clone() if k not in acc else acc[k] + p.grad
+    for k in both:
+        assert rel(both[k], acc[k].cpu()) <= 1e-4, k
+    opt = utils.optim.SGD(inf.parameters(), lr=0.01)
+    t = total(xa, da)
+    opt.step()                                           # uses the gradients above; rewrites the weights through raw pointers
+    with pytest.raises(RuntimeError, match='convolution weight was modified'):
+        t.backward()
+
+
+def test_multi_launch_and_small_kernels():
+    import _hip
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(1000, generator=g).to(d)
+    b = torch.randn(4097, generator=g).to(d)[1:]                  # 16-B alignment lost
+    c64 = torch.randn(300, generator=g, dtype=torch.float64).to(d)
+    i64 = torch.arange(10, device=d)
+    dst = torch.empty(300, device=d)
+    src = torch.randn(77, generator=g).to(d)
+    cp = torch.empty(77, device=d)
+    many = [torch.randn(5 + i, generator=g).to(d) for i in range(120)]      # more items than one table holds
+    _hip.multi([(_hip.MULTI_ZERO, a, None), (_hip.MULTI_ZERO, b, None), (_hip.MULTI_F64_TO_F32, dst, c64), (_hip.MULTI_ZERO, i64, None),
+                (_hip.MULTI_COPY, cp, src)] + [(_hip.MULTI_ZERO, t, None) for t in many])
+    assert not a.any() and not b.any() and not i64.any() and all(not t.any() for t in many)
+    assert torch.equal(dst, c64.float()) and torch.equal(cp, src)
+    L = _hip.lib()
+    v, w = torch.randn(5, generator=g).to(d), torch.tensor([5.0, 1, 1, 1, 1], device=d)
+    out = torch.empty(1, device=d)
+    _hip.check(L.y2_small_dot(_hip.ptr(v), _hip.ptr(w), 5, _hip.ptr(out), _hip.stream()), 'dot')
+    want = 0.0
+    for i in range(5):
+        want = np.float32(want + np.float32(v[i].item()) * np.float32(w[i].item()))
+    assert abs(out.item() - float(want)) <= 1e-6 * max(1.0, abs(float(want)))
+    sc = torch.empty(5, device=d)
+    _hip.check(L.y2_small_scale(_hip.ptr(out), _hip.ptr(w), 5, _hip.ptr(sc), _hip.stream()), 'scale')
+    assert torch.equal(sc, out * w)
+
+
+def test_weighted_total_equals_the_reference_expression():
+    import model
+    A, C, rows, B = 5, 20, 3, 2
+    gen = torch.Generator().manual_seed(9)
+    feat = 0.5 * torch.randn(B, A * (5 + C), rows, rows, generator=gen)
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    data = synth.norm_data(synth.labels(B, 96, C, seed=3), 96, 96, rows, rows)
+
+    class Id(torch.nn.Module):
+        def forward(self, t):
+            return t
+    grads = []
+    for fused in (True, False):
+        f = feat.to(dev()).requires_grad_(True)
+        l, dbg = model.loss(anchors, data, model._inference(model.Inference(None, Id(), anchors), f), 0.6)
+        t = model.weighted_total(l, oloss.HPARAM) if fused else sum(l[k] * oloss.HPARAM[k] for k in l)
+        assert t.shape == (1,)
+        t.backward()
+        grads.append((t.item(), f.grad.clone()))
+        assert set(dbg.keys()) == {'iou', 'data', 'positive', 'negative'}
+        assert dbg['positive'].dtype == torch.bool and dbg['negative'].shape == dbg['positive'].shape
+        assert set(dbg['data'].keys()) == {'yx_min', 'yx_max', 'cls'}
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * abs(grads[1][0])
+    assert rel(grads[0][1], grads[1][1].cpu()) <= 1e-6
+
+
+def test_plan_cache_serves_the_multi_scale_schedule():
+    """utils/data.py:135-141 changes the input size every few batches: the plans (buffers, algorithm choices) of the sizes seen stay
+    cached, a revisit builds nothing, results are those of a fresh model, and a parameter update in between only moves operand pointers."""
+    import _hip
+    import utils
+    import model
+    sd = odark.init_state_dict(5, 20, seed=0, channels=NARROW, head_scale=1 / 8.0)
+    inf, anchors = build(sd)
+    inf.eval()
+    xs = {S: synth.images(2, S, seed=S).to(dev()) for S in (64, 96, 128)}
+    first = {}
+    with torch.no_grad():
+        for S in (64, 96, 128):
+            first[S] = inf.dnn(xs[S]).clone()
+        misses = inf.dnn._plans.misses
+        for S in (96, 64, 128, 64):
+            assert torch.equal(inf.dnn(xs[S]), first[S])
+        assert inf.dnn._plans.misses == misses and len(inf.dnn._plans.d) == 3
+        # a parameter update between visits: same plans, new weights
+        with torch.no_grad():
+            for p in inf.dnn.parameters():
+                p.mul_(1.01)
+        now = {k: v.detach().cpu().double() for k, v in inf.dnn.state_dict().items()}
+        for S in (64, 128):
+            got = inf.dnn(xs[S])
+            assert rel(got, odark.forward(xs[S].cpu().double(), now)) <= TOL
+        assert inf.dnn._plans.misses == misses
+    small = _hip.PlanCache(entries=2)
+    for k in range(4):
+        small.put(k, {}, 10)
+    assert list(small.d) == [2, 3]

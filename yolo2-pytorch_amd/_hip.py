@@ -47,10 +47,21 @@ class PrepItem(ctypes.Structure):
 
 PREP_FPROP, PREP_DGRAD, PREP_WINO_FPROP, PREP_WINO_DGRAD = 0, 1, 2, 3
 
+
+class MultiItem(ctypes.Structure):
+    """y2_multi_item (include/yolo2_hip.h)."""
+    _fields_ = [('src', c_void_p), ('dst', c_void_p), ('n', ctypes.c_int64), ('op', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+MULTI_ZERO, MULTI_F64_TO_F32, MULTI_COPY = 0, 1, 2
+
 SIGNATURES = {
     'y2_abi_version': [],
     'y2_pack_weight': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'y2_prep_weights': [ctypes.POINTER(PrepItem), c_int, c_void_p],
+    'y2_multi': [ctypes.POINTER(MultiItem), c_int, c_void_p],
+    'y2_small_dot': [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    'y2_small_scale': [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     'y2_unpack_weight_grad': [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'y2_bn_fold': [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p],
     'y2_conv_fwd': [ctypes.POINTER(ConvParams), c_void_p],
@@ -76,7 +87,7 @@ SIGNATURES = {
     'y2_conv_wgrad': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'y2_conv_wgrad_ex': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'y2_conv0_wgrad': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    'y2_bn_finalize': [c_void_p, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    'y2_bn_finalize': [c_void_p, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     'y2_bn_act_fwd': [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'y2_bn_act_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
                       c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
@@ -160,24 +171,46 @@ def ptr(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+def multi(items, st=None):
+    """One y2_multi launch.  items: (op, dst tensor, src tensor or None) - MULTI_ZERO fills fp32 / fp64 / integer tensors with zero
+    bytes (the element count is converted to fp32 words), the other ops take the element count of dst."""
+    if not items:
+        return
+    table = (MultiItem * len(items))()
+    for e, (op, dst, src) in zip(table, items):
+        e.op, e.dst = op, dst.data_ptr()
+        if op == MULTI_ZERO:
+            nbytes = dst.numel() * dst.element_size()
+            assert nbytes % 4 == 0 and dst.is_contiguous()
+            e.n, e.src = nbytes // 4, None
+        else:
+            assert dst.dtype == torch.float32 and dst.is_contiguous() and src.is_contiguous() and src.numel() >= dst.numel()
+            e.n, e.src = dst.numel(), src.data_ptr()
+    check(lib().y2_multi(table, len(items), stream() if st is None else st), 'y2_multi')
+
+
 def require_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise RuntimeError('yolo2-hip: this operator runs only on an MI355X GPU tensor (got device %s); there is no CPU fallback' % t.device)
 
 
-# Memory written through raw pointers (the fused optimizers, y2_bn_finalize's running statistics) does not bump torch's
-# `_version` counters, so caches of packed / folded / transformed weights also key on this epoch: every writer of parameter
-# or buffer memory outside torch calls `mutated()`.
-_EPOCH = [0]
+# Memory written through raw pointers (the fused optimizers, y2_bn_finalize's running statistics) is invisible to torch's
+# in-place bookkeeping, so every such writer reports the tensors it wrote with `wrote(...)`: their `_version` counters advance
+# exactly as if a torch in-place op had run.  Caches of packed / folded / transformed weights key on (data_ptr, _version) of
+# the tensors they were derived from and nothing else: per tensor, per model - training one model never invalidates another
+# model's caches or captured graphs.
+def wrote(tensors):
+    """Advance torch's version counter of every tensor in `tensors` (Parameters / buffers written by a HIP kernel)."""
+    torch.autograd.graph.increment_version(tensors)
 
 
-def mutated():
-    _EPOCH[0] += 1
+# Execution plans additionally depend on the measured algorithm table: adopting another process's table (import_tune) moves this.
+_TUNE_EPOCH = [0]
 
 
-def epoch():
-    return _EPOCH[0]
+def tune_epoch():
+    return _TUNE_EPOCH[0]
 
 
 # ---- deterministic mode (include/yolo2_hip.h: y2_set_deterministic): fixed-order reductions instead of atomics, heuristic instead of
@@ -244,6 +277,40 @@ def conv_workspace(params, dev):
     else:
         params.workspace, params.workspace_bytes = None, 0
     return need
+
+
+class PlanCache(object):
+    """Small LRU of execution plans keyed on the input shape (multi-scale training / evaluation cycles through ~10 sizes,
+    utils/data.py:135-141: a single-entry cache would re-plan, re-allocate and re-tune at every size switch).  Bounded by entry
+    count and by the bytes of the intermediate buffers the plans own (Y2_PLAN_CACHE / Y2_PLAN_CACHE_GB)."""
+
+    def __init__(self, entries=None, gbytes=None):
+        import collections
+        self.entries = int(os.environ.get('Y2_PLAN_CACHE', '12')) if entries is None else entries
+        self.bytes = int(float(os.environ.get('Y2_PLAN_CACHE_GB', '64')) * (1 << 30)) if gbytes is None else int(gbytes * (1 << 30))
+        self.d = collections.OrderedDict()
+        self.hits = self.misses = 0
+
+    def get(self, key):
+        plan = self.d.get(key)
+        if plan is None:
+            self.misses += 1
+            return None
+        self.hits += 1
+        self.d.move_to_end(key)
+        return plan
+
+    def put(self, key, plan, nbytes):
+        self.d[key] = plan
+        plan['nbytes'] = nbytes
+        while len(self.d) > 1 and (len(self.d) > self.entries or sum(p['nbytes'] for p in self.d.values()) > self.bytes):
+            self.d.popitem(last=False)
+
+    def latest(self):
+        return next(reversed(self.d.values())) if self.d else None
+
+    def clear(self):
+        self.d.clear()
 
 
 _TUNE = {}
@@ -383,7 +450,7 @@ def import_tune(items, dev):
     _TUNE.clear()
     for k, v in items:
         _TUNE[tuple(str(dev) if e == '@dev' else e for e in k)] = v
-    mutated()
+    _TUNE_EPOCH[0] += 1
 
 
 def _tune_save():
@@ -398,18 +465,32 @@ def _tune_save():
 _WGRAD_WS = {}
 
 
-def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None):
+def wgrad_choice(B, H, W, cin, ldx, cout, ldz, k, has_v, dev):
+    """Which kernel conv_wgrad will run for this problem: 0 = y2_conv_wgrad (accumulates into a ZEROED buffer), 1 = y2_wino_wgrad
+    (overwrites), None = eligible for both and not measured yet (conv_wgrad will time them and zero the buffer itself)."""
+    if not (wino_eligible(cout, cin, k) and not (ldx % 4) and not (ldz % 4)):
+        return 0
+    if DETERMINISTIC or not AUTOTUNE:
+        return 1 if cin >= 128 else 0
+    return _TUNE.get(('wgrad', B, H, W, cin, ldx, cout, ldz, bool(has_v), str(dev)))
+
+
+def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=False):
     """Packed weight gradient dw[cout][k*k][cin] of a stride-1 "same" convolution: y2_conv_wgrad (9 shifted reductions
     over pixels) or, for 3x3 layers where it measures faster, y2_wino_wgrad (16 reductions over 2x2 tiles).  The choice
     is timed once per problem shape and cached.  `v`: the layer's transformed input kept from a Winograd forward (see
-    include/yolo2_hip.h, y2_wino_wgrad) - the weight gradient then skips its input transform."""
+    include/yolo2_hip.h, y2_wino_wgrad) - the weight gradient then skips its input transform.  `out`: destination (cout*k*k*cin
+    floats) instead of a fresh tensor; `zeroed`: the caller has zero-filled it (one y2_multi launch for all layers of a step)."""
     L, st, dev = lib(), stream(), x.device
     nw = cout * cin * k * k
+    choice = wgrad_choice(B, H, W, cin, ldx, cout, ldz, k, v is not None, dev)
     eligible = wino_eligible(cout, cin, k) and not (ldx % 4) and not (ldz % 4)
     key = ('wgrad', B, H, W, cin, ldx, cout, ldz, v is not None, str(dev))
-    choice = (None if DETERMINISTIC else _TUNE.get(key)) if eligible else 0
     # the direct kernel accumulates split partial sums into a zeroed buffer; the Winograd path overwrites (no fill needed)
-    dwp = torch.empty(nw, dtype=torch.float32, device=dev) if choice == 1 else torch.zeros(nw, dtype=torch.float32, device=dev)
+    dwp = out if out is not None else torch.empty(nw, dtype=torch.float32, device=dev)
+    assert dwp.numel() >= nw and dwp.is_contiguous()
+    if choice != 1 and not zeroed:
+        dwp.zero_()
 
     def direct():
         check(L.y2_conv_wgrad(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, k, st), 'y2_conv_wgrad')
@@ -425,7 +506,7 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None):
     def wino():
         check(L.y2_wino_wgrad(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, ptr(v), ptr(ws), ws.numel() * 4, st), 'y2_wino_wgrad')
     if choice is None:
-        if not AUTOTUNE or DETERMINISTIC or torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing():
             choice = 1 if cin >= 128 else 0
         else:
             times = []

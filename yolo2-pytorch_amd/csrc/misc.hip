@@ -196,6 +196,49 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restri
     }
 }
 
+// Multi-range utility pass (y2_multi): zero fills, fp64 -> fp32 conversions and copies of many small ranges in ONE launch (a training
+// step zeroes ~30 accumulation buffers and hands out ~50 affine-parameter gradients; as separate fills / copies they were pure launch latency).
+struct MultiTable {
+    y2_multi_item item[Y2_MULTI_MAX_ITEMS];
+    int first_block[Y2_MULTI_MAX_ITEMS + 1];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void multi_kernel(const MultiTable tb) {
+    int it = 0;
+    while (it + 1 < tb.count && (int)blockIdx.x >= tb.first_block[it + 1]) ++it;
+    const y2_multi_item& q = tb.item[it];
+    const long long nblk = tb.first_block[it + 1] - tb.first_block[it];
+    const long long blk = blockIdx.x - tb.first_block[it];
+    float* __restrict__ dst = q.dst;
+    const long long n = q.n;
+    if (q.op == Y2_MULTI_ZERO) {
+        const bool v4 = !(reinterpret_cast<uintptr_t>(dst) & 15u);
+        const long long n4 = v4 ? n / 4 : 0;
+        for (long long i = blk * 256 + threadIdx.x; i < n4; i += nblk * 256) reinterpret_cast<f32x4*>(dst)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (long long i = n4 * 4 + blk * 256 + threadIdx.x; i < n; i += nblk * 256) dst[i] = 0.f;
+    } else if (q.op == Y2_MULTI_F64_TO_F32) {
+        const double* __restrict__ src = static_cast<const double*>(q.src);
+        for (long long i = blk * 256 + threadIdx.x; i < n; i += nblk * 256) dst[i] = (float)src[i];
+    } else {
+        const float* __restrict__ src = static_cast<const float*>(q.src);
+        for (long long i = blk * 256 + threadIdx.x; i < n; i += nblk * 256) dst[i] = src[i];
+    }
+}
+
+// loss_total = sum_k hparam[k] * loss[k] (train.py:348-349) and its gradient, for the handful of loss terms: one wave
+__global__ void small_dot_kernel(const float* __restrict__ v, const float* __restrict__ w, int n, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += v[i] * w[i];       // left to right, like Python's sum() over the dict
+        out[0] = s;
+    }
+}
+__global__ void small_scale_kernel(const float* __restrict__ g, const float* __restrict__ w, int n, float* __restrict__ out) {
+    const int i = threadIdx.x;
+    if (i < n) out[i] = g[0] * w[i];
+}
+
 inline int stream_grid(long long total, int block) {
     long long g = (total + block - 1) / block;
     const long long cap = (long long)Y2_NUM_CU * 8;
@@ -204,8 +247,8 @@ inline int stream_grid(long long total, int block) {
 
 }  // namespace
 
-extern "C" int y2_abi_version(void) { return 1; }
-extern "C" const char* y2_build_info(void) { return "libyolo2_hip gfx950 fp32-mfma abi1"; }
+extern "C" int y2_abi_version(void) { return 2; }
+extern "C" const char* y2_build_info(void) { return "libyolo2_hip gfx950 fp32-mfma abi2"; }
 
 extern "C" int y2_pack_weight(const float* w, float* dst, int Cout, int Cin, int ksize, int mode, y2_stream_t stream) {
     if (w == nullptr || dst == nullptr || Cout <= 0 || Cin <= 0 || ksize <= 0 || (mode != 0 && mode != 1)) return Y2_EINVAL;
@@ -237,6 +280,43 @@ extern "C" int y2_prep_weights(const y2_prep_item* items, int32_t count, y2_stre
         if (blocks > 0) Y2_LAUNCH("prep_weights_kernel", 0.0, prep_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, y2_s(stream), tb);
         Y2_LAUNCH_CHECK();
     }
+    return Y2_OK;
+}
+
+extern "C" int y2_multi(const y2_multi_item* items, int32_t count, y2_stream_t stream) {
+    if (items == nullptr || count < 0) return Y2_EINVAL;
+    for (int lo = 0; lo < count; lo += Y2_MULTI_MAX_ITEMS) {
+        MultiTable tb;
+        tb.count = count - lo < Y2_MULTI_MAX_ITEMS ? count - lo : Y2_MULTI_MAX_ITEMS;
+        int blocks = 0;
+        for (int i = 0; i < tb.count; ++i) {
+            const y2_multi_item& q = items[lo + i];
+            if (q.dst == nullptr || q.n < 0 || q.op < Y2_MULTI_ZERO || q.op > Y2_MULTI_COPY || (q.op != Y2_MULTI_ZERO && q.src == nullptr)) return Y2_EINVAL;
+            long long nb = (q.n + 4095) / 4096;            // ~16 elements per thread
+            if (nb < 1) nb = 1;
+            if (nb > 1024) nb = 1024;
+            tb.item[i] = q;
+            tb.first_block[i] = blocks;
+            blocks += (int)nb;
+        }
+        tb.first_block[tb.count] = blocks;
+        if (blocks > 0) Y2_LAUNCH("multi_kernel", 0.0, multi_kernel, dim3((unsigned)blocks), dim3(256), 0, y2_s(stream), tb);
+        Y2_LAUNCH_CHECK();
+    }
+    return Y2_OK;
+}
+
+extern "C" int y2_small_dot(const float* v, const float* w, int32_t n, float* out, y2_stream_t stream) {
+    if (!v || !w || !out || n <= 0 || n > 64) return Y2_EINVAL;
+    Y2_LAUNCH("small_dot_kernel", 0.0, small_dot_kernel, dim3(1), dim3(64), 0, y2_s(stream), v, w, n, out);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_small_scale(const float* g, const float* w, int32_t n, float* out, y2_stream_t stream) {
+    if (!g || !w || !out || n <= 0 || n > 64) return Y2_EINVAL;
+    Y2_LAUNCH("small_scale_kernel", 0.0, small_scale_kernel, dim3(1), dim3(64), 0, y2_s(stream), g, w, n, out);
+    Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
 

@@ -20,9 +20,10 @@ inline int stream_grid(long long total, int block, int cap_mult = 8) {
 // running stats take the unbiased variance.
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, double n, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum, float eps,
-                                   float* scale, float* shift, float* mean_out, float* invstd_out, int C) {
+                                   float* scale, float* shift, float* mean_out, float* invstd_out, int C, long long* num_batches_tracked) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;      // nn.BatchNorm2d's step counter, without a launch of its own
     double s1 = 0.0, s2 = 0.0;
     for (int r = 0; r < Y2_STATS_REPL; ++r) { s1 += stats[(size_t)r * 2 * C + c]; s2 += stats[(size_t)r * 2 * C + C + c]; }
     const double mean = s1 / n;
@@ -160,10 +161,12 @@ __global__ void bn_act_bwd_kernel(const ActBwdArgs a, long long total) {
     for (int e = 0; e < CV; ++e) {
         sc[e] = a.scale ? a.scale[c + e] : 1.f; sh[e] = a.shift ? a.shift[c + e] : 0.f;
         mu[e] = a.has_bn ? a.mean[c + e] : 0.f; is[e] = a.has_bn ? a.invstd[c + e] : 1.f;
-        if (APPLY && a.has_bn) {
+        if (APPLY && a.has_bn == 1) {
             gs[e] = a.gamma[c + e] * is[e];
             ma[e] = (float)(a.sums[c + e] / a.n);
             mb[e] = (float)(a.sums[a.C + c + e] / a.n);
+        } else if (APPLY && a.has_bn == 2) {      // frozen statistics (eval-mode BatchNorm): z-hat does not depend on the batch
+            gs[e] = a.gamma[c + e] * is[e]; ma[e] = 0.f; mb[e] = 0.f;
         } else { gs[e] = 1.f; ma[e] = 0.f; mb[e] = 0.f; }
     }
     float s1[CV], s2[CV];
@@ -567,10 +570,10 @@ inline int act_grid(long long total, int Cg) {
 // ================================================================================================ C ABI
 extern "C" int y2_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps,
-                              float* scale, float* shift, float* mean, float* invstd, int C, y2_stream_t stream) {
+                              float* scale, float* shift, float* mean, float* invstd, int C, long long* num_batches_tracked, y2_stream_t stream) {
     if (!stats || !gamma || !beta || !scale || !shift || !mean || !invstd || C <= 0 || count <= 0) return Y2_EINVAL;
     Y2_LAUNCH("bn_finalize_kernel", 0.0, bn_finalize_kernel, dim3(y2_cdiv(C, 256)), dim3(256), 0, y2_s(stream), stats, count, gamma, beta, running_mean, running_var,
-                       momentum, eps, scale, shift, mean, invstd, C);
+                       momentum, eps, scale, shift, mean, invstd, C, num_batches_tracked);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }
@@ -603,7 +606,7 @@ extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float*
                                 const float* dy_full2, int ld2, const float* residual, int ldr, float* dres, int lddr,
                                 double* sums, float* dz, int ldd, int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream) {
     if (!z || (!dy_full && !dy_pool) || !sums || !dz || B <= 0 || H <= 0 || W <= 0 || C <= 0) return Y2_EINVAL;
-    if (has_bn && (!mean || !invstd || !gamma)) return Y2_EINVAL;
+    if (has_bn < 0 || has_bn > 2 || (has_bn && (!mean || !invstd || !gamma))) return Y2_EINVAL;
     const bool pool = dy_pool != nullptr;
     if ((pool || fmode == 1) && ((H & 1) || (W & 1))) return Y2_EINVAL;
     if (C > 8192) return Y2_ENOSUP;

@@ -121,6 +121,12 @@ def loss(anchors, data, pred, threshold):
     return train_graph.loss(anchors, data, pred, threshold)
 
 
+def weighted_total(loss_, hparam):
+    """The weighted sum of the loss terms, train.py:348-349: `sum(loss[key] * hparam[key] for key in loss)`."""
+    from model import train_graph
+    return train_graph.weighted_total(loss_, hparam)
+
+
 _PRED_KEYS = ('feature', 'iou', 'center_offset', 'size_norm', 'yx_min', 'yx_max', 'logits')
 
 

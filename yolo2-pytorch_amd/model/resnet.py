@@ -86,7 +86,7 @@ class ResNet(nn.Module):
                 nn.init.ones_(m.weight)
                 nn.init.zeros_(m.bias)
         self._cache = None
-        self._plan_cache = None
+        self._plans = _hip.PlanCache()
         self.profile = None
         self.grad_ready_hook = None   # train.DataParallelRCCL: called as hook(param, grad) from inside backward
 
@@ -108,8 +108,8 @@ class ResNet(nn.Module):
 
     # ------------------------------------------------------------------ preparation: packed weights + folded BN
     def _versions(self):
-        # torch version counters + the library's mutation epoch (raw-pointer writers: utils.optim, y2_bn_finalize)
-        return (_hip.epoch(),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        # torch version counters (raw-pointer writers - utils.optim, y2_bn_finalize - advance them through _hip.wrote)
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def _prepare(self, dev):
         ver = (dev, self._versions())
@@ -153,11 +153,25 @@ class ResNet(nn.Module):
         return prep
 
     def _plan(self, prep, dev, B, cin0, H, W):
-        key = (id(prep), dev, B, cin0, H, W)
-        if self._plan_cache is not None and self._plan_cache[0] == key:
-            return self._plan_cache[1]
-        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        keep, flops, ulist = [], [0.0], {}
+        key = (str(dev), B, cin0, H, W, _hip.tune_epoch(), _hip.WINOGRAD, _hip.FORCE_ALGO)
+        plan = self._plans.get(key)
+        if plan is not None:
+            if plan['prep'] is not prep:      # same shape, new parameter version: only the weight operand pointers move
+                for p, conv in zip([plan['stem']] + list(plan['arr']), plan['convs']):
+                    wp, scale, shift, cin, cout, k = prep[conv]
+                    u = prep['wino'].get(id(wp))
+                    p.w = (u if p.algo in (1, 2, 3) else wp).data_ptr()
+                    p.scale = scale.data_ptr() if scale is not None else None
+                    p.shift = shift.data_ptr() if shift is not None else None
+                plan['prep'] = prep
+            return plan
+        nbytes = [0]
+
+        def new(*s):
+            t = torch.empty(*s, dtype=torch.float32, device=dev)
+            nbytes[0] += t.numel() * 4
+            return t
+        keep, flops, ulist, convs = [], [0.0], {}, []
 
         def conv_params(conv, x, h, w, ldx, y, stride, pad, slope, residual=None):
             wp, scale, shift, cin, cout, k = prep[conv]
@@ -169,6 +183,7 @@ class ResNet(nn.Module):
             p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize = B, h, w, cin, ldx, cout, k
             p.stride, p.pad_plus1, p.slope, p.tile = stride, pad + 1, slope, 0
             ulist[id(p)] = prep['wino'].get(id(wp))
+            convs.append(conv)
             if residual is not None:
                 p.residual, p.ldr = residual.data_ptr(), cout
             ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
@@ -217,9 +232,9 @@ class ResNet(nn.Module):
         for p in [p_stem] + plist:
             p.workspace, p.workspace_bytes = (ws.data_ptr(), ws.numel() * 4) if ws is not None else (None, 0)
         arr = (_hip.ConvParams * len(plist))(*plist)
-        plan = dict(x4=x4, cpad=cpad, stem=p_stem, stem_out=stem, stem_hw=(h1, w1, c1), pooled=pooled, arr=arr, n=len(plist), head_index=head_index,
-                    head_shape=head_shape, flops=flops[0], keep=(keep, prep, ws))
-        self._plan_cache = (key, plan)
+        plan = dict(key=key, x4=x4, cpad=cpad, stem=p_stem, stem_out=stem, stem_hw=(h1, w1, c1), pooled=pooled, arr=arr, n=len(plist), head_index=head_index,
+                    head_shape=head_shape, flops=flops[0], convs=convs, prep=prep, keep=(keep, ws))
+        self._plans.put(key, plan, nbytes[0])
         return plan
 
     def forward_nhwc(self, x):
@@ -253,6 +268,9 @@ class ResNet(nn.Module):
         if self.training:        # BN semantics follow self.training alone (see model.yolo2.Darknet.forward)
             from model import train_graph
             return train_graph.resnet_forward(self, x)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from model import train_graph
+            return train_graph.resnet_forward(self, x, frozen=True)     # differentiable eval mode: frozen BatchNorm statistics
         with torch.no_grad():
             out = self.forward_nhwc(x)
         return out.permute(0, 3, 1, 2)

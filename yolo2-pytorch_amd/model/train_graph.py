@@ -38,30 +38,32 @@ def _side_stream(dev):
 
 SYNC_POSITIVES = True   # data parallel: all-reduce the positive count so the cls mean is over the global batch
 
-# Set by train.DataParallelRCCL: callable(tensor) summing a small tensor over the wrapper's process group, in place (it knows
-# the group and how to reach it: RCCL directly on device memory, or host staging under the gloo test backend).
-# None: the default group is used when torch.distributed is initialised with more than one rank.
-DP_ALL_REDUCE = None
+# train.DataParallelRCCL tags the tensors its forward returns with `_y2_dp_reduce`: a callable(tensor) summing a small tensor over
+# THAT wrapper's process group, in place (it knows the group and how to reach it: RCCL directly on device memory, or host
+# staging under the gloo test backend).  model.loss reads the tag off pred['feature'], so the reduction follows the model the
+# predictions came from: an unwrapped model in the same process reduces nothing, two wrappers on two groups do not mix.
+DP_TAG = '_y2_dp_reduce'
 
 
-def _sum_over_ranks(t):
+def _sum_over_ranks(t, reducer):
     """True when `t` was summed over more than one rank."""
-    if DP_ALL_REDUCE is not None:
-        return DP_ALL_REDUCE(t)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        if t.is_cuda and dist.get_backend() == 'gloo':
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return True
-    return False
+    return bool(reducer(t)) if reducer is not None else False
+
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.01
 LEAKY = 0.1
 _WINO_CHUNK_BYTES = int(os.environ.get('Y2_WINO_CHUNK_MB', '4096')) << 20      # csrc/wino.hip: wino_chunk_bytes()
+
+
+def _counter(bn):
+    """nn.BatchNorm2d.num_batches_tracked as y2_bn_finalize increments it in place: an int64 scalar on the module's device."""
+    t = bn.num_batches_tracked
+    if t is None:
+        return None
+    if t.dtype != torch.int64 or not t.is_cuda:
+        raise RuntimeError('BatchNorm2d.num_batches_tracked must be an int64 GPU tensor (got %s on %s)' % (t.dtype, t.device))
+    return t
 
 
 def _new(dev, *shape, dtype=torch.float32):
@@ -104,7 +106,7 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
 class _Block(object):
     """One conv block of the forward pass: geometry + saved tensors for backward."""
     __slots__ = ('mod', 'name', 'x', 'ldx', 'H', 'W', 'cin', 'cout', 'k', 'z', 'scale', 'shift', 'mean', 'invstd', 'pool',
-                 'out_full', 'out_pool', 'out_ld', 'out_off', 'out_mode', 'has_bn', 'slope', 'first', 'wino_v')
+                 'out_full', 'out_pool', 'out_ld', 'out_off', 'out_mode', 'has_bn', 'slope', 'first', 'wino_v', 'eff')
 
 
 def _train_operands(dnn, dev):
@@ -115,7 +117,7 @@ def _train_operands(dnn, dev):
     (y2_conv0_fwd reads the state_dict layout) and blocks whose output width is not a multiple of 4 (the 125 / 425-channel head: its
     data gradient runs zero-padded) are left to the per-layer path."""
     from model import yolo2 as _yolo2
-    key = (dev, dnn._versions())
+    key = (dev, dnn._weight_versions())       # the convolution weights only: the BatchNorm buffer updates of a forward pass do not move it
     cache = getattr(dnn, '_train_cache', None)
     if cache is not None and cache[0] == key:
         return cache[1]
@@ -166,271 +168,477 @@ def darknet_forward(dnn, x):
     return out.permute(0, 3, 1, 2)
 
 
+def darknet_forward_eval_grad(dnn, x):
+    """eval()-mode forward that stays differentiable (nn.Module semantics: the reference back-propagates through `dnn` in eval mode,
+    receptive_field_analyzer.py:67,87; frozen-BatchNorm fine-tuning).  Forward = the inference chain (folded BatchNorm, nothing
+    saved but the input); backward re-runs the network through the training graph with FROZEN statistics and back-propagates."""
+    params = [p for p in dnn.parameters()]
+    out = DarknetEvalGradFn.apply(dnn, x, *params)
+    return out.permute(0, 3, 1, 2)
+
+
+class _Eff(object):
+    """Effective parameters of one conv block for one pass: the module's own tensors, or - for channel counts that are not
+    multiples of 4 (pruned checkpoints, model/__init__.py:29-43) - zero-padded copies living in a 4-aligned channel space."""
+    __slots__ = ('w', 'gamma', 'beta', 'rm', 'rv', 'bias', 'cout', 'cin', 'cout_r', 'cin_r', 'in_idx', 'padded')
+
+
+def _pad_layout(dnn):
+    """{Conv2d block: (cout_e, cin_e, in_idx)} when some width of the network is not a multiple of 4, else None.  The kernels of the
+    training path (LDS-DMA operand loads, vectorised BatchNorm passes) want 4-aligned channel strides, so such a network runs in a
+    zero-padded channel space: padded output channels are exactly zero through conv / BatchNorm (gamma 1, beta 0) / LeakyReLU / pool,
+    padded input channels meet zero weights, and every gradient of a padded element is exactly zero - the real slices are what
+    autograd sees.  in_idx: position of every real input channel in the padded input (None = a plain prefix); the concat buffer
+    [4 * c_pt | c_l2] (model/yolo2.py:126-129) interleaves the padding of the reorg'ed passthrough copies."""
+    b1, b2, b3 = dnn._blocks()
+    up = lambda c: (c + 3) // 4 * 4
+    mods = [m for _, m, _ in b1 + b2 + b3] + [dnn.passthrough]
+    head = b3[-1][1]
+    if all(m.conv.weight.shape[0] % 4 == 0 or m is head for m in mods) and all(m.conv.weight.shape[1] % 4 == 0 for m in mods[1:]):
+        return None
+    lay = {}
+    prev = None
+    for i, (_, m, _) in enumerate(b1):
+        cout, cin = m.conv.weight.shape[:2]
+        lay[m] = (up(cout), cin if i == 0 else prev, None)
+        prev = up(cout)
+    route = prev
+    m = dnn.passthrough
+    c_pt = m.conv.weight.shape[0]
+    lay[m] = (up(c_pt), route, None)
+    for _, m, _ in b2:
+        lay[m] = (up(m.conv.weight.shape[0]), prev, None)
+        prev = up(m.conv.weight.shape[0])
+    c_l2 = b2[-1][1].conv.weight.shape[0]
+    idx = [q * up(c_pt) + c for q in range(4) for c in range(c_pt)] + [4 * up(c_pt) + c for c in range(c_l2)]
+    m = b3[0][1]
+    lay[m] = (up(m.conv.weight.shape[0]), 4 * up(c_pt) + up(c_l2), idx)
+    lay[head] = (head.conv.weight.shape[0], up(m.conv.weight.shape[0]), None)       # the head's own width stays (its gradient runs zero-padded, see backward)
+    return lay
+
+
+def _effective(dnn, dev, frozen):
+    """{block: _Eff} for one pass (see _pad_layout)."""
+    lay = _pad_layout(dnn)
+    out = {}
+    for m in dnn.modules():
+        if not hasattr(m, 'conv') or not hasattr(m, 'has_act'):
+            continue
+        e = _Eff()
+        w = m.conv.weight.detach()
+        cout, cin = w.shape[:2]
+        e.cout_r, e.cin_r = cout, cin
+        e.cout, e.cin, e.in_idx = (cout, cin, None) if lay is None else lay[m]
+        e.padded = (e.cout, e.cin) != (cout, cin)
+        bn = m.bn
+        if not e.padded:
+            e.w = _hip.f32c(w)
+            e.gamma, e.beta = (bn.weight.detach(), bn.bias.detach()) if bn is not None else (None, None)
+            e.rm, e.rv = (bn.running_mean, bn.running_var) if bn is not None else (None, None)
+            e.bias = _hip.f32c(m.conv.bias.detach()) if m.conv.bias is not None else None
+        else:
+            # host-side glue on the pruned-model path only: scatter the real rows / columns into zero tensors of the padded shape
+            k = w.shape[2]
+            e.w = torch.zeros(e.cout, e.cin, k, k, dtype=torch.float32, device=dev)
+            if e.in_idx is None:
+                e.w[:cout, :cin] = w
+            else:
+                e.w[:cout].index_copy_(1, torch.tensor(e.in_idx, dtype=torch.long, device=dev), _hip.f32c(w))
+            pad = lambda t, fill: torch.cat([_hip.f32c(t.detach()), torch.full((e.cout - cout,), fill, dtype=torch.float32, device=dev)])
+            e.gamma, e.beta = (pad(bn.weight, 1.0), pad(bn.bias, 0.0)) if bn is not None else (None, None)
+            e.rm, e.rv = (pad(bn.running_mean, 0.0), pad(bn.running_var, 1.0)) if bn is not None else (None, None)
+            e.bias = pad(m.conv.bias, 0.0) if m.conv.bias is not None else None
+        out[m] = e
+    return out
+
+
+def _darknet_fwd(ctx, dnn, x, params, frozen):
+    _hip.require_gpu(x)
+    L = _hip.lib()
+    st = _hip.stream()
+    x = _hip.f32c(x.detach())
+    B, cin0, H, W = x.shape
+    if H % 32 or W % 32:
+        raise ValueError('input size must be a multiple of 32 (got %dx%d)' % (H, W))
+    dev = x.device
+    b1, b2, b3 = dnn._blocks()
+    eff = _effective(dnn, dev, frozen)
+    prepared = _train_operands(dnn, dev) if not any(e.padded for e in eff.values()) else {}
+    det = _hip.ensure_deterministic(dev)      # fixed-order reductions: BN statistics by y2_colstats_det instead of epilogue atomics
+    # one zero-filled arena for every layer's replicated BN-statistics accumulators (one launch instead of 22 fills)
+    arena = None
+    if not frozen:
+        arena = torch.empty(_hip.STATS_REPL * 2 * sum(e.cout for e in eff.values()), dtype=torch.float64, device=dev)
+        _hip.multi([(_hip.MULTI_ZERO, arena, None)])
+    arena_used = [0]
+
+    def take(n):
+        t = arena[arena_used[0]:arena_used[0] + n]
+        arena_used[0] += n
+        return t
+    blocks = []
+    written = []          # running statistics / step counters updated through raw pointers by y2_bn_finalize
+
+    def run_block(name, mod, xin, ldx, h, w, pool, out_full=None, out_ld=0, out_off=0, out_mode=0, want_full=True, first=False):
+        """raw conv + stats -> finalize -> act.  Returns (_Block, full activation or None, pooled activation or None)."""
+        blk = _Block()
+        e = eff[mod]
+        L.y2_prof_set_tag(1 + len(blocks))          # measurement hooks: forward launches of block i carry tag 1 + i
+        cout, cin, k = e.cout, e.cin, mod.kernel_size
+        blk.mod, blk.name, blk.x, blk.ldx, blk.H, blk.W, blk.cin, blk.cout, blk.k = mod, name, xin, ldx, h, w, cin, cout, k
+        blk.pool, blk.has_bn, blk.slope, blk.first = pool, mod.bn is not None, (LEAKY if mod.has_act else 1.0), first
+        blk.wino_v = None
+        blk.eff = e
+        z = _new(dev, B, h, w, cout)
+        stats = take(_hip.STATS_REPL * 2 * cout) if (blk.has_bn and not frozen) else None
+        estats = None if det else stats          # statistics accumulated by the convolution's epilogue (atomics)
+        if first:
+            _hip.check(L.y2_conv0_fwd(_hip.ptr(xin), _hip.ptr(e.w), None, None, _hip.ptr(z), None, _hip.ptr(estats),
+                                      B, h, w, cin, cout, cout, 0, 1.0, st), 'y2_conv0_fwd')
+        elif mod in prepared:
+            blk.wino_v = _conv(L, st, xin, prepared[mod]['wp'], z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=True, u=prepared[mod]['uf'])
+        else:
+            wp = _new(dev, e.w.numel())
+            _hip.check(L.y2_pack_weight(_hip.ptr(e.w), _hip.ptr(wp), cout, cin, k, 0, st), 'y2_pack_weight')
+            blk.wino_v = _conv(L, st, xin, wp, z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=True)
+        if det and stats is not None:
+            _hip.colstats_det(z, B * h * w, cout, cout, stats)
+        blk.z = z
+        if blk.has_bn and frozen:
+            # eval-mode BatchNorm: the folded affine of the inference path; z-hat is built from the running statistics
+            blk.scale, blk.shift = _new(dev, cout), _new(dev, cout)
+            _hip.check(L.y2_bn_fold(_hip.ptr(e.gamma), _hip.ptr(e.beta), _hip.ptr(e.rm), _hip.ptr(e.rv), BN_EPS, _hip.ptr(blk.scale), _hip.ptr(blk.shift), cout, st), 'y2_bn_fold')
+            blk.mean, blk.invstd = _hip.f32c(e.rm), torch.rsqrt(_hip.f32c(e.rv) + BN_EPS)
+        elif blk.has_bn:
+            bn = mod.bn
+            blk.scale, blk.shift, blk.mean, blk.invstd = (_new(dev, cout) for _ in range(4))
+            _hip.check(L.y2_bn_finalize(_hip.ptr(stats), float(B * h * w), _hip.ptr(e.gamma), _hip.ptr(e.beta),
+                                        _hip.ptr(e.rm), _hip.ptr(e.rv), BN_MOMENTUM, BN_EPS,
+                                        _hip.ptr(blk.scale), _hip.ptr(blk.shift), _hip.ptr(blk.mean), _hip.ptr(blk.invstd), cout,
+                                        _hip.ptr(_counter(bn)), st), 'y2_bn_finalize')
+            if e.padded and bn.running_mean is not None:
+                bn.running_mean.copy_(e.rm[:e.cout_r])
+                bn.running_var.copy_(e.rv[:e.cout_r])
+                written.extend(t for t in (bn.num_batches_tracked,) if t is not None)
+            else:
+                written.extend(t for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked) if t is not None)
+        else:
+            blk.scale, blk.mean, blk.invstd = None, None, None
+            blk.shift = e.bias
+        y_full = y_pool = None
+        if out_full is not None:
+            y_full = out_full
+        elif want_full:
+            y_full, out_ld, out_off = _new(dev, B, h, w, cout), cout, 0
+        if pool:
+            y_pool = _new(dev, B, h // 2, w // 2, cout)
+        _hip.check(L.y2_bn_act_fwd(_hip.ptr(z), _hip.ptr(blk.scale), _hip.ptr(blk.shift), blk.slope, _hip.ptr(y_full), _hip.ptr(y_pool),
+                                   B, h, w, cout, cout, out_ld, out_off, cout, 0, out_mode, st), 'y2_bn_act_fwd')
+        blk.out_full, blk.out_pool, blk.out_ld, blk.out_off, blk.out_mode = y_full, y_pool, out_ld, out_off, out_mode
+        blocks.append(blk)
+        return blk, y_full, y_pool
+
+    # ---- layers1 (model/yolo2.py:76-96)
+    cur, ld, h, w = x, cin0, H, W
+    full_last = None
+    for i, (name, mod, pool) in enumerate(b1):
+        last = i == len(b1) - 1
+        pool = pool or last      # layers2 starts with the MaxPool that follows layers1[-1] (model/yolo2.py:97)
+        blk, yf, yp = run_block(name, mod, cur, ld, h, w, pool, want_full=(not pool) or last, first=(i == 0))
+        if last:
+            full_last, fh, fw = yf, h, w
+        if pool:
+            cur, h, w = yp, h // 2, w // 2
+        else:
+            cur = yf
+        ld = blk.cout
+    # ---- passthrough + reorg into the concat buffer (model/yolo2.py:107,126,129)
+    c_pt = eff[dnn.passthrough].cout
+    c_l2 = eff[b2[-1][1]].cout
+    cat = _new(dev, B, h, w, 4 * c_pt + c_l2)
+    run_block('passthrough', dnn.passthrough, full_last, full_last.shape[-1], fh, fw, False, out_full=cat, out_ld=cat.shape[-1], out_off=0, out_mode=1)
+    # ---- layers2 (leading MaxPool already applied: `cur` is the pooled output of layers1[-1])
+    for i, (name, mod, pool) in enumerate(b2):
+        if i == len(b2) - 1:
+            blk, yf, yp = run_block(name, mod, cur, ld, h, w, False, out_full=cat, out_ld=cat.shape[-1], out_off=4 * c_pt)
+        else:
+            blk, yf, yp = run_block(name, mod, cur, ld, h, w, False)
+            cur, ld = yf, blk.cout
+    # ---- layers3
+    cur, ld = cat, cat.shape[-1]
+    for i, (name, mod, pool) in enumerate(b3):
+        blk, yf, yp = run_block(name, mod, cur, ld, h, w, False)
+        cur, ld = yf, blk.cout
+    if written:
+        _hip.wrote(written)
+    ctx.dnn = dnn
+    ctx.blocks = blocks
+    ctx.prepared = prepared
+    ctx.prepared_key = dnn._train_cache[0] if prepared else None
+    ctx.geom = (B, cin0, H, W, c_pt, c_l2)
+    ctx.x = x
+    ctx.frozen = frozen
+    ctx.param_ids = [id(p) for p in params]
+    L.y2_prof_set_tag(0)
+    return cur
+
+
+def _darknet_bwd(ctx, dout):
+    L = _hip.lib()
+    st = _hip.stream()
+    dnn, blocks = ctx.dnn, ctx.blocks
+    if ctx.prepared and (getattr(dnn, '_train_cache', (None, None))[0] != ctx.prepared_key or ctx.prepared_key != (dout.device, dnn._weight_versions())):
+        raise RuntimeError('model.yolo2: a convolution weight was modified (optimizer step, load_state_dict, in-place edit) between this forward and '
+                           'its backward; the per-model GEMM operand buffers this graph was recorded against hold other weights now')
+    B, cin0, H, W, c_pt, c_l2 = ctx.geom
+    dev = dout.device
+    dout = _hip.f32c(dout)
+    grads = {}
+    hook = getattr(dnn, 'grad_ready_hook', None)
+    buffer_hook = getattr(dnn, 'grad_buffer_hook', None)     # train.DataParallelRCCL: where the averaged gradient of a parameter will live (its flat-bucket slice)
+
+    def ready(param, g):
+        grads[id(param)] = g
+        if hook is not None:
+            hook(param, g)
+
+    def dest(param):
+        """Tensor a finished gradient of `param` is written to: the data-parallel bucket slice when the wrapper offers one (the
+        all-reduce then runs in place, no copy into the bucket), else fresh memory."""
+        t = buffer_hook(param) if buffer_hook is not None else None
+        return t if t is not None else _new(dev, *param.shape)
+
+    # gradient sources per block index: (dy_full tensor, ldf, foff, fmode), dy_pool tensor
+    n = len(blocks)
+    src_full = [None] * n
+    src_pool = [None] * n
+    idx = {b.name: i for i, b in enumerate(blocks)}
+    head = n - 1
+    src_full[head] = (dout, blocks[head].cout, 0, 0)
+    n1 = len(dnn._blocks()[0])
+    i_pass = idx['passthrough']
+    order = list(range(n - 1, -1, -1))
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev) if (BWD_STREAMS > 1 and not _hip.DETERMINISTIC and not torch.cuda.is_current_stream_capturing()) else None
+    late = []                                         # (parameter, gradient, event) of weight gradients still running on the side stream
+    affine_grads = []                                 # (parameter, offset into sums_arena, length)
+
+    # ---- everything that must start from zero, filled by ONE launch: the fp64 sums of all BatchNorm backward passes, the
+    # accumulation targets of the direct (split, atomically added) weight gradients and the zero-padded gradient of an unaligned head
+    sums_arena = torch.empty(2 * sum(b.cout for b in blocks), dtype=torch.float64, device=dev)
+    zero = [sums_arena]
+    bufs = dnn.__dict__.setdefault('_train_bufs', (dev, {}))
+    if bufs[0] != dev:
+        bufs = dnn._train_bufs = (dev, {})
+
+    def persistent(tag, nel):
+        t = bufs[1].get(tag)
+        if t is None or t.numel() != nel:
+            t = bufs[1][tag] = torch.empty(nel, dtype=torch.float32, device=dev)
+        return t
+    wg = {}          # block index -> (accumulation target, it is the final gradient tensor, pre-zeroed)
+    dzs = {}
+    for i in order:
+        blk = blocks[i]
+        e = blk.eff
+        cop = (blk.cout + 3) // 4 * 4
+        weight = blk.mod.conv.weight
+        if cop != blk.cout:
+            dzs[i] = _new(dev, B, blk.H, blk.W, cop)
+            zero.append(dzs[i])
+        if blk.first:
+            if blk.cin <= 3 and blk.cout <= 64:
+                t = dest(weight) if not e.padded else _new(dev, blk.cout, blk.cin, 3, 3)
+                wg[i] = (t, True, True)
+                zero.append(t)
+            continue
+        choice = _hip.wgrad_choice(B, blk.H, blk.W, blk.cin, blk.ldx, cop, cop, blk.k, blk.wino_v is not None, dev)
+        final = blk.k == 1 and cop == blk.cout and not e.padded        # [cout][1][cin] IS the state_dict layout: no unpack pass
+        if blk.k == 1:      # (never a persistent buffer: what this kernel writes is handed to autograd as it is, or as a prefix view)
+            t = dest(weight).view(-1) if final else _new(dev, cop * blk.cin)
+        else:               # packed [cout][tap][cin] staging of a 3x3 gradient, unpacked into the gradient tensor afterwards: reused every step
+            t = persistent((blk.name, 'dwp'), cop * blk.cin * blk.k * blk.k)
+        if choice == 0:
+            zero.append(t)
+        wg[i] = (t, final, choice == 0)
+    _hip.multi([(_hip.MULTI_ZERO, t, None) for t in zero], st)
+    sums_used = 0
+
+    def flush_weight_grads(keep=0):
+        while len(late) > keep:
+            prm, g, evt = late.pop(0)
+            main.wait_event(evt)
+            ready(prm, g)
+    for i in order:
+        blk = blocks[i]
+        e = blk.eff
+        L.y2_prof_set_tag(101 + i)                  # backward launches of block i: tag 101 + i
+        h, w, cout, cin, k = blk.H, blk.W, blk.cout, blk.cin, blk.k
+        sums = sums_arena[sums_used:sums_used + 2 * cout]
+        sums_used += 2 * cout
+        # the wgrad / dgrad DMA kernels want channel counts that are multiples of 4: an unaligned Cout (the 125 / 425 channel head)
+        # is handled in a zero-padded channel space here; unaligned widths elsewhere were padded by the forward (_pad_layout)
+        cop = (cout + 3) // 4 * 4
+        dz = dzs[i] if i in dzs else _new(dev, B, h, w, cop)
+        sf, sp = src_full[i], src_pool[i]
+        _hip.check(L.y2_bn_act_bwd(_hip.ptr(blk.z), _hip.ptr(blk.scale), _hip.ptr(blk.shift), _hip.ptr(blk.mean), _hip.ptr(blk.invstd),
+                                   _hip.ptr(e.gamma) if blk.has_bn else None, blk.slope,
+                                   _hip.ptr(sf[0]) if sf else None, sf[1] if sf else 0, sf[2] if sf else 0, sf[3] if sf else 0,
+                                   _hip.ptr(sp), cout, 0, _hip.ptr(sums), _hip.ptr(dz), cop, B, h, w, cout, cout,
+                                   (2 if ctx.frozen else 1) if blk.has_bn else 0, st), 'y2_bn_act_bwd')
+        # parameter gradients of the affine part = the fp64 sums of pass 1: converted for ALL layers by one launch after the loop
+        # (they are a few KB per layer; 23 separate 5-microsecond conversions were pure launch latency)
+        if blk.has_bn:
+            affine_grads.append((blk.mod.bn.bias, sums_used - 2 * cout, e.cout_r))
+            affine_grads.append((blk.mod.bn.weight, sums_used - cout, e.cout_r))
+        elif blk.mod.conv.bias is not None:
+            affine_grads.append((blk.mod.conv.bias, sums_used - 2 * cout, e.cout_r))
+        # weight gradient: off the critical path (nothing downstream of this layer's backward needs it), so it runs on a SIDE stream
+        # and its MFMA-bound kernel overlaps the HBM-bound passes (y2_bn_act_bwd, Winograd input transforms) of the layers that
+        # follow on the main stream.  The gradient is handed to autograd / the data-parallel hook one layer later, behind an event.
+        weight = blk.mod.conv.weight
+
+        def real(dw):
+            """[cop][cin_e][k][k] in the (padded) channel space of the pass -> the parameter's own shape."""
+            if not e.padded and cop == cout:
+                return dw
+            dw = dw[:e.cout_r]                       # a prefix of the leading dimension: contiguous, no copy
+            if e.cin != e.cin_r:
+                dw = dw.index_select(1, torch.tensor(e.in_idx, dtype=torch.long, device=dev)) if e.in_idx is not None else dw[:, :e.cin_r].contiguous()
+            return dw
+
+        def weight_grad(st_w):
+            if i in wg and blk.first:
+                dw0 = wg[i][0]
+                _hip.check(L.y2_conv0_wgrad(_hip.ptr(ctx.x), _hip.ptr(dz), _hip.ptr(dw0), B, h, w, cin, cout, cop, st_w), 'y2_conv0_wgrad')
+                return real(dw0)
+            if blk.first:
+                x4 = torch.zeros(B, h, w, 4, dtype=torch.float32, device=dev)
+                x4[..., :cin] = ctx.x.permute(0, 2, 3, 1)          # layout conversion only (NCHW plugin input -> NHWC, 4th channel zero)
+                dwp = torch.zeros(cop * k * k * 4, dtype=torch.float32, device=dev)
+                _hip.check(L.y2_conv_wgrad(_hip.ptr(x4), _hip.ptr(dz), _hip.ptr(dwp), B, h, w, 4, 4, cop, cop, k, st_w), 'y2_conv_wgrad')
+                dw4 = _new(dev, cop, 4, k, k)
+                _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw4), cop, 4, k, st_w), 'y2_unpack_weight_grad')
+                return dw4[:e.cout_r, :cin].contiguous()
+            tgt, final, zeroed = wg[i]
+            _hip.conv_wgrad(blk.x, dz, B, h, w, cin, blk.ldx, cop, cop, k, v=blk.wino_v, out=tgt, zeroed=zeroed)     # direct or Winograd, by measurement
+            if final:
+                return tgt.view(cout, cin, 1, 1)
+            if k == 1:
+                return real(tgt.view(cop, cin, 1, 1))
+            dw = dest(weight) if (cop == cout and not e.padded) else _new(dev, cop, cin, k, k)
+            _hip.check(L.y2_unpack_weight_grad(_hip.ptr(tgt), _hip.ptr(dw), cop, cin, k, st_w), 'y2_unpack_weight_grad')
+            return real(dw)
+
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(main)                           # dz (and everything before it) is complete on the main stream
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                gw = weight_grad(_hip.stream())
+                for tns in (dz, blk.x, blk.wino_v, ctx.x):       # read on the side stream: the allocator must not recycle them under it
+                    if tns is not None:
+                        tns.record_stream(side)
+                done = torch.cuda.Event()
+                done.record(side)
+            gw.record_stream(main)
+            flush_weight_grads(keep=1)
+            late.append((weight, gw, done))
+        else:
+            ready(weight, weight_grad(st))
+        blk.wino_v = None
+        if not blk.first:
+            # data gradient -> the producer's gradient source
+            dx = _new(dev, B, h, w, cin)
+            ready_ops = ctx.prepared.get(blk.mod)
+            if ready_ops is not None:        # rotated / in-out-swapped operands prepared with the forward's (same parameter version)
+                _conv(L, st, dz, ready_ops['wd'], dx, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'])
+            else:
+                wsrc = e.w
+                if cop != cout:
+                    wpad = torch.zeros(cop, cin, k, k, dtype=torch.float32, device=dev)
+                    wpad[:cout] = wsrc                                   # zero rows for the padded output channels
+                    wsrc = wpad
+                wd = _new(dev, wsrc.numel())
+                _hip.check(L.y2_pack_weight(_hip.ptr(wsrc), _hip.ptr(wd), cop, cin, k, 1, st), 'y2_pack_weight')
+                _conv(L, st, dz, wd, dx, B, h, w, cop, cop, cin, k, cin)
+            # route dx
+            if blk.name == 'layers3.0':
+                dcat = dx                                           # [B,h,w,4*c_pt + c_l2]
+                src_full[i_pass] = (dcat, dcat.shape[-1], 0, 1)     # reorg'ed channels first
+                src_full[idx[dnn._blocks()[1][-1][0]]] = (dcat, dcat.shape[-1], 4 * c_pt, 0)
+            elif blk.name == 'passthrough':
+                j = n1 - 1
+                src_full[j] = (dx, cin, 0, 0)
+            elif i == n1 + 1 and blk.name.startswith('layers2.'):   # first conv of layers2: its input is the pooled layers1[-1]
+                src_pool[n1 - 1] = dx
+            else:
+                prod = i - 1
+                if blocks[prod].pool:
+                    src_pool[prod] = dx
+                else:
+                    src_full[prod] = (dx, cin, 0, 0)
+        blk.z = None   # free as we go
+    # ---- affine-parameter gradients: fp64 sums -> fp32, one launch; straight into the data-parallel bucket slices when there are any
+    items, handed = [], []
+    gb_all = None
+    for prm, off, ln in affine_grads:
+        t = buffer_hook(prm) if buffer_hook is not None else None
+        if t is None:
+            if gb_all is None:
+                gb_all = _new(dev, sums_arena.numel())
+                items.append((_hip.MULTI_F64_TO_F32, gb_all, sums_arena))
+            t = gb_all[off:off + ln]
+        else:
+            items.append((_hip.MULTI_F64_TO_F32, t, sums_arena[off:off + ln]))
+        handed.append((prm, t))
+    _hip.multi(items, st)
+    for prm, t in handed:
+        ready(prm, t)
+    flush_weight_grads()
+    L.y2_prof_set_tag(0)
+    out = [None, None]
+    for pid in ctx.param_ids:
+        out.append(grads.get(pid))
+    ctx.blocks = None
+    ctx.prepared = None
+    return tuple(out)
+
+
 class DarknetTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dnn, x, *params):
-        _hip.require_gpu(x)
-        L = _hip.lib()
-        st = _hip.stream()
-        x = _hip.f32c(x.detach())
-        B, cin0, H, W = x.shape
-        if H % 32 or W % 32:
-            raise ValueError('input size must be a multiple of 32 (got %dx%d)' % (H, W))
-        dev = x.device
-        b1, b2, b3 = dnn._blocks()
-        prepared = _train_operands(dnn, dev)
-        det = _hip.ensure_deterministic(dev)      # fixed-order reductions: BN statistics by y2_colstats_det instead of epilogue atomics
-        # one zero-filled arena for every layer's replicated BN-statistics accumulators (one fill kernel instead of 22)
-        couts = [m.conv.weight.shape[0] for _, m, _ in b1 + b2 + b3] + [dnn.passthrough.conv.weight.shape[0]]
-        arena = torch.zeros(_hip.STATS_REPL * 2 * sum(couts), dtype=torch.float64, device=dev)
-        arena_used = [0]
-
-        def take(n):
-            t = arena[arena_used[0]:arena_used[0] + n]
-            arena_used[0] += n
-            return t
-        blocks = []
-
-        def run_block(name, mod, xin, ldx, h, w, pool, out_full=None, out_ld=0, out_off=0, out_mode=0, want_full=True, first=False):
-            """raw conv + stats -> finalize -> act.  Returns (_Block, full activation or None, pooled activation or None)."""
-            blk = _Block()
-            L.y2_prof_set_tag(1 + len(blocks))          # measurement hooks: forward launches of block i carry tag 1 + i
-            weight = mod.conv.weight.detach()
-            cout, cin, k, _ = weight.shape
-            blk.mod, blk.name, blk.x, blk.ldx, blk.H, blk.W, blk.cin, blk.cout, blk.k = mod, name, xin, ldx, h, w, cin, cout, k
-            blk.pool, blk.has_bn, blk.slope, blk.first = pool, mod.bn is not None, (LEAKY if mod.has_act else 1.0), first
-            blk.wino_v = None
-            z = _new(dev, B, h, w, cout)
-            stats = take(_hip.STATS_REPL * 2 * cout) if blk.has_bn else None
-            estats = None if det else stats          # statistics accumulated by the convolution's epilogue (atomics)
-            if first:
-                _hip.check(L.y2_conv0_fwd(_hip.ptr(xin), _hip.ptr(_hip.f32c(weight)), None, None, _hip.ptr(z), None, _hip.ptr(estats),
-                                          B, h, w, cin, cout, cout, 0, 1.0, st), 'y2_conv0_fwd')
-            elif mod in prepared:
-                blk.wino_v = _conv(L, st, xin, prepared[mod]['wp'], z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=True, u=prepared[mod]['uf'])
-            else:
-                wp = _new(dev, weight.numel())
-                _hip.check(L.y2_pack_weight(_hip.ptr(_hip.f32c(weight)), _hip.ptr(wp), cout, cin, k, 0, st), 'y2_pack_weight')
-                blk.wino_v = _conv(L, st, xin, wp, z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=True)
-            if det and stats is not None:
-                _hip.colstats_det(z, B * h * w, cout, cout, stats)
-            blk.z = z
-            if blk.has_bn:
-                bn = mod.bn
-                blk.scale, blk.shift, blk.mean, blk.invstd = (_new(dev, cout) for _ in range(4))
-                _hip.check(L.y2_bn_finalize(_hip.ptr(stats), float(B * h * w), _hip.ptr(bn.weight.detach()), _hip.ptr(bn.bias.detach()),
-                                            _hip.ptr(bn.running_mean), _hip.ptr(bn.running_var), BN_MOMENTUM, BN_EPS,
-                                            _hip.ptr(blk.scale), _hip.ptr(blk.shift), _hip.ptr(blk.mean), _hip.ptr(blk.invstd), cout, st), 'y2_bn_finalize')
-                _hip.mutated()      # running statistics were written through raw pointers
-                if bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked += 1
-            else:
-                blk.scale, blk.mean, blk.invstd = None, None, None
-                blk.shift = _hip.f32c(mod.conv.bias.detach()) if mod.conv.bias is not None else None
-            y_full = y_pool = None
-            if out_full is not None:
-                y_full = out_full
-            elif want_full:
-                y_full, out_ld, out_off = _new(dev, B, h, w, cout), cout, 0
-            if pool:
-                y_pool = _new(dev, B, h // 2, w // 2, cout)
-            _hip.check(L.y2_bn_act_fwd(_hip.ptr(z), _hip.ptr(blk.scale), _hip.ptr(blk.shift), blk.slope, _hip.ptr(y_full), _hip.ptr(y_pool),
-                                       B, h, w, cout, cout, out_ld, out_off, cout, 0, out_mode, st), 'y2_bn_act_fwd')
-            blk.out_full, blk.out_pool, blk.out_ld, blk.out_off, blk.out_mode = y_full, y_pool, out_ld, out_off, out_mode
-            blocks.append(blk)
-            return blk, y_full, y_pool
-
-        # ---- layers1 (model/yolo2.py:76-96)
-        cur, ld, h, w = x, cin0, H, W
-        full_last = None
-        for i, (name, mod, pool) in enumerate(b1):
-            last = i == len(b1) - 1
-            pool = pool or last      # layers2 starts with the MaxPool that follows layers1[-1] (model/yolo2.py:97)
-            blk, yf, yp = run_block(name, mod, cur, ld, h, w, pool, want_full=(not pool) or last, first=(i == 0))
-            if last:
-                full_last, fh, fw = yf, h, w
-            if pool:
-                cur, h, w = yp, h // 2, w // 2
-            else:
-                cur = yf
-            ld = blk.cout
-        # ---- passthrough + reorg into the concat buffer (model/yolo2.py:107,126,129)
-        c_pt = dnn.passthrough.conv.weight.shape[0]
-        c_l2 = b2[-1][1].conv.weight.shape[0]
-        cat = _new(dev, B, h, w, 4 * c_pt + c_l2)
-        run_block('passthrough', dnn.passthrough, full_last, full_last.shape[-1], fh, fw, False, out_full=cat, out_ld=cat.shape[-1], out_off=0, out_mode=1)
-        # ---- layers2 (leading MaxPool already applied: `cur` is the pooled output of layers1[-1])
-        for i, (name, mod, pool) in enumerate(b2):
-            if i == len(b2) - 1:
-                blk, yf, yp = run_block(name, mod, cur, ld, h, w, False, out_full=cat, out_ld=cat.shape[-1], out_off=4 * c_pt)
-            else:
-                blk, yf, yp = run_block(name, mod, cur, ld, h, w, False)
-                cur, ld = yf, blk.cout
-        # ---- layers3
-        cur, ld = cat, cat.shape[-1]
-        for i, (name, mod, pool) in enumerate(b3):
-            blk, yf, yp = run_block(name, mod, cur, ld, h, w, False)
-            cur, ld = yf, blk.cout
-        ctx.dnn = dnn
-        ctx.blocks = blocks
-        ctx.prepared = prepared
-        ctx.geom = (B, cin0, H, W, c_pt, c_l2)
-        ctx.x = x
-        ctx.param_ids = [id(p) for p in params]
-        L.y2_prof_set_tag(0)
-        return cur
+        if x.requires_grad:
+            raise RuntimeError('model.yolo2: the gradient with respect to the input image is not implemented (the first layer has no data-gradient '
+                               'kernel); detach the input')
+        return _darknet_fwd(ctx, dnn, x, params, frozen=False)
 
     @staticmethod
     def backward(ctx, dout):
-        L = _hip.lib()
-        st = _hip.stream()
-        dnn, blocks = ctx.dnn, ctx.blocks
-        if ctx.prepared and getattr(dnn, '_train_cache', (None, None))[1] is not ctx.prepared:
-            raise RuntimeError('model.yolo2: the weights changed (another forward after an optimizer step) between this forward and its backward; '
-                               'the prepared GEMM operands of this graph are gone')
-        B, cin0, H, W, c_pt, c_l2 = ctx.geom
-        dev = dout.device
-        dout = _hip.f32c(dout)
-        grads = {}
-        hook = getattr(dnn, 'grad_ready_hook', None)
+        return _darknet_bwd(ctx, dout)
 
-        def ready(param, g):
-            grads[id(param)] = g
-            if hook is not None:
-                hook(param, g)
 
-        # gradient sources per block index: (dy_full tensor, ldf, foff, fmode), dy_pool tensor
-        n = len(blocks)
-        src_full = [None] * n
-        src_pool = [None] * n
-        idx = {b.name: i for i, b in enumerate(blocks)}
-        head = n - 1
-        src_full[head] = (dout, blocks[head].cout, 0, 0)
-        # who consumes whose output
-        n1 = len(dnn._blocks()[0])
-        i_pass = idx['passthrough']
-        order = list(range(n - 1, -1, -1))
-        dcat = None
-        sums_arena = torch.zeros(2 * sum(b.cout for b in blocks), dtype=torch.float64, device=dev)     # one fill for all layers
-        sums_used = 0
-        main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if (BWD_STREAMS > 1 and not _hip.DETERMINISTIC and not torch.cuda.is_current_stream_capturing()) else None
-        late = []                                         # (parameter, gradient, event) of weight gradients still running on the side stream
-        affine_grads = []                                 # (parameter, offset into sums_arena, length)
+class _Tape(object):
+    """Stand-in for an autograd ctx when the training graph is run from inside another Function's backward."""
 
-        def flush_weight_grads(keep=0):
-            while len(late) > keep:
-                prm, g, evt = late.pop(0)
-                main.wait_event(evt)
-                ready(prm, g)
-        for i in order:
-            blk = blocks[i]
-            L.y2_prof_set_tag(101 + i)                  # backward launches of block i: tag 101 + i
-            h, w, cout, cin, k = blk.H, blk.W, blk.cout, blk.cin, blk.k
-            sums = sums_arena[sums_used:sums_used + 2 * cout]
-            sums_used += 2 * cout
-            # the wgrad / dgrad DMA kernels want channel counts that are multiples of 4: an unaligned Cout (the 125 / 425
-            # channel head) is handled in a zero-padded channel space; unaligned Cin is an inference-only feature
-            cop = (cout + 3) // 4 * 4
-            if not blk.first and cin % 4:
-                raise RuntimeError('training needs conv input channel counts that are multiples of 4 (%s has %d); inference supports any width' % (blk.name, cin))
-            dz = _new(dev, B, h, w, cop) if cop == cout else torch.zeros(B, h, w, cop, dtype=torch.float32, device=dev)
-            sf, sp = src_full[i], src_pool[i]
-            _hip.check(L.y2_bn_act_bwd(_hip.ptr(blk.z), _hip.ptr(blk.scale), _hip.ptr(blk.shift), _hip.ptr(blk.mean), _hip.ptr(blk.invstd),
-                                       _hip.ptr(blk.mod.bn.weight.detach()) if blk.has_bn else None, blk.slope,
-                                       _hip.ptr(sf[0]) if sf else None, sf[1] if sf else 0, sf[2] if sf else 0, sf[3] if sf else 0,
-                                       _hip.ptr(sp), cout, 0, _hip.ptr(sums), _hip.ptr(dz), cop, B, h, w, cout, cout, int(blk.has_bn), st), 'y2_bn_act_bwd')
-            # parameter gradients of the affine part = the fp64 sums of pass 1: converted for ALL layers by one launch after the loop
-            # (they are a few KB per layer; 23 separate 5-microsecond conversions were pure launch latency)
-            if blk.has_bn:
-                affine_grads.append((blk.mod.bn.bias, sums_used - 2 * cout, cout))
-                affine_grads.append((blk.mod.bn.weight, sums_used - cout, cout))
-            elif blk.mod.conv.bias is not None:
-                affine_grads.append((blk.mod.conv.bias, sums_used - 2 * cout, cout))
-            # weight gradient: off the critical path (nothing downstream of this layer's backward needs it), so it runs on a SIDE stream
-            # and its MFMA-bound kernel overlaps the HBM-bound passes (y2_bn_act_bwd, Winograd input transforms) of the layers that
-            # follow on the main stream.  The gradient is handed to autograd / the data-parallel hook one layer later, behind an event.
-            weight = blk.mod.conv.weight
 
-            def weight_grad(st_w):
-                if blk.first and cin <= 3 and cout <= 64:
-                    dw0 = torch.zeros(cout, cin, k, k, dtype=torch.float32, device=dev)
-                    _hip.check(L.y2_conv0_wgrad(_hip.ptr(ctx.x), _hip.ptr(dz), _hip.ptr(dw0), B, h, w, cin, cout, cop, st_w), 'y2_conv0_wgrad')
-                    return dw0
-                if blk.first:
-                    x4 = torch.zeros(B, h, w, 4, dtype=torch.float32, device=dev)
-                    x4[..., :cin] = ctx.x.permute(0, 2, 3, 1)          # layout conversion only (NCHW plugin input -> NHWC, 4th channel zero)
-                    dwp = torch.zeros(cop * k * k * 4, dtype=torch.float32, device=dev)
-                    _hip.check(L.y2_conv_wgrad(_hip.ptr(x4), _hip.ptr(dz), _hip.ptr(dwp), B, h, w, 4, 4, cop, cop, k, st_w), 'y2_conv_wgrad')
-                    dw4 = _new(dev, cop, 4, k, k)
-                    _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw4), cop, 4, k, st_w), 'y2_unpack_weight_grad')
-                    return dw4[:cout, :cin].contiguous()
-                dwp = _hip.conv_wgrad(blk.x, dz, B, h, w, cin, blk.ldx, cop, cop, k, v=blk.wino_v)     # direct or Winograd, by measurement
-                dw = _new(dev, cop, cin, k, k)
-                _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cop, cin, k, st_w), 'y2_unpack_weight_grad')
-                return dw if cop == cout else dw[:cout].contiguous()
+class DarknetEvalGradFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dnn, x, *params):
+        if x.requires_grad:
+            raise RuntimeError('model.yolo2: the gradient with respect to the input image is not implemented (the first layer has no data-gradient '
+                               'kernel); detach the input')
+        ctx.dnn, ctx.x, ctx.params = dnn, x.detach(), params
+        ctx.key = dnn._versions()
+        return dnn.forward_nhwc(x.detach())
 
-            if side is not None:
-                ev = torch.cuda.Event()
-                ev.record(main)                           # dz (and everything before it) is complete on the main stream
-                with torch.cuda.stream(side):
-                    side.wait_event(ev)
-                    gw = weight_grad(_hip.stream())
-                    for tns in (dz, blk.x, blk.wino_v, ctx.x):       # read on the side stream: the allocator must not recycle them under it
-                        if tns is not None:
-                            tns.record_stream(side)
-                    done = torch.cuda.Event()
-                    done.record(side)
-                gw.record_stream(main)
-                flush_weight_grads(keep=1)
-                late.append((weight, gw, done))
-            else:
-                ready(weight, weight_grad(st))
-            blk.wino_v = None
-            if not blk.first:
-                # data gradient -> the producer's gradient source
-                dx = _new(dev, B, h, w, cin)
-                ready_ops = ctx.prepared.get(blk.mod)
-                if ready_ops is not None:        # rotated / in-out-swapped operands prepared with the forward's (same parameter version)
-                    _conv(L, st, dz, ready_ops['wd'], dx, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'])
-                else:
-                    wsrc = _hip.f32c(weight.detach())
-                    if cop != cout:
-                        wpad = torch.zeros(cop, cin, k, k, dtype=torch.float32, device=dev)
-                        wpad[:cout] = wsrc                                   # zero rows for the padded output channels
-                        wsrc = wpad
-                    wd = _new(dev, wsrc.numel())
-                    _hip.check(L.y2_pack_weight(_hip.ptr(wsrc), _hip.ptr(wd), cop, cin, k, 1, st), 'y2_pack_weight')
-                    _conv(L, st, dz, wd, dx, B, h, w, cop, cop, cin, k, cin)
-                # route dx
-                if blk.name == 'layers3.0':
-                    dcat = dx                                           # [B,h,w,4*c_pt + c_l2]
-                    src_full[i_pass] = (dcat, dcat.shape[-1], 0, 1)     # reorg'ed channels first
-                    src_full[idx[dnn._blocks()[1][-1][0]]] = (dcat, dcat.shape[-1], 4 * c_pt, 0)
-                elif blk.name == 'passthrough':
-                    j = n1 - 1
-                    src_full[j] = (dx, cin, 0, 0)
-                elif i == n1 + 1 and blk.name.startswith('layers2.'):   # first conv of layers2: its input is the pooled layers1[-1]
-                    src_pool[n1 - 1] = dx
-                else:
-                    prod = i - 1
-                    if blocks[prod].pool:
-                        src_pool[prod] = dx
-                    else:
-                        src_full[prod] = (dx, cin, 0, 0)
-            blk.z = None   # free as we go
-        gb_all = _new(dev, sums_arena.numel())
-        _hip.check(L.y2_f64_to_f32(_hip.ptr(sums_arena), _hip.ptr(gb_all), sums_arena.numel(), 1.0, st), 'y2_f64_to_f32')
-        for prm, off, ln in affine_grads:
-            ready(prm, gb_all[off:off + ln])
-        flush_weight_grads()
-        L.y2_prof_set_tag(0)
-        out = [None, None]
-        for pid in ctx.param_ids:
-            out.append(grads.get(pid))
-        ctx.blocks = None
-        ctx.prepared = None
-        return tuple(out)
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.dnn._versions() != ctx.key:
+            raise RuntimeError('model.yolo2: parameters or buffers were modified between an eval-mode forward and its backward')
+        tape = _Tape()
+        _darknet_fwd(tape, ctx.dnn, ctx.x, ctx.params, frozen=True)      # recompute with frozen BatchNorm statistics, keeping the activations
+        return _darknet_bwd(tape, dout)
 
 
 # ------------------------------------------------------------------------------------------------ head
@@ -483,7 +691,7 @@ def inference_forward(inference, feature):
 
 class RegionLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, iou, co, sn, logits, yx_min, yx_max, gt_min, gt_max, gt_cls, anchors_dev, rows, cols, threshold):
+    def forward(ctx, iou, co, sn, logits, yx_min, yx_max, gt_min, gt_max, gt_cls, anchors_dev, rows, cols, threshold, reducer=None):
         L = _hip.lib()
         dev = iou.device
         B, cells, A = iou.shape
@@ -511,7 +719,7 @@ class RegionLossFn(torch.autograd.Function):
         if SYNC_POSITIVES and cls_i is not None:
             # exact data-parallel parity of the cls term (mean over positives, model/__init__.py:162): global positive count
             npos = sums[5:6]
-            if _sum_over_ranks(npos):
+            if _sum_over_ranks(npos, reducer):
                 _hip.check(L.y2_region_loss_finalize(_hip.ptr(sums), float(B * n), 1, _hip.ptr(out), _hip.stream()), 'y2_region_loss_finalize')
         ctx.saved = (iou, co, sn, lg, gt_min, gt_max, cls_i, cls_oh, anchors_dev, best_iou, best_idx, positive, sums)
         ctx.geom = (B, rows, cols, A, C, N, float(threshold))
@@ -532,7 +740,44 @@ class RegionLossFn(torch.autograd.Function):
                                         _hip.ptr(cls_i), _hip.ptr(cls_oh), _hip.ptr(anchors_dev), B, rows, cols, A, C, N, thr,
                                         _hip.ptr(best_iou), _hip.ptr(best_idx), _hip.ptr(positive), _hip.ptr(sums), _hip.ptr(w),
                                         _hip.ptr(d_iou), _hip.ptr(d_co), _hip.ptr(d_sn), _hip.ptr(d_lg), _hip.stream()), 'y2_region_loss_bwd')
-        return (d_iou, d_co, d_sn, d_lg) + (None,) * 9
+        return (d_iou, d_co, d_sn, d_lg) + (None,) * 10
+
+
+class LossDict(dict):
+    """The five loss terms as the reference returns them (model/__init__.py:165-167: one-element tensors keyed foreground /
+    background / center / size [/ cls]); `vector` is the tensor they are slices of - `weighted_total` sums over it with one launch."""
+    vector = None
+
+
+class _LazyDebug(object):
+    """The reference's debug dict (model/__init__.py:167: iou, data, positive, negative), consumed by the TensorBoard summaries
+    only: every entry is computed at first access instead of costing 7 launches in every training step."""
+
+    def __init__(self, makers):
+        self._makers, self._values = makers, {}
+
+    def __getitem__(self, key):
+        if key not in self._values:
+            self._values[key] = self._makers[key]()
+        return self._values[key]
+
+    def __contains__(self, key):
+        return key in self._makers
+
+    def __iter__(self):
+        return iter(self._makers)
+
+    def __len__(self):
+        return len(self._makers)
+
+    def keys(self):
+        return self._makers.keys()
+
+    def items(self):
+        return [(k, self[k]) for k in self._makers]
+
+    def get(self, key, default=None):
+        return self[key] if key in self._makers else default
 
 
 def loss(anchors, data, pred, threshold):
@@ -546,22 +791,62 @@ def loss(anchors, data, pred, threshold):
     dev = iou.device
     gt_min, gt_max, gt_cls = (data[k].to(dev) for k in ('yx_min', 'yx_max', 'cls'))
     out, best_iou, best_idx, positive = RegionLossFn.apply(iou, pred['center_offset'], pred['size_norm'], logits, pred['yx_min'], pred['yx_max'],
-                                                           gt_min, gt_max, gt_cls, anchors_dev, rows, cols, threshold)
-    result = dict(foreground=out[0:1], background=out[1:2], center=out[2:3], size=out[3:4])
+                                                           gt_min, gt_max, gt_cls, anchors_dev, rows, cols, threshold,
+                                                           getattr(pred['feature'], DP_TAG, None))
+    result = LossDict(foreground=out[0:1], background=out[1:2], center=out[2:3], size=out[3:4])
     if logits is not None:
         result['cls'] = out[4:5]
-    positive_b = positive.bool()
-    negative = ~positive_b & (best_iou < threshold)
-    # debug dict of the reference (:167): matched data gathered per slot (plumbing for summaries, not on the hot path)
-    B = iou.shape[0]
-    flat = best_idx.view(B, -1).long()
-    _data = {}
-    for key, t in (('yx_min', gt_min), ('yx_max', gt_max), ('cls', gt_cls)):
-        if t.dim() == 2:
-            _data[key] = torch.gather(t, 1, flat).view(*best_idx.shape)
-        else:
-            _data[key] = torch.gather(t, 1, flat.unsqueeze(-1).expand(-1, -1, t.shape[-1])).view(*best_idx.shape, -1)
-    return result, dict(iou=best_iou, data=_data, positive=positive_b, negative=negative)
+    result.vector = out
+
+    def matched():
+        # matched ground truth gathered per slot (plumbing for summaries, not on the hot path)
+        B = iou.shape[0]
+        flat = best_idx.view(B, -1).long()
+        _data = {}
+        for key, t in (('yx_min', gt_min), ('yx_max', gt_max), ('cls', gt_cls)):
+            if t.dim() == 2:
+                _data[key] = torch.gather(t, 1, flat).view(*best_idx.shape)
+            else:
+                _data[key] = torch.gather(t, 1, flat.unsqueeze(-1).expand(-1, -1, t.shape[-1])).view(*best_idx.shape, -1)
+        return _data
+    debug = _LazyDebug(dict(iou=lambda: best_iou, data=matched, positive=lambda: positive.bool(),
+                            negative=lambda: ~positive.bool() & (best_iou < threshold)))
+    return result, debug
+
+
+_HPARAM_DEV = {}
+
+
+class _WeightedTotalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vector, weights):
+        total = torch.empty(1, dtype=torch.float32, device=vector.device)
+        _hip.check(_hip.lib().y2_small_dot(_hip.ptr(vector), _hip.ptr(weights), vector.numel(), _hip.ptr(total), _hip.stream()), 'y2_small_dot')
+        ctx.weights = weights
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        out = torch.empty_like(ctx.weights)
+        _hip.check(_hip.lib().y2_small_scale(_hip.ptr(_hip.f32c(g)), _hip.ptr(ctx.weights), out.numel(), _hip.ptr(out), _hip.stream()), 'y2_small_scale')
+        return out, None
+
+
+def weighted_total(loss_, hparam):
+    """`sum(loss[key] * hparam[key] for key in loss)` (train.py:348-349) as one launch over the loss vector (a one-element tensor,
+    like the reference's sum); any other mapping takes the reference's expression literally."""
+    vec = getattr(loss_, 'vector', None)
+    keys = list(loss_)
+    if vec is None or not vec.is_cuda or keys != ['foreground', 'background', 'center', 'size', 'cls'][:len(keys)]:
+        return sum(loss_[key] * hparam[key] for key in loss_)
+    w = tuple(float(hparam[k]) for k in keys) + (0.0,) * (vec.numel() - len(keys))
+    key = (w, str(vec.device))
+    wd = _HPARAM_DEV.get(key)
+    if wd is None:
+        if len(_HPARAM_DEV) > 64:
+            _HPARAM_DEV.clear()
+        wd = _HPARAM_DEV[key] = torch.tensor(w, dtype=torch.float32, device=vec.device)
+    return _WeightedTotalFn.apply(vec, wd)
 
 
 # ------------------------------------------------------------------------------------------------ ResNet plugins
@@ -571,16 +856,17 @@ class _ROp(object):
                  'residual', 'y', 'slope', 'first', 'pool')       # pool = (ksize, stride, pad, pad_end) of a 'pool' op
 
 
-def resnet_forward(net, x):
+def resnet_forward(net, x, frozen=False):
+    """frozen: eval()-mode BatchNorm (running statistics, nothing updated) with autograd recording."""
     params = [p for p in net.parameters()]
-    out = ResNetTrainFn.apply(net, x, *params)
+    out = ResNetTrainFn.apply(net, x, frozen, *params)
     return out.permute(0, 3, 1, 2)
 
 
-def tiny_forward(net, x):
+def tiny_forward(net, x, frozen=False):
     """Training-mode forward of model.yolo2.Tiny (model/yolo2.py:140-173) through the same op-list graph as the ResNets."""
     params = [p for p in net.parameters()]
-    out = ResNetTrainFn.apply(net, x, *params)
+    out = ResNetTrainFn.apply(net, x, frozen, *params)
     return out.permute(0, 3, 1, 2)
 
 
@@ -608,8 +894,10 @@ class ResNetTrainFn(torch.autograd.Function):
     MOMENTUM = 0.1
 
     @staticmethod
-    def forward(ctx, net, x, *params):
+    def forward(ctx, net, x, frozen, *params):
         _hip.require_gpu(x)
+        if x.requires_grad:
+            raise RuntimeError('model: the gradient with respect to the input image is not implemented; detach the input')
         L = _hip.lib()
         st = _hip.stream()
         x = _hip.f32c(x.detach())
@@ -618,6 +906,7 @@ class ResNetTrainFn(torch.autograd.Function):
             raise ValueError('input size must be a multiple of 32 (got %dx%d)' % (H, W))
         dev = x.device
         ops = []
+        ctx.frozen = frozen
         cpad = (cin0 + 3) // 4 * 4
         x4 = _new(dev, B, H, W, cpad)
         _hip.check(L.y2_nchw_to_nhwc(_hip.ptr(x), _hip.ptr(x4), B, cin0, H, W, cpad, st), 'y2_nchw_to_nhwc')
@@ -636,21 +925,25 @@ class ResNetTrainFn(torch.autograd.Function):
             _hip.check(L.y2_pack_weight(_hip.ptr(weight), _hip.ptr(wp), cout, ldx, k, 0, st), 'y2_pack_weight')
             ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
             z = _new(dev, B, ho, wo, cout)
-            stats = torch.zeros(_hip.STATS_REPL * 2 * cout, dtype=torch.float64, device=dev) if bn is not None else None
+            stats = torch.zeros(_hip.STATS_REPL * 2 * cout, dtype=torch.float64, device=dev) if (bn is not None and not frozen) else None
             det = _hip.ensure_deterministic(dev)
             _gen_conv(L, st, xin, wp, z, B, h, w, ldx, ldx, cout, k, stride, pad, stats=None if det else stats)
             if det and stats is not None:
                 _hip.colstats_det(z, B * ho * wo, cout, cout, stats)
             op.kind, op.conv, op.bn, op.x, op.ldx, op.h, op.w, op.ho, op.wo = 'conv', conv, bn, xin, ldx, h, w, ho, wo
             op.stride, op.pad, op.k, op.cin, op.cout, op.z, op.residual, op.slope, op.first = stride, pad, k, cin_true, cout, z, residual, slope, first
-            if bn is not None:
+            if bn is not None and frozen:
+                op.scale, op.shift = _new(dev, cout), _new(dev, cout)
+                _hip.check(L.y2_bn_fold(_hip.ptr(_hip.f32c(bn.weight.detach())), _hip.ptr(_hip.f32c(bn.bias.detach())), _hip.ptr(_hip.f32c(bn.running_mean)),
+                                        _hip.ptr(_hip.f32c(bn.running_var)), BN_EPS, _hip.ptr(op.scale), _hip.ptr(op.shift), cout, st), 'y2_bn_fold')
+                op.mean, op.invstd = _hip.f32c(bn.running_mean), torch.rsqrt(_hip.f32c(bn.running_var) + BN_EPS)
+            elif bn is not None:
                 op.scale, op.shift, op.mean, op.invstd = (_new(dev, cout) for _ in range(4))
                 _hip.check(L.y2_bn_finalize(_hip.ptr(stats), float(B * ho * wo), _hip.ptr(bn.weight.detach()), _hip.ptr(bn.bias.detach()),
                                             _hip.ptr(bn.running_mean), _hip.ptr(bn.running_var), ResNetTrainFn.MOMENTUM if momentum is None else momentum, BN_EPS,
-                                            _hip.ptr(op.scale), _hip.ptr(op.shift), _hip.ptr(op.mean), _hip.ptr(op.invstd), cout, st), 'y2_bn_finalize')
-                _hip.mutated()
-                if bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked += 1
+                                            _hip.ptr(op.scale), _hip.ptr(op.shift), _hip.ptr(op.mean), _hip.ptr(op.invstd), cout,
+                                            _hip.ptr(_counter(bn)), st), 'y2_bn_finalize')
+                _hip.wrote([t for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked) if t is not None])      # written through raw pointers
             else:
                 op.scale = op.mean = op.invstd = None
                 op.shift = _hip.f32c(conv.bias.detach()) if conv.bias is not None else None
@@ -745,7 +1038,7 @@ class ResNetTrainFn(torch.autograd.Function):
                                           _hip.ptr(srcs[0]), cout, 0, 0, None, 0, 0,
                                           _hip.ptr(srcs[1]) if len(srcs) > 1 else None, cout,
                                           _hip.ptr(op.residual), cout if op.residual is not None else 0, _hip.ptr(dres), cout,
-                                          _hip.ptr(sums), _hip.ptr(dz), cop, B, ho, wo, cout, cout, int(has_bn), st), 'y2_bn_act_bwd_ex')
+                                          _hip.ptr(sums), _hip.ptr(dz), cop, B, ho, wo, cout, cout, (2 if ctx.frozen else 1) if has_bn else 0, st), 'y2_bn_act_bwd_ex')
             if op.residual is not None:
                 G.setdefault(id(op.residual), []).append(dres)
             if has_bn:
@@ -783,7 +1076,7 @@ class ResNetTrainFn(torch.autograd.Function):
             else:
                 _gen_conv(L, st, dz, wd, dx, B, ho, wo, cop, cop, cin, k, op.stride, op.pad, transposed=True, out_hw=(op.h, op.w))
             G.setdefault(id(op.x), []).append(dx)
-        out = [None, None]
+        out = [None, None, None]
         for pid in ctx.param_ids:
             out.append(grads.get(pid))
         ctx.ops = None

@@ -112,7 +112,7 @@ class Darknet(nn.Module):
                                      Conv2d(c_mix, model.output_channels(len(anchors), num_cls), 1, bn=False, act=False))
         self.init()
         self._cache = None  # packed weights / folded BN for eval, keyed on parameter versions
-        self._plan_cache = None
+        self._plans = _hip.PlanCache()  # execution plans (intermediate buffers + y2_conv_params arrays) per input shape, LRU
         self.grad_ready_hook = None  # set by train.DataParallelRCCL: called as hook(param, grad) inside backward, layer by layer
         self.profile = None  # tools: list receiving (kernel, flops, start_event, end_event) per conv launch
 
@@ -146,9 +146,26 @@ class Darknet(nn.Module):
         return self.layers1[0]
 
     def _versions(self):
-        """Cache key of everything derived from the parameters: torch's version counters plus the library's mutation epoch
-        (raw-pointer writers - utils.optim, y2_bn_finalize - are invisible to `_version`)."""
-        return (_hip.epoch(),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        """Cache key of everything derived from the parameters and buffers: (address, torch version counter) per tensor.  The
+        raw-pointer writers (utils.optim, y2_bn_finalize) advance the counters of what they wrote through _hip.wrote, so the key is
+        per tensor and per model: training another model does not touch it."""
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def _weight_versions(self):
+        """Cache key of what is derived from the convolution weights alone (the training step's GEMM operands): BatchNorm buffer
+        updates of a forward pass do not move it."""
+        return tuple((m.conv.weight.data_ptr(), m.conv.weight._version) for m in self.modules() if isinstance(m, Conv2d))
+
+    @property
+    def _plan_cache(self):
+        """(tools / bench) the most recently used plan as (key, plan), None before the first forward."""
+        plan = self._plans.latest()
+        return None if plan is None else (plan['key'], plan)
+
+    @_plan_cache.setter
+    def _plan_cache(self, value):
+        assert value is None
+        self._plans.clear()
 
     def _prepare_eval(self, device):
         """Pack weights to [Cout][tap][Cin] and fold BN once per parameter version (y2_pack_weight / y2_bn_fold)."""
@@ -202,19 +219,35 @@ class Darknet(nn.Module):
     def _plan(self, prep, dev, B, cin0, H, W):
         """Execution plan for one input shape: intermediate NHWC buffers (never exposed, reused across calls) and the
         y2_conv_params array of the 22 generic convolutions (model/yolo2.py:76-113 in execution order)."""
-        key = (id(prep), dev, B, cin0, H, W)
-        if self._plan_cache is not None and self._plan_cache[0] == key:
-            return self._plan_cache[1]
-        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        key = (str(dev), B, cin0, H, W, _hip.tune_epoch(), _hip.WINOGRAD, _hip.FORCE_ALGO)
+        plan = self._plans.get(key)
+        if plan is not None:
+            if plan['prep'] is not prep:
+                # same shape, new parameter version (a training step ran in between): the buffers, algorithms and tiles stay, only the
+                # operand pointers of the packed / folded / transformed weights move
+                for p, blk in zip(plan['arr'], plan['blks']):
+                    wp, scale, shift, u = prep[blk]
+                    p.w = (u if p.algo in (1, 2, 3) else wp).data_ptr()
+                    p.scale = scale.data_ptr() if scale is not None else None
+                    p.shift = shift.data_ptr() if shift is not None else None
+                plan['prep'] = prep
+            return plan
+        nbytes = [0]
+
+        def new(*s):
+            t = torch.empty(*s, dtype=torch.float32, device=dev)
+            nbytes[0] += t.numel() * 4
+            return t
         b1, b2, b3 = self._blocks()
         plist, flops, keep = [], 0.0, []
 
-        ulist = []
+        ulist, blks = [], []
 
         def add(blk, *args, **kw):
             p, f = self._conv_params(prep, blk, *args, **kw)
             plist.append(p)
             ulist.append(prep[blk][3])
+            blks.append(blk)
             return f
         name, blk0, pool = b1[0]
         c = blk0.conv.weight.shape[0]
@@ -277,10 +310,10 @@ class Darknet(nn.Module):
         # multiply-adds the MFMA pipe really executes: a Winograd layer runs 16 GEMMs over ceil(H/2)*ceil(W/2) tiles per image
         executed = sum(2.0 * p.Cin * p.Cout * (16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2, 3) else p.ksize ** 2 * p.B * p.H * p.W)
                        for p in plist)
-        plan = dict(arr=arr, n=len(plist), first=first, head_index=head_index, head_shape=head_shape, flops=flops, flops_executed=executed,
-                    algos=[int(p.algo != 0) for p in plist],
-                    flops0=2.0 * cin0 * blk0.conv.weight.shape[0] * 9 * B * H * W, keep=(keep, full_last, cat, prep, ws))
-        self._plan_cache = (key, plan)
+        plan = dict(key=key, arr=arr, n=len(plist), first=first, head_index=head_index, head_shape=head_shape, flops=flops, flops_executed=executed,
+                    algos=[int(p.algo != 0) for p in plist], blks=blks, prep=prep,
+                    flops0=2.0 * cin0 * blk0.conv.weight.shape[0] * 9 * B * H * W, keep=(keep, full_last, cat, ws))
+        self._plans.put(key, plan, nbytes[0])
         return plan
 
     def forward_nhwc(self, x):
@@ -319,10 +352,15 @@ class Darknet(nn.Module):
     def forward(self, x):
         # BN semantics follow self.training alone, like nn.BatchNorm2d (model/yolo2.py:58): train() mode normalises with batch
         # statistics and updates the running ones whether or not autograd is recording (under no_grad the graph is simply
-        # not taped); eval() mode runs the folded-BN inference chain, which is not differentiable (it returns no grad_fn).
+        # not taped); eval() mode runs the folded-BN inference chain - and stays differentiable like any nn.Module when autograd is
+        # recording (frozen-BatchNorm fine-tuning; the reference back-propagates through `dnn` in eval mode,
+        # receptive_field_analyzer.py:67,87): the backward then re-runs the layers with frozen statistics (train_graph).
         if self.training:
             from model import train_graph  # training graph (autograd.Function over the HIP kernels)
             return train_graph.darknet_forward(self, x)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from model import train_graph
+            return train_graph.darknet_forward_eval_grad(self, x)
         with torch.no_grad():
             out = self.forward_nhwc(x)
         # NCHW view of the NHWC head image: same values/shape as the reference's output; model.Inference's
@@ -363,7 +401,7 @@ class Tiny(Darknet):
         self.layers = nn.Sequential(*mods)
         self.init()
         self._cache = None
-        self._plan_cache = None
+        self._plans = _hip.PlanCache()
         self.grad_ready_hook = None
         self.profile = None
 
@@ -423,6 +461,9 @@ class Tiny(Darknet):
         if self.training:
             from model import train_graph
             return train_graph.tiny_forward(self, x)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from model import train_graph
+            return train_graph.tiny_forward(self, x, frozen=True)      # differentiable eval mode: the op-list graph with frozen statistics
         with torch.no_grad():
             out = self.forward_nhwc(x)
         return out.permute(0, 3, 1, 2)

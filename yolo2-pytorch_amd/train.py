@@ -27,11 +27,19 @@ import utils
 BUCKET_BYTES = 25 * 1024 * 1024
 
 
+_SCALES = {}
+
+
 def norm_data(data, height, width, rows, cols, keys='yx_min, yx_max'):
     """train.py:57-62: ground-truth boxes from pixels to grid-cell units."""
     _data = {key: data[key] for key in data}
     t = _data[keys.split(', ')[0]]
-    scale = torch.tensor([rows / height, cols / width], dtype=torch.float32, device=t.device).view(1, 1, 2)
+    key = (rows / height, cols / width, str(t.device))
+    scale = _SCALES.get(key)        # (a per-call host -> device copy of two floats from pageable memory is a synchronous copy)
+    if scale is None:
+        if len(_SCALES) > 256:
+            _SCALES.clear()
+        scale = _SCALES[key] = torch.tensor(key[:2], dtype=torch.float32, device=t.device).view(1, 1, 2)
     for key in keys.split(', '):
         _data[key] = _data[key] * scale
     return _data
@@ -73,38 +81,47 @@ class DataParallelRCCL(nn.Module):
         self._pending = False
         for p in self._params:
             p.register_post_accumulate_grad_hook(self._late_hook)
-        # modules whose backward produces gradients layer by layer announce them early (overlap with compute)
+        # modules whose backward produces gradients layer by layer announce them early (overlap with compute) and may write them
+        # straight into the flat buckets (grad_buffer_hook: no copy into the bucket)
         for m in module.modules():
             if hasattr(m, 'grad_ready_hook'):
                 m.grad_ready_hook = self._early_hook
-        # the region loss sums its positive count over THIS group (model/__init__.py:162: mean over the positives of the global batch)
-        from model import train_graph
-        train_graph.DP_ALL_REDUCE = self._sum_small
+                m.grad_buffer_hook = self._grad_buffer
+        self._shape_calls = {}
 
     tune_synced = None
-    SYNC_TUNE_AT = 4        # forward call at which every rank adopts rank 0's measured algorithm choices (after 3 whole steps)
+    SYNC_TUNE_AT = 4        # forward call WITH A GIVEN INPUT SHAPE at which every rank adopts rank 0's measured algorithm choices (after 3 whole steps at that shape)
     _calls = 0
 
     def _sync_tune(self):
-        """Each rank times its kernels itself during the first steps; near-ties resolve differently from rank to rank, and the step
-        time of the job is the slowest rank's.  One broadcast of rank 0's table makes the plans identical."""
-        try:
-            import _hip
-            dev = next((p.device for p in self._params if p.is_cuda), None)
-            if dev is None:
-                return
-            first = dist.get_rank(self.pg) == 0
-            src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0      # (None = the default group: rank 0 is rank 0)
-            box = [_hip.export_tune() if first else None]
-            if self._staged:
-                dist.broadcast_object_list(box, src=src, group=self.pg)
-            else:
-                dist.broadcast_object_list(box, src=src, group=self.pg, device=dev)
-            if not first:
+        """Each rank times its kernels itself during the first steps at a new input shape; near-ties resolve differently from rank
+        to rank, and the step time of the job is the slowest rank's.  One broadcast of rank 0's table makes the plans identical.
+        Every rank reaches the collective (the input shapes of a step are the same on all ranks: utils/data.py:135-141 resizes the
+        whole batch); whatever can fail locally happens outside it and degrades to "keep my own choices"."""
+        import _hip
+        dev = next((p.device for p in self._params if p.is_cuda), None)
+        first = dist.get_rank(self.pg) == 0
+        src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0      # (None = the default group: rank 0 is rank 0)
+        table = None
+        if first:
+            try:
+                table = _hip.export_tune()
+            except Exception as e:
+                logging.warning('autotune choices not exported: %s' % e)
+        box = [table]
+        if self._staged or dev is None:
+            dist.broadcast_object_list(box, src=src, group=self.pg)
+        else:
+            dist.broadcast_object_list(box, src=src, group=self.pg, device=dev)
+        if box[0] is None or dev is None:
+            return
+        if not first:
+            try:
                 _hip.import_tune(box[0], dev)
-            self.tune_synced = len(box[0])
-        except Exception as e:      # never fatal: the ranks keep their own choices
-            logging.warning('autotune choices not synchronised: %s' % e)
+            except Exception as e:      # never fatal: this rank keeps its own choices
+                logging.warning('autotune choices not adopted: %s' % e)
+                return
+        self.tune_synced = len(box[0])
 
     def _all_reduce(self, t):
         if t.is_cuda and self._staged:
@@ -156,7 +173,33 @@ class DataParallelRCCL(nn.Module):
     def _start(self):
         if not self._pending:
             self._pending = True
+            # a second backward without a forward() in between (two outputs, retain_graph): gradients of the first are still the
+            # bucket slices this backward is about to rewrite - give the caller private copies and treat them as accumulated
+            had = None
+            for q in self._params:
+                if q.grad is not None and q.grad is self._views.get(id(q)):
+                    q.grad = q.grad.clone()
+                    had = self._had if isinstance(self._had, set) else set(self._had)
+                    had.add(id(q))
+                    self._had = had
+                    del self._views[id(q)]
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+
+    def _grad_buffer(self, p):
+        """Where the averaged gradient of `p` will live: its slice of the flat bucket.  A backward that writes the gradient there
+        (model.train_graph) saves the copy into the bucket; None = not this time (an accumulating caller, a moved module, a
+        parameter this wrapper does not reduce)."""
+        w = self._where.get(id(p))
+        if w is None or id(p) in self._done or id(p) in self._had:
+            return None
+        self._start()
+        if p.grad is not None:
+            return None
+        bi, off = w
+        flat = self._flat[bi]
+        if flat.device != p.device or flat.dtype != p.dtype:
+            return None
+        return flat[off:off + p.numel()].view_as(p)
 
     def _launch_bucket(self, bi):
         """Zero the slots (and flags) of parameters without a gradient this step, then start the bucket's all-reduce.  EVERY
@@ -179,7 +222,9 @@ class DataParallelRCCL(nn.Module):
         bi, off = self._where[id(p)]
         if self._flat[bi].device != g.device:       # the module moved (train.py:423-432: .cpu() for evaluation, .cuda() to resume)
             self._flat[bi] = self._flat[bi].to(g.device)
-        self._flat[bi][off:off + p.numel()].copy_(g.reshape(-1))
+        slot = self._flat[bi][off:off + p.numel()]
+        if g.data_ptr() != slot.data_ptr() or g.numel() != slot.numel() or not g.is_contiguous():      # (else: written in place through _grad_buffer)
+            slot.copy_(g.reshape(-1))
         self._done.add(id(p))
         self._ready[bi] += 1
         while self._next < len(self._buckets) and self._ready[self._next] == len(self._buckets[self._next]):
@@ -238,8 +283,11 @@ class DataParallelRCCL(nn.Module):
         self._pending = False
         self._reset()
         self._calls += 1
-        if self._calls == self.SYNC_TUNE_AT and self.world > 1:
-            self._sync_tune()
+        if self.world > 1:
+            shape = tuple(tuple(a.shape) for a in args if isinstance(a, torch.Tensor))
+            seen = self._shape_calls[shape] = self._shape_calls.get(shape, 0) + 1
+            if seen == self.SYNC_TUNE_AT:       # a new input size (multi-scale training) was tuned by every rank for 3 steps: adopt rank 0's table
+                self._sync_tune()
         # gradients the caller kept from earlier steps (accumulation: no zero_grad): a kept gradient that is a bucket slice (see
         # _finalize) becomes a private copy before this step's _fill rewrites the bucket, and _had remembers who accumulates
         self._had = set()
@@ -249,7 +297,14 @@ class DataParallelRCCL(nn.Module):
                     q.grad = q.grad.clone()
                 self._had.add(id(q))
         self._views = {}
-        return self.module(*args, **kwargs)
+        out = self.module(*args, **kwargs)
+        # the region loss sums its positive count over THIS wrapper's group (model/__init__.py:162: mean over the positives of the
+        # global batch): the reducer travels with the predictions (model.train_graph.DP_TAG)
+        from model import train_graph
+        for t in (out if isinstance(out, (tuple, list)) else (out,)):
+            if isinstance(t, torch.Tensor):
+                setattr(t, train_graph.DP_TAG, self._sum_small)
+        return out
 
 
 def init_distributed():
@@ -287,7 +342,7 @@ def iterate(inference, optimizer, data, loss_hparam, threshold, anchors, clip=No
     height, width = tensor.size()[-2:]
     rows, cols = pred['feature'].size()[-2:]
     loss, debug = model.loss(anchors, norm_data(data, height, width, rows, cols), pred, threshold)
-    loss_total = sum(loss[key] * loss_hparam[key] for key in loss)
+    loss_total = model.weighted_total(loss, loss_hparam)      # = sum(loss[key] * loss_hparam[key] for key in loss), one launch
     optimizer.zero_grad()
     loss_total.backward()
     if clip is not None:

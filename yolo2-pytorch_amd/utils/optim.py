@@ -66,12 +66,14 @@ class SGD(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _hip.lib()
+        written = []
         for group in self.param_groups:
             fresh, seasoned = [], []
             for p in group['params']:
                 if p.grad is None:
                     continue
                 g = _grad(p)
+                written.append(p)
                 buf = None
                 first = False
                 if group['momentum'] != 0:
@@ -85,7 +87,8 @@ class SGD(torch.optim.Optimizer):
                 if rows:
                     _launch(L.y2_opt_sgd, rows, group['lr'], group['momentum'], group['dampening'], group['weight_decay'],
                             int(group['nesterov']), first)
-        _hip.mutated()      # parameters were written through raw pointers: packed-weight caches must not survive
+        if written:
+            _hip.wrote(written)      # parameters were written through raw pointers: advance their version counters (packed-weight caches key on them)
         return loss
 
 
@@ -106,12 +109,14 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _hip.lib()
+        written = []
         for group in self.param_groups:
             by_step = {}
             for p in group['params']:
                 if p.grad is None:
                     continue
                 g = _grad(p)
+                written.append(p)
                 state = self.state[p]
                 if len(state) == 0:
                     state['step'] = torch.tensor(0.0)          # host counter, torch.optim's layout
@@ -122,7 +127,8 @@ class Adam(torch.optim.Optimizer):
             b1, b2 = group['betas']
             for step, rows in by_step.items():
                 _launch(L.y2_opt_adam, rows, group['lr'], b1, b2, group['eps'], group['weight_decay'], step)
-        _hip.mutated()
+        if written:
+            _hip.wrote(written)
         return loss
 
 
