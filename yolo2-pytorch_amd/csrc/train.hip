@@ -372,10 +372,13 @@ __device__ __forceinline__ float iou_box(float ymin1, float xmin1, float ymax1, 
 // model.iou_match (model/__init__.py:59-73): best IoU of every (cell, anchor) slot over the image's GT boxes; first max.
 __global__ __launch_bounds__(256) void loss_match_kernel(const float* __restrict__ yx_min, const float* __restrict__ yx_max,
                                                          const float* __restrict__ gt_min, const float* __restrict__ gt_max,
-                                                         int n, int N, float* best_iou, int32_t* best_idx) {
+                                                         int n, int N, float* best_iou, int32_t* best_idx, uint8_t* positive, double* sums) {
     __shared__ float g[4 * 256];
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    // first kernel of the loss: it also clears what the following kernels accumulate into (no memset launches)
+    if (blockIdx.x == 0 && b == 0 && threadIdx.x < 6) sums[threadIdx.x] = 0.0;
+    if (i < n) positive[(size_t)b * n + i] = 0;
     float y0 = 0, x0 = 0, y1 = 0, x1 = 0;
     if (i < n) {
         const size_t o = ((size_t)b * n + i) * 2;
@@ -704,11 +707,7 @@ extern "C" int y2_region_loss_fwd(const float* iou, const float* center_offset, 
     if (C > 0 && !logits) return Y2_EINVAL;
     const int n = rows * cols * A;
     hipStream_t s = y2_s(stream);
-    hipError_t e = hipMemsetAsync(positive, 0, (size_t)B * n, s);
-    if (e != hipSuccess) return -(1000 + (int)e);
-    e = hipMemsetAsync(sums, 0, 6 * sizeof(double), s);
-    if (e != hipSuccess) return -(1000 + (int)e);
-    Y2_LAUNCH("loss_match_kernel", 0.0, loss_match_kernel, dim3(y2_cdiv(n, 256), B), dim3(256), 0, s, yx_min, yx_max, gt_yx_min, gt_yx_max, n, N, best_iou, best_idx);
+    Y2_LAUNCH("loss_match_kernel", 0.0, loss_match_kernel, dim3(y2_cdiv(n, 256), B), dim3(256), 0, s, yx_min, yx_max, gt_yx_min, gt_yx_max, n, N, best_iou, best_idx, positive, sums);
     Y2_LAUNCH("loss_positive_kernel", 0.0, loss_positive_kernel, dim3(y2_cdiv((long long)B * N, 256)), dim3(256), 0, s, gt_yx_min, gt_yx_max, anchors, B, N, rows, cols, A, positive);
     LossArgs a;
     a.iou = iou; a.co = center_offset; a.sn = size_norm; a.logits = logits; a.best_iou = best_iou; a.best_idx = best_idx; a.positive = positive;

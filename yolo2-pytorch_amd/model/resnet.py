@@ -171,7 +171,7 @@ class ResNet(nn.Module):
             t = torch.empty(*s, dtype=torch.float32, device=dev)
             nbytes[0] += t.numel() * 4
             return t
-        keep, flops, ulist, convs = [], [0.0], {}, []
+        keep, flops, ulist, conv_order = [], [0.0], {}, []
 
         def conv_params(conv, x, h, w, ldx, y, stride, pad, slope, residual=None):
             wp, scale, shift, cin, cout, k = prep[conv]
@@ -183,7 +183,7 @@ class ResNet(nn.Module):
             p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize = B, h, w, cin, ldx, cout, k
             p.stride, p.pad_plus1, p.slope, p.tile = stride, pad + 1, slope, 0
             ulist[id(p)] = prep['wino'].get(id(wp))
-            convs.append(conv)
+            conv_order.append(conv)
             if residual is not None:
                 p.residual, p.ldr = residual.data_ptr(), cout
             ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
@@ -233,7 +233,7 @@ class ResNet(nn.Module):
             p.workspace, p.workspace_bytes = (ws.data_ptr(), ws.numel() * 4) if ws is not None else (None, 0)
         arr = (_hip.ConvParams * len(plist))(*plist)
         plan = dict(key=key, x4=x4, cpad=cpad, stem=p_stem, stem_out=stem, stem_hw=(h1, w1, c1), pooled=pooled, arr=arr, n=len(plist), head_index=head_index,
-                    head_shape=head_shape, flops=flops[0], convs=convs, prep=prep, keep=(keep, ws))
+                    head_shape=head_shape, flops=flops[0], convs=conv_order, prep=prep, keep=(keep, ws))
         self._plans.put(key, plan, nbytes[0])
         return plan
 

@@ -556,8 +556,10 @@ def _darknet_bwd(ctx, dout):
             else:
                 wsrc = e.w
                 if cop != cout:
-                    wpad = torch.zeros(cop, cin, k, k, dtype=torch.float32, device=dev)
-                    wpad[:cout] = wsrc                                   # zero rows for the padded output channels
+                    wpad = bufs[1].get((blk.name, 'wpad'))               # zero rows for the padded output channels: written once, kept
+                    if wpad is None or wpad.shape != (cop, cin, k, k):
+                        wpad = bufs[1][(blk.name, 'wpad')] = torch.zeros(cop, cin, k, k, dtype=torch.float32, device=dev)
+                    _hip.multi([(_hip.MULTI_COPY, wpad[:cout], wsrc)], st)
                     wsrc = wpad
                 wd = _new(dev, wsrc.numel())
                 _hip.check(L.y2_pack_weight(_hip.ptr(wsrc), _hip.ptr(wd), cop, cin, k, 1, st), 'y2_pack_weight')
@@ -662,6 +664,7 @@ class DecodeFn(torch.autograd.Function):
         ctx.save_for_backward(iou, co)
         ctx.shape = (B, rows, cols, A, C)
         ctx.mark_non_differentiable(mn, mx)
+        ctx.set_materialize_grads(False)      # (autograd would launch a zero fill per unused / non-differentiable output)
         return iou, co, sn, mn, mx, logits
 
     @staticmethod
@@ -672,6 +675,12 @@ class DecodeFn(torch.autograd.Function):
         dev = iou.device
         df = _new(dev, B, rows, cols, A * (5 + C))
         c = lambda t: _hip.f32c(t) if t is not None else None
+        if d_iou is None:
+            d_iou = torch.zeros_like(iou)
+        if d_co is None:
+            d_co = torch.zeros_like(co)
+        if d_sn is None:
+            d_sn = torch.zeros_like(co)
         d_iou, d_co, d_sn = c(d_iou), c(d_co), c(d_sn)
         d_logits = c(d_logits) if (C > 0 and d_logits is not None) else None
         _hip.check(L.y2_decode_bwd(_hip.ptr(iou), _hip.ptr(co), _hip.ptr(d_iou), _hip.ptr(d_co), _hip.ptr(d_sn), _hip.ptr(d_logits),
@@ -724,6 +733,7 @@ class RegionLossFn(torch.autograd.Function):
         ctx.saved = (iou, co, sn, lg, gt_min, gt_max, cls_i, cls_oh, anchors_dev, best_iou, best_idx, positive, sums)
         ctx.geom = (B, rows, cols, A, C, N, float(threshold))
         ctx.mark_non_differentiable(best_iou, best_idx, positive)
+        ctx.set_materialize_grads(False)
         return out, best_iou, best_idx, positive
 
     @staticmethod
@@ -732,6 +742,8 @@ class RegionLossFn(torch.autograd.Function):
         iou, co, sn, lg, gt_min, gt_max, cls_i, cls_oh, anchors_dev, best_iou, best_idx, positive, sums = ctx.saved
         B, rows, cols, A, C, N, thr = ctx.geom
         dev = iou.device
+        if d_out is None:
+            return (None,) * 14
         w = _hip.f32c(d_out)
         d_iou = torch.empty_like(iou)
         d_co, d_sn = torch.empty_like(co), torch.empty_like(sn)
