@@ -143,6 +143,19 @@ typedef struct y2_conv_params {
 #define Y2_ALGO_WINOGRAD_IMPLICIT 3 /* as FUSED, and the input transform B^T d B happens in that kernel's operand loader: the transformed input
                                       (4x the input) never goes to memory either.  Cin % 32 == 0, a batch chunk's input < 1 GB.
                                       Bit-identical results to FUSED.  (Leaves no transformed input behind for y2_wino_wgrad.) */
+#define Y2_ALGO_WINOGRAD_SPLIT 4   /* as WINOGRAD (three kernels, fp32 transforms), but the 16 GEMMs run on the bf16 matrix pipe with every fp32 operand
+                                      split into three bf16 planes and six plane products per multiply ("bf16x6", csrc/gemm_split.hip): fp32-level
+                                      accuracy at 2.67x the fp32-MFMA rate.  w = y2_split_bf16x3 of the y2_wino_weight output; Cin % 32 == 0.
+                                      Opt-in precision mode of the Python layer (Y2_SPLIT_BF16=1); never chosen by the library itself. */
+
+/* Three bf16 planes of an fp32 array (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round to nearest even):
+ * dst = [3][n] bf16 (6 n bytes), n % 4 == 0, src 16-B aligned.  The weight operand of Y2_ALGO_WINOGRAD_SPLIT. */
+int y2_split_bf16x3(const float* src, void* dst, long long n, y2_stream_t stream);
+
+/* C[g] (M x N, row stride ldc, fp32) = A[g] (M x K) * B[g]^T (N x K) for g < groups on the bf16 matrix pipe, operands as plane triples
+ * A = [3][groups][M][K], B = [3][groups][N][K] (y2_split_bf16x3 of the fp32 arrays [groups][M][K] / [groups][N][K]); K % 32 == 0.
+ * The GEMM stage of Y2_ALGO_WINOGRAD_SPLIT, exposed for tests and tools. */
+int y2_gemm_split(const void* A, const void* B, float* C, long long M, int32_t N, int32_t K, int32_t ldc, int32_t groups, y2_stream_t stream);
 
 /* Winograd F(2x2,3x3) filter transform U[p][co][ci] = (G g G^T)[p], p = 4*xi + nu, from a packed 3x3 weight
  * (y2_pack_weight mode 0 for the forward conv, mode 1 for the data gradient: [Cout][9][Cin]).  Same role as the cuDNN

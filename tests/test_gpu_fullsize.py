@@ -78,7 +78,7 @@ def test_full_batch_matches_fp64_oracle_on_sampled_images(net, batch, truth):
         assert rel(got[j:j + 1], truth[j:j + 1]) <= 2e-5, (i, rel(got[j:j + 1], truth[j:j + 1]))
 
 
-@pytest.mark.parametrize('algo', ['direct', 'winograd', 'fused', 'implicit'])
+@pytest.mark.parametrize('algo', ['direct', 'winograd', 'fused', 'implicit', 'split'])
 def test_full_batch_under_each_forced_algorithm(net, batch, truth, algo, monkeypatch):
     """Deterministic algorithm coverage of the whole-model path: with autotune out of the picture every eligible 3x3 layer runs the
     direct implicit GEMM / the three-kernel Winograd / the fused Winograd kernel (the rest stays direct), at the full batch-32
@@ -87,17 +87,23 @@ def test_full_batch_under_each_forced_algorithm(net, batch, truth, algo, monkeyp
     inf, anchors, sd = net
     x, feat = batch
     monkeypatch.setattr(_hip, 'FORCE_ALGO', algo)
+    if algo == 'split':
+        monkeypatch.setattr(_hip, 'SPLIT', True)     # the opt-in precision mode (bf16 plane triples): same truth, same tolerance
+        inf.dnn._cache = None                        # ... its weight operands are prepared with the others
     inf.dnn._plan_cache = None
     try:
         with torch.no_grad():
             f = inf.dnn.forward_nhwc(x.to(dev())).clone()
         plan = inf.dnn._plan_cache[1]
         algos = [plan['arr'][i].algo for i in range(plan['n'])]
-        want = {'direct': 0, 'winograd': 1, 'fused': 2, 'implicit': 3}[algo]
+        want = {'direct': 0, 'winograd': 1, 'fused': 2, 'implicit': 3, 'split': 4}[algo]
         assert (max(algos) == want) and (algo == 'direct' or algos.count(want) >= 10), algos     # 13 eligible layers (Cin >= 64)
     finally:
         inf.dnn._plan_cache = None
+        if algo == 'split':
+            inf.dnn._cache = None
     got = f[list(SAMPLED)].permute(0, 3, 1, 2)
+    print('forced plan %s: worst max|err|/rms over the sampled images %.3g' % (algo, max(rel(got[j:j + 1], truth[j:j + 1]) for j in range(len(SAMPLED)))))
     worst = max(rel(got[j:j + 1], truth[j:j + 1]) for j in range(len(SAMPLED)))
     # 2e-5 * rms is the stated tolerance of the production (autotuned) plan, checked above.  A plan that pins ONE algorithm on all 13
     # eligible layers is a stress configuration: the all-direct plan accumulates K = 9*Cin (up to 11520) products sequentially in one

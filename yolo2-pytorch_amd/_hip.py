@@ -59,6 +59,8 @@ SIGNATURES = {
     'y2_abi_version': [],
     'y2_pack_weight': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'y2_prep_weights': [ctypes.POINTER(PrepItem), c_int, c_void_p],
+    'y2_split_bf16x3': [c_void_p, c_void_p, ctypes.c_longlong, c_void_p],
+    'y2_gemm_split': [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, c_void_p],
     'y2_multi': [ctypes.POINTER(MultiItem), c_int, c_void_p],
     'y2_small_dot': [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     'y2_small_scale': [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
@@ -325,9 +327,21 @@ if TUNE_CACHE and os.path.exists(TUNE_CACHE):
 
 
 WINOGRAD = os.environ.get('Y2_WINOGRAD', '1') != '0'     # 0: never pick the Winograd F(2x2,3x3) algorithm
-FORCE_ALGO = os.environ.get('Y2_FORCE_ALGO') or None     # 'direct' | 'winograd' | 'fused' | 'implicit': no autotune, that algorithm wherever the library accepts it
-if FORCE_ALGO not in (None, 'direct', 'winograd', 'fused', 'implicit'):
-    raise ValueError('Y2_FORCE_ALGO must be direct, winograd, fused or implicit (got %r)' % FORCE_ALGO)
+FORCE_ALGO = os.environ.get('Y2_FORCE_ALGO') or None     # 'direct' | 'winograd' | 'fused' | 'implicit' | 'split': no autotune, that algorithm wherever the library accepts it
+if FORCE_ALGO not in (None, 'direct', 'winograd', 'fused', 'implicit', 'split'):
+    raise ValueError('Y2_FORCE_ALGO must be direct, winograd, fused, implicit or split (got %r)' % FORCE_ALGO)
+# Opt-in precision mode: the Winograd GEMMs may run on the bf16 matrix pipe with three bf16 planes per fp32 operand and six plane
+# products per multiply (Y2_ALGO_WINOGRAD_SPLIT, csrc/gemm_split.hip): fp32-level accuracy (same parity tests), 2.67x the fp32-MFMA rate.
+SPLIT = os.environ.get('Y2_SPLIT_BF16', '0') == '1' or FORCE_ALGO == 'split'
+
+
+def split_planes(t):
+    """y2_split_bf16x3 of a contiguous fp32 GPU tensor: [3][numel] bf16 (hi, mid, lo planes)."""
+    require_gpu(t)
+    t = f32c(t)
+    out = torch.empty(3 * t.numel(), dtype=torch.bfloat16, device=t.device)
+    check(lib().y2_split_bf16x3(ptr(t), ptr(out), t.numel(), stream()), 'y2_split_bf16x3')
+    return out
 IMPLICIT = os.environ.get('Y2_WINO_IMPLICIT', '1') != '0'  # 0: never offer Y2_ALGO_WINOGRAD_IMPLICIT (A/B runs)
 WINO_MIN_CIN = 32                                        # below this the transforms cost more than the GEMM saves (measured; 32: the 208x208 layer, one K slab per tile of the fused kernels)
 
@@ -357,7 +371,7 @@ def _time_conv(L, params, st):
     return t
 
 
-def autotune_conv(params, dev, wino_w=None, implicit_ok=True):
+def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None):
     """Measure-don't-guess algorithm + tile selection for one y2_conv_fwd problem: the first time a problem shape is seen,
     every tile configuration of the direct kernel - and, when `wino_w` (y2_wino_weight output) is given, of the Winograd
     path - is timed (HIP events, best of 2 x 3 launches) and the fastest is cached for the process; later calls only
@@ -367,23 +381,26 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True):
     so the algorithm that never materialises it (3) is not offered."""
     wino_ok = (wino_w is not None and WINOGRAD and params.ksize == 3 and params.stride in (0, 1) and params.pad_plus1 in (0, 2)
                and not params.transposed and not params.residual and params.out_mode == 0)
+    split_ok = bool(wino_ok and SPLIT and wino_split is not None and params.Cin % 32 == 0)
     key = (params.B, params.H, params.W, params.Cin, params.ldx, params.Cout, params.ksize, bool(params.y), bool(params.y_pool),
            bool(params.stats), params.out_mode, params.stride, params.pad_plus1, bool(params.residual), params.transposed, params.out_h, params.out_w, str(dev),
-           bool(wino_ok), bool(implicit_ok and IMPLICIT))
+           bool(wino_ok), bool(implicit_ok and IMPLICIT)) + (('split',) if split_ok else ())
     implicit_ok = bool(implicit_ok and IMPLICIT) and params.Cin % 32 == 0
     w_direct = params.w
 
     def apply(choice):
         algo, tile = choice
         params.algo, params.tile = algo, tile
-        params.w = wino_w.data_ptr() if algo in (1, 2, 3) else w_direct
+        params.w = wino_split.data_ptr() if algo == 4 else wino_w.data_ptr() if algo in (1, 2, 3) else w_direct
         return choice
     if FORCE_ALGO is not None:
         # deterministic algorithm coverage (tests, A/B runs): every eligible layer takes the named algorithm, everything else the
         # direct kernel with the library's own tile choice; no measurement, no cache
-        want = {'direct': None, 'winograd': (1, 5), 'fused': (2, 0), 'implicit': (3, 0)}[FORCE_ALGO]
+        want = {'direct': None, 'winograd': (1, 5), 'fused': (2, 0), 'implicit': (3, 0), 'split': (4, 0)}[FORCE_ALGO]
         if want is not None and want[0] == 3 and not implicit_ok:
             want = (2, 0)               # where the transformed input must stay behind: the fused kernel that reads it
+        if want is not None and want[0] == 4 and not split_ok:
+            want = (1, 5) if wino_ok else None
         if want is not None and wino_ok and (want[0] == 1 or params.Cin % 32 == 0):
             apply(want)
             if lib().y2_conv_fwd_workspace_bytes(ctypes.byref(params)) >= 0:
@@ -417,6 +434,8 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True):
             cands.append((2, 0))        # fused GEMM + output transform (no product tensor): pays on the 52x52 layers
         if implicit_ok:
             cands.append((3, 0))        # ... with the input transform in its loader (no transformed input in memory either)
+        if split_ok:
+            cands.append((4, 0))        # three-kernel Winograd with the GEMMs on the bf16 pipe (opt-in precision mode)
     best, best_t = (0, 0), float('inf')
     stats_save = params.stats
     params.stats = None          # timing launches must not accumulate statistics twice

@@ -986,11 +986,14 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     if ((p->scale != nullptr && !y2_aligned16(p->scale)) || (p->shift != nullptr && !y2_aligned16(p->shift))) return Y2_ENOSUP;
     const bool implicit = p->algo == Y2_ALGO_WINOGRAD_IMPLICIT;      // fused, and the input transform happens in the fused kernel's loader
     const bool fused = p->algo == Y2_ALGO_WINOGRAD_FUSED || implicit;
-    if (fused && (p->Cin % 32) != 0) return Y2_ENOSUP;
+    const bool split = p->algo == Y2_ALGO_WINOGRAD_SPLIT;            // three kernels, the 16 GEMMs on the bf16 matrix pipe (gemm_split.hip): V and w are bf16 plane triples
+    if ((fused || split) && (p->Cin % 32) != 0) return Y2_ENOSUP;
     if (implicit && p->Cin < 32) return Y2_ENOSUP;
     const int th = (p->H + 1) / 2, tw = (p->W + 1) / 2;
     // Batch chunks bound the workspace (V = 4x the input, M = 4x the output of a chunk); see wino_chunk_bytes().
-    const size_t img_bytes = implicit ? (size_t)th * tw * sizeof(int32_t) : (size_t)16 * th * tw * ((size_t)p->Cin + (fused ? 0 : p->Cout)) * sizeof(float);
+    const size_t img_bytes = implicit ? (size_t)th * tw * sizeof(int32_t) :
+                             split ? (size_t)16 * th * tw * ((size_t)p->Cin * 6 + (size_t)p->Cout * 4) :
+                                     (size_t)16 * th * tw * ((size_t)p->Cin + (fused ? 0 : p->Cout)) * sizeof(float);
     int cb = (int)(wino_chunk_bytes() / (img_bytes > 0 ? img_bytes : 1));
     if (cb < 1) cb = 1;
     if (cb > p->B) cb = p->B;
@@ -999,11 +1002,14 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     // the implicit kernel addresses the chunk's input through one buffer descriptor with 2^30 / 2^31 as out-of-image sentinels
     while (implicit && cb > 1 && (size_t)cb * p->H * p->W * p->ldx * sizeof(float) >= 0x40000000ull) cb = (cb + 1) / 2;
     if (implicit && (size_t)cb * p->H * p->W * p->ldx * sizeof(float) >= 0x40000000ull) return Y2_ENOSUP;
+    // the split GEMM addresses the three planes of one position's V through one buffer descriptor: 66 * T * Cin bytes below 2^31
+    while (split && cb > 1 && (size_t)66 * cb * th * tw * p->Cin >= 0x7fffffffull) cb = (cb + 1) / 2;
+    if (split && ((size_t)66 * cb * th * tw * p->Cin >= 0x7fffffffull || (size_t)66 * p->Cout * p->Cin >= 0x7fffffffull)) return Y2_ENOSUP;
     const int nchunks = y2_cdiv(p->B, cb);
     cb = y2_cdiv(p->B, nchunks);                     // equal chunks
     const long long T = (long long)cb * th * tw;    // tiles of a full chunk
     if (T * (p->Cin / 4) >= 0xffffffffLL || T * (p->Cout / 4) >= 0xffffffffLL || T > 0x7fffffff) return Y2_ENOSUP;
-    const size_t vbytes = implicit ? 0 : align256((size_t)16 * T * p->Cin * sizeof(float));
+    const size_t vbytes = implicit ? 0 : align256((size_t)16 * T * p->Cin * (split ? 6 : sizeof(float)));
     const size_t mbytes = fused ? align256((size_t)(T + 63) * sizeof(int32_t)) + WF_DUMP_BYTES + 256 :      // ... + the 8 tile counters
                                  align256((size_t)16 * T * p->Cout * sizeof(float));   // fused: tile decode table + 1 KB dump area
     if (fused && (vbytes >= 0x7fffffffull || (size_t)16 * p->Cout * p->Cin * 4 >= 0x7fffffffull)) return Y2_ENOSUP;
@@ -1016,7 +1022,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
         float* const dummy = reinterpret_cast<float*>(256);
         q.x = dummy; q.w = dummy; q.y = dummy;
         size_t inner = 0;
-        if (!fused) {
+        if (!fused && !split) {
             const int rc = y2_internal_conv_grouped(&q, 16, T * p->Cin, (long long)p->Cout * p->Cin, T * p->Cout, stream, &inner);
             if (rc != Y2_OK) return rc;
         }
@@ -1046,7 +1052,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
         ia.sched = fused ? reinterpret_cast<int32_t*>(M + (mbytes - 256) / sizeof(float)) : nullptr;
         ia.sched_init = (int)(fused_grid / Y2_NUM_XCD);
         if (implicit) Y2_LAUNCH("wino_tile_table_kernel", 0.0, wino_tile_table_kernel, dim3((unsigned)y2_cdiv(Tc, 256)), dim3(256), 0, s, ia.tile_pix, ia.T, ia.H, ia.W, th, tw, d_tt, d_tw, ia.sched, ia.sched_init);
-        else Y2_LAUNCH("wino_input_kernel", 0.0, wino_input_kernel, dim3((unsigned)y2_cdiv(Tc * ia.c4n, 256)), dim3(256), 0, s, ia);
+        else if (!split) Y2_LAUNCH("wino_input_kernel", 0.0, wino_input_kernel, dim3((unsigned)y2_cdiv(Tc * ia.c4n, 256)), dim3(256), 0, s, ia);
 
         if (fused) {
             WinoFusedArgs fa;
@@ -1119,12 +1125,20 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
 #undef Y2_WF_LAUNCH
             continue;
         }
+        if (split) {
+            // stage 1 again with plane output (the fp32 launch above is skipped: see the `split` test in front of it), stage 2 on the bf16 pipe
+            const int rc1 = y2_internal_wino_input_split(ia.x, V, nb, p->H, p->W, p->Cin, p->ldx, stream);
+            if (rc1 != Y2_OK) return rc1;
+            const int rc2 = y2_internal_gemm_split(V, p->w, M, Tc, p->Cout, p->Cin, p->Cout, 16, stream);
+            if (rc2 != Y2_OK) return rc2;
+        } else {
         q.W = (int)Tc;
         q.x = V; q.w = p->w; q.y = M;
         q.workspace = M + mbytes / sizeof(float);
         q.workspace_bytes = (long long)((size_t)p->workspace_bytes - vbytes - mbytes);
         const int rc = y2_internal_conv_grouped(&q, 16, Tc * p->Cin, (long long)p->Cout * p->Cin, Tc * p->Cout, stream, nullptr);
         if (rc != Y2_OK) return rc;
+        }
 
         WinoOutArgs oa;
         oa.m = M; oa.scale = p->scale; oa.shift = p->shift; oa.stats = p->stats;

@@ -199,6 +199,8 @@ class Darknet(nn.Module):
             # Winograd-transformed copy of the deep 3x3 filters (the plan picks direct or Winograd per layer by measurement)
             u = _hip.wino_weight(wp, cout, cin) if (blk is not first and _hip.wino_eligible(cout, cin, k)) else None
             prep[blk] = (wp, scale, shift, u)
+            if u is not None and _hip.SPLIT and cin % 32 == 0:
+                prep.setdefault('split', {})[blk] = _hip.split_planes(u)      # bf16 plane triple of U (opt-in precision mode, Y2_ALGO_WINOGRAD_SPLIT)
         self._cache = (ver, prep)
         return prep
 
@@ -219,7 +221,7 @@ class Darknet(nn.Module):
     def _plan(self, prep, dev, B, cin0, H, W):
         """Execution plan for one input shape: intermediate NHWC buffers (never exposed, reused across calls) and the
         y2_conv_params array of the 22 generic convolutions (model/yolo2.py:76-113 in execution order)."""
-        key = (str(dev), B, cin0, H, W, _hip.tune_epoch(), _hip.WINOGRAD, _hip.FORCE_ALGO)
+        key = (str(dev), B, cin0, H, W, _hip.tune_epoch(), _hip.WINOGRAD, _hip.FORCE_ALGO, _hip.SPLIT)
         plan = self._plans.get(key)
         if plan is not None:
             if plan['prep'] is not prep:
@@ -227,7 +229,7 @@ class Darknet(nn.Module):
                 # operand pointers of the packed / folded / transformed weights move
                 for p, blk in zip(plan['arr'], plan['blks']):
                     wp, scale, shift, u = prep[blk]
-                    p.w = (u if p.algo in (1, 2, 3) else wp).data_ptr()
+                    p.w = (prep['split'][blk] if p.algo == 4 else u if p.algo in (1, 2, 3) else wp).data_ptr()
                     p.scale = scale.data_ptr() if scale is not None else None
                     p.shift = shift.data_ptr() if shift is not None else None
                 plan['prep'] = prep
@@ -300,15 +302,15 @@ class Darknet(nn.Module):
                 flops += add(blk, cur, B, h, w, ld, y=out, ldy=c)
                 cur, ld = out, c
                 keep.append(out)
-        for p, u in zip(plist, ulist):
-            _hip.autotune_conv(p, dev, wino_w=u)      # per-layer algorithm + tile choice by measurement (cached per problem shape)
+        for p, u, blk in zip(plist, ulist, blks):
+            _hip.autotune_conv(p, dev, wino_w=u, wino_split=prep.get('split', {}).get(blk))      # per-layer algorithm + tile choice by measurement (cached per problem shape)
         need = max([_hip.lib().y2_conv_fwd_workspace_bytes(ctypes.byref(p)) for p in plist] + [0])
         ws = _hip.workspace(dev, need) if need > 0 else None
         for p in plist:
             p.workspace, p.workspace_bytes = (ws.data_ptr(), ws.numel() * 4) if ws is not None else (None, 0)
         arr = (_hip.ConvParams * len(plist))(*plist)
         # multiply-adds the MFMA pipe really executes: a Winograd layer runs 16 GEMMs over ceil(H/2)*ceil(W/2) tiles per image
-        executed = sum(2.0 * p.Cin * p.Cout * (16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2, 3) else p.ksize ** 2 * p.B * p.H * p.W)
+        executed = sum(2.0 * p.Cin * p.Cout * (16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2, 3, 4) else p.ksize ** 2 * p.B * p.H * p.W)
                        for p in plist)
         plan = dict(key=key, arr=arr, n=len(plist), first=first, head_index=head_index, head_shape=head_shape, flops=flops, flops_executed=executed,
                     algos=[int(p.algo != 0) for p in plist], blks=blks, prep=prep,
@@ -442,7 +444,7 @@ class Tiny(Darknet):
                 else:
                     out = new(B, h, w, c)
                     p, _ = self._conv_params(prep, m, cur, B, h, w, ld, y=out, ldy=c)
-                _hip.autotune_conv(p, dev, wino_w=prep[m][3])
+                _hip.autotune_conv(p, dev, wino_w=prep[m][3], wino_split=prep.get('split', {}).get(m))
                 _hip.conv_workspace(p, dev)
                 _hip.check(L.y2_conv_fwd(ctypes.byref(p), st), 'y2_conv_fwd')
                 cur, ld = out, c
