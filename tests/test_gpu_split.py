@@ -34,11 +34,12 @@ def test_split_planes_are_round_to_nearest_even_residuals():
 
 
 @pytest.mark.parametrize('M,N,K,groups', [(128, 128, 32, 1), (300, 200, 96, 3), (1568, 1024, 512, 2), (64, 64, 1280, 16), (129, 257, 64, 1), (5408, 512, 1024, 1)])
-@pytest.mark.parametrize('bk', ['32', '16'])
+@pytest.mark.parametrize('bk', ['32x8', '32x4', '16x4'])
 def test_gemm_split_matches_fp64(M, N, K, groups, bk, monkeypatch):
     """C = A B^T from plane triples against fp64, held to the error an exact-fp32 GEMM (fp32 products, fp32 accumulation) makes."""
     import _hip
-    monkeypatch.setenv('Y2_SPLIT_BK', bk)
+    monkeypatch.setenv('Y2_SPLIT_BK', bk.split('x')[0])
+    monkeypatch.setenv('Y2_SPLIT_WAVES', bk.split('x')[1])
     L = _hip.lib()
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(groups, M, K, generator=g)
@@ -46,7 +47,8 @@ def test_gemm_split_matches_fp64(M, N, K, groups, bk, monkeypatch):
     A[:, :, ::7] *= 30.0                                     # mixed magnitudes inside a reduction
     Ad, Bd = A.to(dev()), B.to(dev())
     C = torch.full((groups, M, N + 3), -7.0, device=dev())   # row stride > N: the pad columns must stay untouched
-    _hip.check(L.y2_gemm_split(_hip.ptr(_hip.split_planes(Ad)), _hip.ptr(_hip.split_planes(Bd)), _hip.ptr(C), M, N, K, N + 3, groups, _hip.stream()), 'y2_gemm_split')
+    As, Bs = _hip.split_planes(Ad), _hip.split_planes(Bd)       # (kept alive: a temporary's memory would be recycled by the next allocation)
+    _hip.check(L.y2_gemm_split(_hip.ptr(As), _hip.ptr(Bs), _hip.ptr(C), M, N, K, N + 3, groups, _hip.stream()), 'y2_gemm_split')
     want = torch.einsum('gmk,gnk->gmn', A.double(), B.double())
     f32 = torch.einsum('gmk,gnk->gmn', A, B)                 # CPU fp32 GEMM: the accuracy class claimed
     e_split, e_f32 = rel_err(C[:, :, :N].cpu(), want), rel_err(f32, want)
@@ -56,11 +58,12 @@ def test_gemm_split_matches_fp64(M, N, K, groups, bk, monkeypatch):
 
 
 @pytest.mark.parametrize('B,cin,cout,H,W', [(2, 64, 128, 12, 12), (3, 256, 128, 13, 13), (1, 128, 256, 26, 26), (2, 32, 64, 20, 20), (4, 512, 1024, 13, 13), (1, 1280, 64, 7, 9)])
-@pytest.mark.parametrize('bk', ['32', '16'])
+@pytest.mark.parametrize('bk', ['32x8', '32x4', '16x4'])
 def test_conv_split_mode_is_as_accurate_as_fp32_winograd(B, cin, cout, H, W, bk, monkeypatch):
     """y2_conv_fwd with algo = Y2_ALGO_WINOGRAD_SPLIT against fp64 F.conv2d (with BN affine + LeakyReLU, pooled output where the map
     is even): the tolerance of the fp32 Winograd tests (8e-5 x rms allowed, ~8e-6 measured) and within 1.5x of algo 1 on the same input."""
-    monkeypatch.setenv('Y2_SPLIT_BK', bk)
+    monkeypatch.setenv('Y2_SPLIT_BK', bk.split('x')[0])
+    monkeypatch.setenv('Y2_SPLIT_WAVES', bk.split('x')[1])
     g = torch.Generator().manual_seed(cin + cout + H)
     x = torch.randn(B, cin, H, W, generator=g)
     w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5

@@ -18,7 +18,7 @@ L, st = _hip.lib(), _hip.stream()
 B = args.batch
 LAYERS = [('104x104 64->128', 104, 64, 128), ('52x52 128->256', 52, 128, 256), ('26x26 256->512', 26, 256, 512), ('13x13 512->1024', 13, 512, 1024),
           ('13x13 1024->1024', 13, 1024, 1024), ('13x13 1280->1024', 13, 1280, 1024)]
-print('%-20s %10s %10s %10s %10s %10s   (ms; executed Winograd TFLOP/s in brackets)' % ('layer', 'direct', 'wino', 'fused', 'split32', 'split16'))
+print('%-20s %10s %10s %10s %10s %10s %10s   (ms; executed Winograd TFLOP/s in brackets)' % ('layer', 'direct', 'wino', 'fused', 'split32x8', 'split32x4', 'split16x4'))
 for name, H, cin, cout in LAYERS:
     g = torch.Generator().manual_seed(H + cin)
     x = torch.randn(B, H, H, cin, generator=g).to(dev)
@@ -32,9 +32,9 @@ for name, H, cin, cout in LAYERS:
     exe = 2.0 * cin * cout * 16 * B * ((H + 1) // 2) ** 2
     row = []
     ref = None
-    for algo, wt, env in ((0, wp, None), (1, u, None), (2, u, None), (4, us, '32'), (4, us, '16')):
+    for algo, wt, env in ((0, wp, None), (1, u, None), (2, u, None), (4, us, ('32', '8')), (4, us, ('32', '4')), (4, us, ('16', '4'))):
         if env:
-            os.environ['Y2_SPLIT_BK'] = env
+            os.environ['Y2_SPLIT_BK'], os.environ['Y2_SPLIT_WAVES'] = env
         p = _hip.ConvParams()
         p.x, p.w, p.y, p.scale, p.shift = x.data_ptr(), wt.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr()
         p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize, p.ldy, p.slope, p.algo, p.tile = B, H, H, cin, cin, cout, 3, cout, 0.1, algo, (5 if algo == 1 else 0)
@@ -54,4 +54,4 @@ for name, H, cin, cout in LAYERS:
             e1.record(); e1.synchronize()
             best = min(best, e0.elapsed_time(e1) / 5)
         row.append('%.3f[%3.0f]%s' % (best, (exe if algo else exe * 36 / 16) / best / 1e9, '' if err < 5e-5 else ' ERR %.1e' % err))
-    print('%-20s %10s %10s %10s %10s %10s' % tuple([name] + row))
+    print('%-20s %10s %10s %10s %10s %10s %10s' % tuple([name] + row))

@@ -132,6 +132,7 @@ struct GemmSplitArgs {
     long long planeA, planeB;  // elements per plane
     long long gA, gB, gC;      // elements per group
     int M, N, K, ldc, tiles_m, tiles_n, groups;
+    long long* stamps;         // debug builds (-DY2_STAMPS): cycle stamps of workgroup 0
     unsigned a_bytes, b_bytes; // bytes from a group's plane-0 slice to the end of its plane-2 slice (the buffer range; masked rows use an offset beyond it)
 };
 
@@ -139,13 +140,19 @@ constexpr int GS_BM = 128, GS_BN = 128;
 
 // BK = 32: 48 KB stages, 3-deep ring = 144 KB: one workgroup per CU (one wave per SIMD), 48 MFMAs per barrier.
 // BK = 16: 24 KB stages, 3-deep ring = 72 KB: two workgroups per CU cover each other's barrier / LDS-read bubbles, 24 MFMAs per barrier.
-template <int BK>
-__global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitArgs a) {
+// NW = 8 (512 threads, wave tile 64 x 32): two waves per SIMD - while one is held in an LDS-DMA issue (~60 cycles, twice a bf16 MFMA), in
+// its fragment reads or at the barrier, the other feeds the matrix pipe; every wave issues half the DMA instructions of the 4-wave form.
+template <int BK, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_split_kernel(const GemmSplitArgs a) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     constexpr unsigned OOB = 0x80000000u;
     constexpr int ROWB = BK * 2;                        // bytes per row and plane in a stage
     constexpr int LPR = ROWB / 16;                      // lanes (16-B chunks) per row
-    constexpr int RPI = 256 / LPR;                      // rows per DMA instruction of the workgroup
+    constexpr int NT = NW * 64;
+    constexpr int RPI = NT / LPR;                       // rows per DMA instruction of the workgroup
+    constexpr int WN_WAVES = NW / 2;                    // wave grid 2 x (NW / 2)
+    constexpr int WN = GS_BN / WN_WAVES;                // wave tile 64 x WN
+    constexpr int MB = 2, NBK = WN / 32;                // 32 x 32 blocks per wave tile
     constexpr int PLANE_A = GS_BM * ROWB, PLANE_B = GS_BN * ROWB;
     constexpr int STAGE = 3 * (PLANE_A + PLANE_B);
     constexpr int NA = GS_BM / RPI, NB = GS_BN / RPI;   // DMA instructions per plane
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitArgs a) 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
     const int l31 = lane & 31, half = lane >> 5;
 
     int tile = y2_xcd_remap(blockIdx.x, gridDim.x);
@@ -191,11 +198,11 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitArgs a) 
         unsigned char* base = gs_smem + slot * STAGE + wave * 1024;
         if (j < 3 * NA) {
             const int p = j / NA, i = j % NA;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(base + p * PLANE_A + i * 4096), 16, (int)a_off[i], (int)(p * pa_bytes + (unsigned)k0 * 2u), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(base + p * PLANE_A + i * (NT * 16)), 16, (int)a_off[i], (int)(p * pa_bytes + (unsigned)k0 * 2u), 0, 0);
         } else {
             const int jj = j - 3 * NA;
             const int p = jj / NB, i = jj % NB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(base + 3 * PLANE_A + p * PLANE_B + i * 4096), 16, (int)b_off[i], (int)(p * pb_bytes + (unsigned)k0 * 2u), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(base + 3 * PLANE_A + p * PLANE_B + i * (NT * 16)), 16, (int)b_off[i], (int)(p * pb_bytes + (unsigned)k0 * 2u), 0, 0);
         }
     };
     auto issue_slab = [&](int k0, int slot) {
@@ -203,13 +210,17 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitArgs a) 
         for (int j = 0; j < NDMA; ++j) issue_piece(k0, slot, j);
     };
 
-    f32x16 acc[2][2];
+    // two accumulator sets: `acc` takes the hi x hi products (K / 16 sequential additions), `accl` the five cross products, which are
+    // 2^-8 ... 2^-16 of it: summed among themselves they keep their low bits, and they meet the main sum once, in the epilogue.  (One
+    // accumulator for everything measured 1.3-2.3x the error of the fp32-MFMA kernels at K >= 512: every small product was rounded to
+    // the big accumulator's last place.)
+    f32x16 acc[MB][NBK], accl[MB][NBK];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NBK; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accl[i][j][r] = 0.f; }
 
     // fragment byte offsets inside a plane: row (wave rows + l31 [+ 32 * block]), physical chunk of logical chunk 2*kk + half
     const int sw = BK == 32 ? ((l31 >> 2) & 3) : ((l31 >> 3) & 1);
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitArgs a) 
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) foff[kk] = l31 * ROWB + (((2 * kk + half) ^ sw) << 4);
     const int fa = wm * 64 * ROWB;
-    const int fb = 3 * PLANE_A + wn * 64 * ROWB;
+    const int fb = 3 * PLANE_A + wn * WN * ROWB;
 
     // the six plane products of one K = 16 step in ascending magnitude: the accumulator meets the small terms first
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
@@ -229,50 +240,66 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitArgs a) 
         constexpr bool prefetch = decltype(PF)::value;
         const unsigned char* sbuf = gs_smem + slot * STAGE;
         // all fragment reads of the slab go out first (those of the first K step in front): the MFMAs of step 0 run while step 1 lands
-        bf16x8 af[KSTEPS][2][3], bfr[KSTEPS][2][3];
+        bf16x8 af[KSTEPS][MB][3], bfr[KSTEPS][NBK][3];
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk)
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {          // in the order the products consume them
+            for (int q = 0; q < 3; ++q) {          // planes in the order the products consume them
                 const int pa = PA[q], pb = PB[q];
-                if (q == 0 || q == 1 || q == 2) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        af[kk][i][pa] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(sbuf + fa + pa * PLANE_A + i * 32 * ROWB + foff[kk]));
-                        bfr[kk][i][pb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(sbuf + fb + pb * PLANE_B + i * 32 * ROWB + foff[kk]));
-                    }
-                }
+                for (int i = 0; i < MB; ++i)
+                    af[kk][i][pa] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(sbuf + fa + pa * PLANE_A + i * 32 * ROWB + foff[kk]));
+#pragma unroll
+                for (int j = 0; j < NBK; ++j)
+                    bfr[kk][j][pb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(sbuf + fb + pb * PLANE_B + j * 32 * ROWB + foff[kk]));
             }
         __builtin_amdgcn_sched_barrier(0);
+        constexpr int NMFMA = KSTEPS * 6 * MB * NBK;
+        constexpr int EVERY = (NMFMA / 2) / NDMA > 0 ? (NMFMA / 2) / NDMA : 1;      // one DMA piece per EVERY MFMAs over the first half of the slab
         int cnt = 0;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk)
 #pragma unroll
             for (int q = 0; q < 6; ++q)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MB; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i][PA[q]], bfr[kk][j][PB[q]], acc[i][j], 0, 0, 0);
-                        if (prefetch && (cnt & 1) == 1 && (cnt >> 1) < NDMA) {
-                            issue_piece(k_next, slot_next, cnt >> 1);
+                    for (int j = 0; j < NBK; ++j) {
+                        if (q == 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i][PA[q]], bfr[kk][j][PB[q]], acc[i][j], 0, 0, 0);
+                        else accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i][PA[q]], bfr[kk][j][PB[q]], accl[i][j], 0, 0, 0);
+                        if (prefetch && (cnt % EVERY) == EVERY - 1 && (cnt / EVERY) < NDMA) {
+                            issue_piece(k_next, slot_next, cnt / EVERY);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                         ++cnt;
                     }
 #pragma unroll
-        for (int j = (24 * KSTEPS) / 2; prefetch && j < NDMA; ++j) issue_piece(k_next, slot_next, j);      // (never: 12 x KSTEPS slots >= NDMA)
+        for (int j = NMFMA / EVERY; prefetch && j < NDMA; ++j) issue_piece(k_next, slot_next, j);
     };
 
+#ifdef Y2_STAMPS
+    // per-stage cycle stamps of wave 0 of workgroup 0 (s_memtime): [stage][0] before the DMA wait, [1] after it, [2] after the barrier, [3] after the MFMAs
+    long long* stamps = (blockIdx.x == 0 && t == 0) ? a.stamps : nullptr;
+#define Y2_STAMP(ks_, w_) do { if (stamps != nullptr && (ks_) < 64) stamps[(ks_) * 4 + (w_)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define Y2_STAMP(ks_, w_) do { } while (0)
+#endif
+#ifdef Y2_STAMPS
+    if (stamps != nullptr) { stamps[252] = (long long)__builtin_readcyclecounter(); stamps[253] = (long long)__builtin_amdgcn_s_memrealtime(); }
+#endif
     issue_slab(0, 0);
     if (nk > 1) issue_slab(BK, 1);
     int cur = 0, nxt = 2;
     // (the prefetching and the draining iterations are separate loops: one loop body with a branch would make the accumulators meet in
     // phi nodes and cost an accumulator copy per MFMA, see conv_wgrad.hip)
     for (int ks = 0; ks + 2 < nk; ++ks) {
+        Y2_STAMP(ks, 0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");      // slab ks landed; slab ks+1 may still be in flight
+        Y2_STAMP(ks, 1);
         __builtin_amdgcn_s_barrier();        // everyone's part of slab ks is in LDS; everyone finished reading slab ks-1 (whose slot is refilled now)
+        Y2_STAMP(ks, 2);
         compute_slab(std::true_type{}, cur, (ks + 2) * BK, nxt);
+        Y2_STAMP(ks, 3);
         cur = cur == 2 ? 0 : cur + 1;
         nxt = nxt == 2 ? 0 : nxt + 1;
     }
@@ -286,17 +313,20 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitArgs a) 
     __builtin_amdgcn_s_barrier();
     compute_slab(std::false_type{}, cur, 0, 0);
 
+#ifdef Y2_STAMPS
+    if (stamps != nullptr) { stamps[254] = (long long)__builtin_readcyclecounter(); stamps[255] = (long long)__builtin_amdgcn_s_memrealtime(); }
+#endif
     // ---- store: register r of block (i, j) is row 8*(r>>2) + 4*half + (r&3), column l31: a wave writes 128-B row segments
     float* C = a.C + (size_t)grp * a.gC;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + l31;
+        for (int j = 0; j < NBK; ++j) {
+            const int col = n0 + wn * WN + j * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-                if (row < a.M && col < a.N) C[(size_t)row * a.ldc + col] = acc[i][j][r];
+                if (row < a.M && col < a.N) C[(size_t)row * a.ldc + col] = acc[i][j][r] + accl[i][j][r];
             }
         }
 }
@@ -332,19 +362,26 @@ int y2_internal_gemm_split(const void* A, const void* B, float* C, long long M, 
     a.a_bytes = (unsigned)span_a; a.b_bytes = (unsigned)span_b;
     const long long grid = (long long)a.tiles_m * a.tiles_n * groups;
     if (grid > 0x7fffffffLL || M > 0x7fffffffLL) return Y2_EINVAL;
-    const char* e = getenv("Y2_SPLIT_BK");            // 16: two workgroups per CU; 32 (default): one, twice the MFMAs per barrier (A/B runs)
+    a.stamps = nullptr;
+#ifdef Y2_STAMPS
+    if (const char* sp = getenv("Y2_GS_STAMPS_PTR")) a.stamps = reinterpret_cast<long long*>(strtoull(sp, nullptr, 0));
+#endif
+    const char* e = getenv("Y2_SPLIT_BK");            // 16: 24 KB stages, two workgroups per CU; 32 (default): 48 KB stages, one (A/B runs)
     const int bk = (e != nullptr && atoi(e) == 16) ? 16 : 32;
+    const char* e2 = getenv("Y2_SPLIT_WAVES");        // 4: one wave per SIMD (wave tile 64 x 64); 8 (default): two (64 x 32)
+    const int nw = (e2 != nullptr && atoi(e2) == 4) ? 4 : 8;
     const char* name = groups > 1 ? "gemm_split_kernel[grouped]" : "gemm_split_kernel";
     const double flops = 2.0 * (double)M * N * K * groups;
-    if (bk == 16) {
-        static Y2LdsAttr attr;
-        if (const int rc = attr.ensure(reinterpret_cast<const void*>(gemm_split_kernel<16>))) return rc;
-        Y2_LAUNCH(name, flops, gemm_split_kernel<16>, dim3((unsigned)grid), dim3(256), (size_t)3 * 3 * (GS_BM + GS_BN) * 32, y2_s(stream), a);
-    } else {
-        static Y2LdsAttr attr;
-        if (const int rc = attr.ensure(reinterpret_cast<const void*>(gemm_split_kernel<32>))) return rc;
-        Y2_LAUNCH(name, flops, gemm_split_kernel<32>, dim3((unsigned)grid), dim3(256), (size_t)3 * 3 * (GS_BM + GS_BN) * 64, y2_s(stream), a);
-    }
+#define Y2_GS_LAUNCH(BK_, NW_)                                                                                                     \
+    do {                                                                                                                           \
+        static Y2LdsAttr attr;                                                                                                     \
+        if (const int rc = attr.ensure(reinterpret_cast<const void*>(gemm_split_kernel<BK_, NW_>))) return rc;                     \
+        Y2_LAUNCH(name, flops, (gemm_split_kernel<BK_, NW_>), dim3((unsigned)grid), dim3(NW_ * 64), (size_t)3 * 3 * (GS_BM + GS_BN) * BK_ * 2, y2_s(stream), a); \
+    } while (0)
+    if (bk == 16) Y2_GS_LAUNCH(16, 4);           // (32-B rows: one DMA instruction of 512 threads would span 256 rows)
+    else if (nw == 4) Y2_GS_LAUNCH(32, 4);
+    else Y2_GS_LAUNCH(32, 8);
+#undef Y2_GS_LAUNCH
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

@@ -36,6 +36,8 @@ def _side_stream(dev):
     return s
 
 
+DEBUG_TAP = None        # tools/debug: callable(block name, dz, dx) invoked per block of the Darknet backward
+
 SYNC_POSITIVES = True   # data parallel: all-reduce the positive count so the cls mean is over the global batch
 
 # train.DataParallelRCCL tags the tensors its forward returns with `_y2_dp_reduce`: a callable(tensor) summing a small tensor over
@@ -481,6 +483,8 @@ def _darknet_bwd(ctx, dout):
         cop = (cout + 3) // 4 * 4
         dz = dzs[i] if i in dzs else _new(dev, B, h, w, cop)
         sf, sp = src_full[i], src_pool[i]
+        if DEBUG_TAP is not None:
+            DEBUG_TAP(blk.name + ':in', blk.z, blk.shift, sf, sp)
         _hip.check(L.y2_bn_act_bwd(_hip.ptr(blk.z), _hip.ptr(blk.scale), _hip.ptr(blk.shift), _hip.ptr(blk.mean), _hip.ptr(blk.invstd),
                                    _hip.ptr(e.gamma) if blk.has_bn else None, blk.slope,
                                    _hip.ptr(sf[0]) if sf else None, sf[1] if sf else 0, sf[2] if sf else 0, sf[3] if sf else 0,
@@ -564,6 +568,8 @@ def _darknet_bwd(ctx, dout):
                 wd = _new(dev, wsrc.numel())
                 _hip.check(L.y2_pack_weight(_hip.ptr(wsrc), _hip.ptr(wd), cop, cin, k, 1, st), 'y2_pack_weight')
                 _conv(L, st, dz, wd, dx, B, h, w, cop, cop, cin, k, cin)
+            if DEBUG_TAP is not None:
+                DEBUG_TAP(blk.name, dz, dx, None, None)
             # route dx
             if blk.name == 'layers3.0':
                 dcat = dx                                           # [B,h,w,4*c_pt + c_l2]
