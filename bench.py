@@ -40,6 +40,12 @@ for p in (ROOT, APP):
         sys.path.insert(0, p)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32, dense, MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # v_mfma_f32_32x32x16_bf16, dense (same guide)
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0     # opt-in split mode: six bf16 plane products per fp32-equivalent multiply-add (csrc/gemm_split.hip)
+
+
+def kernel_peak(name):
+    return PEAK_SPLIT_TFLOPS if name.startswith('gemm_split') else PEAK_FP32_MFMA_TFLOPS
 FLOPS_FWD_PER_IMG = 29.360e9           # sum over the 23 convs of 2*Cin*Cout*k*k*H*W at 416x416, VOC-20
 FLOPS_TRAIN_PER_IMG = 87.78e9          # fwd + wgrad + dgrad (all but the first conv)
 
@@ -62,6 +68,7 @@ def parse_args():
     ap.add_argument('--no-detect', action='store_true')
     ap.add_argument('--no-direct-leg', action='store_true', help='skip the Winograd-off measurements')
     ap.add_argument('--no-conv3', action='store_true', help='skip the batch-64 conv3x3 leg')
+    ap.add_argument('--no-split-leg', action='store_true', help='skip the opt-in split-bf16 precision mode measurement (Y2_SPLIT_BF16=1: Winograd GEMMs on the bf16 matrix pipe)')
     ap.add_argument('--settle', type=float, default=2.0, help='idle seconds between the inference legs and the train leg (outside timed regions)')
     ap.add_argument('--cpu-sample', type=int, default=192, help='images for the CPU baseline (0 = skip)')
     ap.add_argument('--multiscale', action='store_true', help='only the multi-scale training leg (BASELINE configs[3]) at full length')
@@ -191,7 +198,7 @@ def top_kernels(table, min_share=0.01):
         tf = e['flops'] / (e['ms'] * 1e-3) / 1e12 if e['flops'] > 0 and e['ms'] > 0 else None
         rows.append({'kernel': k, 'launches_per_step': round(e['launches'], 2), 'ms_per_step': round(e['ms'], 4), 'share': round(e['ms'] / total, 4),
                      'avg_launch_us': round(e['ms'] / max(e['launches'], 1e-9) * 1e3, 2),
-                     'executed_tflops': None if tf is None else round(tf, 2), 'frac': None if tf is None else round(tf / PEAK_FP32_MFMA_TFLOPS, 4)})
+                     'executed_tflops': None if tf is None else round(tf, 2), 'frac': None if tf is None else round(tf / kernel_peak(k), 4)})
     return rows, total
 
 
@@ -294,6 +301,34 @@ def detect_leg(args, ctx):
             finally:
                 _hip.WINOGRAD = True
                 dnn._plan_cache = None
+        if _hip.WINOGRAD and not _hip.SPLIT and args.model == 'darknet' and not args.no_split_leg:
+            # opt-in precision mode, reported BESIDE the fp32-MFMA headline: the Winograd GEMMs of the layers where it measures faster run
+            # on the bf16 pipe from three bf16 planes per fp32 operand (six plane products); same parity tests (tests/test_gpu_split.py,
+            # the forced 'split' plan of tests/test_gpu_fullsize.py)
+            with torch.no_grad():
+                ref_feat = dnn.forward_nhwc(xs[0]).clone()
+            _hip.SPLIT = True
+            dnn._cache = None
+            dnn._plan_cache = None
+            try:
+                sdt, _, stable, _ = measure(min(args.steps, 20), 3, True)
+                with torch.no_grad():
+                    got = dnn.forward_nhwc(xs[0])
+                plan = dnn._plan_cache[1]
+                sroof = roofline_from(stable, 'the same step in the split-bf16 mode')
+                gs = [r for r in sroof['top_kernels'] if r['kernel'].startswith('gemm_split')]
+                roof['split_bf16x6'] = {'dtype': 'f32 operands as 3 bf16 planes, 6 plane products per multiply on the bf16 MFMA pipe (fp32 accumulate); transforms fp32',
+                                        'images_per_sec': round(args.batch * min(args.steps, 20) / sdt, 2), 'ms_per_step': round(sdt / min(args.steps, 20) * 1e3, 4),
+                                        'layers_on_split_gemm': int(sum(1 for i in range(plan['n']) if plan['arr'][i].algo == 4)),
+                                        'feature_max_abs_diff_over_rms_vs_fp32_mfma_plan': float(((got - ref_feat).abs().max() / ref_feat.pow(2).mean().sqrt()).item()),
+                                        'gemm_split_kernel': gs[0] if gs else None, 'kernel_ms_per_step': sroof['kernel_ms_per_step'],
+                                        'parity': 'same tests as the fp32 path: tests/test_gpu_split.py (GEMM / conv vs fp64), tests/test_gpu_fullsize.py forced plan "split" (2e-5 x rms vs fp64 at batch 32)'}
+            except Exception as e:
+                roof['split_bf16x6'] = {'error': '%s: %s' % (type(e).__name__, e)}
+            finally:
+                _hip.SPLIT = False
+                dnn._cache = None
+                dnn._plan_cache = None
     state = {k: v.detach().cpu() for k, v in dnn.state_dict().items()} if (ctx.world == 1 and args.cpu_sample > 0 and args.model == 'darknet') else None
     del inf, dnn
     torch.cuda.empty_cache()
@@ -343,7 +378,7 @@ def conv3x3_leg(args, ctx):
             ms += e0.elapsed_time(e1) / reps
             a = 2.0 * p.Cin * p.Cout * 9 * p.B * p.H * p.W
             alg += a
-            exe += 2.0 * p.Cin * p.Cout * 16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2, 3) else a
+            exe += 2.0 * p.Cin * p.Cout * 16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2, 3, 4) else a
             layers += 1
         return {'layers': layers, 'ms': round(ms, 4), 'executed_tflops': round(exe / ms / 1e9, 2), 'mfma_utilisation': round(exe / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
                 'direct_equiv_tflops': round(alg / ms / 1e9, 2), 'algorithmic_gflop': round(alg / 1e9, 1), 'executed_gflop': round(exe / 1e9, 1)}
@@ -689,6 +724,12 @@ def main():
                 extra.update(conv_chain_ms_per_step=roof['conv_chain']['ms_per_step'], conv_chain_frac=roof['conv_chain']['frac'])
             if isinstance(roof.get('direct_only'), dict) and 'frac' in roof['direct_only']:
                 extra['detect_direct_only_frac'] = roof['direct_only']['all_mfma_kernels']['frac']
+            sp = roof.get('split_bf16x6')
+            if isinstance(sp, dict) and 'images_per_sec' in sp:
+                extra.update(split_bf16x6_detect_images_per_sec=sp['images_per_sec'], split_bf16x6_detect_ms_per_step=sp['ms_per_step'],
+                             split_bf16x6_feature_diff_over_rms=sp['feature_max_abs_diff_over_rms_vs_fp32_mfma_plan'], split_bf16x6_layers=sp['layers_on_split_gemm'])
+                if sp.get('gemm_split_kernel'):
+                    extra.update(split_bf16x6_gemm_tflops=sp['gemm_split_kernel']['executed_tflops'], split_bf16x6_gemm_frac_of_bf16x6_peak=sp['gemm_split_kernel']['frac'])
             for r in roof.get('top_kernels', []):
                 if r['frac'] is not None:       # one scalar per MFMA kernel of the detect step: frac_<kernel>
                     extra['frac_' + r['kernel'].replace('[', '_').replace(']', '').replace('<', '_').replace('>', '').replace(',', '_')] = r['frac']
@@ -709,7 +750,7 @@ def main():
         if ms is not None:
             out['multiscale'] = ms
         if roof is not None:
-            tables = {k: roof.pop(k) for k in ('top_kernels', 'definition') if k in roof}
+            tables = {k: roof.pop(k) for k in ('top_kernels', 'definition', 'split_bf16x6', 'direct_only', 'conv_chain', 'all_mfma_kernels') if k in roof}
             out['detect_kernel_table'] = tables
             roof.update(extra)
             out['roofline'] = roof

@@ -135,6 +135,8 @@ typedef struct y2_conv_params {
     int32_t algo;        /* Y2_ALGO_DIRECT (0): implicit GEMM, w = y2_pack_weight output.
                             Y2_ALGO_WINOGRAD (1): F(2x2,3x3) for 3x3 / stride 1 / same padding: w = y2_wino_weight output
                             [16][Cout][Cin]; `workspace` is REQUIRED (transformed input + products, y2_conv_fwd_workspace_bytes) */
+    int64_t w_plane;     /* Y2_ALGO_WINOGRAD_SPLIT only: distance in ELEMENTS between the three bf16 planes of w (0 = 16*Cout*Cin, the layout
+                            y2_split_bf16x3 gives one operand; larger when many operands were split as one array) */
 } y2_conv_params;
 
 #define Y2_ALGO_DIRECT 0
@@ -154,6 +156,7 @@ int y2_split_bf16x3(const float* src, void* dst, long long n, y2_stream_t stream
 
 /* C[g] (M x N, row stride ldc, fp32) = A[g] (M x K) * B[g]^T (N x K) for g < groups on the bf16 matrix pipe, operands as plane triples
  * A = [3][groups][M][K], B = [3][groups][N][K] (y2_split_bf16x3 of the fp32 arrays [groups][M][K] / [groups][N][K]); K % 32 == 0.
+ * Two accumulator sets per output (hi x hi products / the five cross products) are added once at the end.
  * The GEMM stage of Y2_ALGO_WINOGRAD_SPLIT, exposed for tests and tools. */
 int y2_gemm_split(const void* A, const void* B, float* C, long long M, int32_t N, int32_t K, int32_t ldc, int32_t groups, y2_stream_t stream);
 
@@ -230,6 +233,18 @@ int y2_filter_visible(const float* iou, const float* prob, int B, int n, int C, 
  * IoU: utils.iou.torch (utils/iou/torch.py:24-61, 116-153, 216-233).  Boxes are (y, x) min / max pairs.
  * Bit-exact to the fp32 operation order of the reference (no FMA contraction, IEEE division).
  * ------------------------------------------------------------------------------------------------ */
+/* The tail of detect.postprocess after NMS (detect.py:69-79) for a whole batch in one launch: k_* = the surviving boxes of every image
+ * (iou, yx_min, yx_max of candidate cand[b][keep[b][k]], k < keep_count[b]; cand NULL: keep holds box indices) and - e_count != NULL,
+ * the `[detect] fix` branch (:73-77) - their expansion into detections: every (box, class) pair with iou * prob > threshold_cls in
+ * row-major order: e_min / e_max [B][limit*C][2], e_score, e_cls (int64) [B][limit*C], e_count [B]. */
+int y2_expand_classes(const float* iou, const float* prob, const float* yx_min, const float* yx_max, const int32_t* cand, const int32_t* keep,
+                      const int32_t* keep_count, int32_t B, int32_t n, int32_t C, int32_t limit, float threshold_cls, float* k_iou, float* k_min, float* k_max,
+                      float* e_min, float* e_max, float* e_score, long long* e_cls, int32_t* e_count, y2_stream_t stream);
+
+/* eval.matching (eval.py:67-75): best[i], which[i] = max / first arg-max over j of IoU(box1 i, box2 j) (utils/iou/torch.py:47-61 arithmetic). */
+int y2_iou_rowmax(const float* yx_min1, const float* yx_max1, const float* yx_min2, const float* yx_max2, int32_t N1, int32_t N2, float min_union,
+                  float* best, long long* which, y2_stream_t stream);
+
 /* batch_iou_matrix: [Bt,N1,2]x2, [Bt,N2,2]x2 -> out [Bt,N1,N2]; iou_matrix is Bt = 1.  min_union = eps32.
  * mode 0: IoU (utils/iou/torch.py:47-61, 139-153);  mode 1: intersection area only (:24-44, 116-136). */
 int y2_iou_matrix(const float* yx_min1, const float* yx_max1, const float* yx_min2, const float* yx_max2,

@@ -43,8 +43,8 @@ def test_version_and_build_info(built):
 
 
 def test_conv_params_struct_layout():
-    # 7 pointers + 12 int32 + 1 float + 1 int32 (112 bytes, 8-aligned) + workspace pointer + int64 size
-    assert ctypes.sizeof(_hip.ConvParams) == 168
+    # 7 pointers + 12 int32 + 1 float + 1 int32 (112 bytes, 8-aligned) + workspace pointer + int64 size + residual pointer + 7 int32 (+ pad) + int64 w_plane
+    assert ctypes.sizeof(_hip.ConvParams) == 176
 
 
 def test_no_cpu_fallback_on_the_gpu_path():

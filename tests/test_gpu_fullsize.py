@@ -32,8 +32,11 @@ def rel(got, ref):
     return (got.double().cpu() - ref.cpu()).abs().max().item() / max(rms, 1e-30)
 
 
-@pytest.fixture(scope='module')
-def net():
+@pytest.fixture(scope='module', params=['fp32-mfma', 'split-bf16x6'])
+def net(request):
+    """Every test of this module runs twice: with the fp32-input MFMA kernels only, and with the opt-in split-bf16 precision mode
+    (Y2_SPLIT_BF16: the Winograd GEMMs of the 13x13 layers on the bf16 pipe from three bf16 planes per operand) - same truth, same tolerances."""
+    import _hip
     import model
     import model.yolo2
     cfg = configparser.ConfigParser()
@@ -42,15 +45,29 @@ def net():
     sd = odark.init_state_dict(5, 20, seed=0, head_scale=1 / 40.0)
     dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, 20)
     dnn.load_state_dict(sd, strict=False)
-    return model.Inference(cfg, dnn, anchors).to(dev()).eval(), anchors, sd
+    saved = _hip.SPLIT
+    _hip.SPLIT = request.param == 'split-bf16x6'
+    yield model.Inference(cfg, dnn, anchors).to(dev()).eval(), anchors, sd
+    _hip.SPLIT = saved
 
 
 @pytest.fixture(scope='module')
 def batch(net):
+    """The batch-32 features of the module.  The plan is PINNED (no timing-based algorithm selection: the library's fixed table), so
+    which images sit next to a threshold - and every number below - is the same from run to run."""
+    import _hip
     inf, anchors, sd = net
     x = synth.images(B, S, seed=1)
-    with torch.no_grad():
-        feat = inf.dnn.forward_nhwc(x.to(dev())).clone()      # [B,13,13,125] NHWC
+    saved = _hip.AUTOTUNE
+    _hip.AUTOTUNE = False
+    try:
+        with torch.no_grad():
+            feat = inf.dnn.forward_nhwc(x.to(dev())).clone()      # [B,13,13,125] NHWC
+        plan = inf.dnn._plan_cache[1]
+        if _hip.SPLIT:
+            assert sum(1 for i in range(plan['n']) if plan['arr'][i].algo == 4) >= 6      # the 13x13 layers
+    finally:
+        _hip.AUTOTUNE = saved
     return x, feat
 
 
@@ -89,7 +106,7 @@ def test_full_batch_under_each_forced_algorithm(net, batch, truth, algo, monkeyp
     monkeypatch.setattr(_hip, 'FORCE_ALGO', algo)
     if algo == 'split':
         monkeypatch.setattr(_hip, 'SPLIT', True)     # the opt-in precision mode (bf16 plane triples): same truth, same tolerance
-        inf.dnn._cache = None                        # ... its weight operands are prepared with the others
+    inf.dnn._cache = None                            # (the split weight operands are prepared with the others)
     inf.dnn._plan_cache = None
     try:
         with torch.no_grad():
@@ -100,8 +117,7 @@ def test_full_batch_under_each_forced_algorithm(net, batch, truth, algo, monkeyp
         assert (max(algos) == want) and (algo == 'direct' or algos.count(want) >= 10), algos     # 13 eligible layers (Cin >= 64)
     finally:
         inf.dnn._plan_cache = None
-        if algo == 'split':
-            inf.dnn._cache = None
+        inf.dnn._cache = None
     got = f[list(SAMPLED)].permute(0, 3, 1, 2)
     print('forced plan %s: worst max|err|/rms over the sampled images %.3g' % (algo, max(rel(got[j:j + 1], truth[j:j + 1]) for j in range(len(SAMPLED)))))
     worst = max(rel(got[j:j + 1], truth[j:j + 1]) for j in range(len(SAMPLED)))

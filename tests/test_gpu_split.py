@@ -79,3 +79,48 @@ def test_conv_split_mode_is_as_accurate_as_fp32_winograd(B, cin, cout, H, W, bk,
     print('conv %dx%d Cin %d Cout %d: split %.3g, fp32 Winograd %.3g' % (H, W, cin, cout, errs[4], errs[1]))
     assert errs[4] <= 8e-5
     assert errs[4] <= max(1.5 * errs[1], 4e-6), errs
+
+
+def test_training_step_in_split_mode_matches_oracle_autograd(monkeypatch):
+    """fprop and data gradients of the Winograd layers through Y2_ALGO_WINOGRAD_SPLIT (forced wherever the library accepts it; the filter
+    transforms of all layers split by one y2_split_bf16x3 pass over their arena): losses, every parameter gradient and the running
+    statistics against the oracle's fp64 autograd at the tolerance of the fp32 training test, and within 1e-4 of the fp32-MFMA run."""
+    import _hip
+    import model
+    import test_gpu_round3 as R
+    from oracle import darknet as odark, loss as oloss, synth
+    from oracle.make_golden import NARROW
+    w = dict(NARROW)
+    w['layers1.5'] = 8
+    sd = odark.init_state_dict(5, 20, seed=0, channels=w, head_scale=1 / 8.0)
+    S, B = 96, 3
+    x = synth.images(B, S, seed=1)
+    data = synth.norm_data(synth.labels(B, S, 20, seed=2), S, S, S // 32, S // 32)
+    grads = {}
+    for mode in ('fp32', 'split'):
+        monkeypatch.setattr(_hip, 'SPLIT', mode == 'split')
+        monkeypatch.setattr(_hip, 'FORCE_ALGO', 'split' if mode == 'split' else 'winograd')
+        inf, anchors = R.build(sd)
+        inf.train()
+        calls = []
+        if mode == 'split':
+            L = _hip.lib()
+            orig = L.y2_conv_fwd
+
+            def spy(p, st):
+                calls.append(p._obj.algo)
+                return orig(p, st)
+            monkeypatch.setattr(L, 'y2_conv_fwd', spy, raising=False)
+        pred = model._inference(inf, x.to(dev()))
+        loss, _ = model.loss(anchors, data, pred, 0.6)
+        model.weighted_total(loss, oloss.HPARAM).backward()
+        if mode == 'split':
+            monkeypatch.undo()
+            assert calls.count(4) >= 8, calls            # fprop and dgrad of the 64-channel 3x3 layers (layers2.*, layers3.0)
+        sd64, lo, stats, f = R.oracle_step(sd, x, data, anchors, True)
+        for k in lo:
+            np.testing.assert_allclose(loss[k].item(), lo[k].item(), rtol=1e-4)
+        R.check_grads(inf, sd64)
+        grads[mode] = {k: p.grad.detach().cpu() for k, p in inf.dnn.named_parameters()}
+    for k in grads['fp32']:
+        assert rel_err(grads['split'][k], grads['fp32'][k]) <= 1e-4, k

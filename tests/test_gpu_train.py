@@ -200,8 +200,10 @@ def test_bn_act_forward_backward(pool, both, C):
     rmd, rvd = torch.zeros(C, device=d), torch.ones(C, device=d)
     gd, bd = gamma.detach().float().to(d), beta.detach().float().to(d)
     n = B * H * W
+    steps = torch.tensor(41, dtype=torch.int64, device=d)          # nn.BatchNorm2d.num_batches_tracked: incremented by the same launch
     _hip.check(L.y2_bn_finalize(_hip.ptr(stats), float(n), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(rmd), _hip.ptr(rvd), 0.01, 1e-5,
-                                _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(mean), _hip.ptr(invstd), C, _hip.stream()), 'fin')
+                                _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(mean), _hip.ptr(invstd), C, _hip.ptr(steps), _hip.stream()), 'fin')
+    assert int(steps) == 42
     np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(rvd.cpu().numpy(), rv.numpy(), rtol=1e-5)
     yo = torch.empty(B, H, W, C, device=d)

@@ -28,7 +28,8 @@ class ConvParams(ctypes.Structure):
                 ('out_mode', ctypes.c_int32), ('slope', c_float), ('tile', ctypes.c_int32),
                 ('workspace', c_void_p), ('workspace_bytes', ctypes.c_int64),
                 ('residual', c_void_p), ('ldr', ctypes.c_int32), ('stride', ctypes.c_int32), ('pad_plus1', ctypes.c_int32),
-                ('transposed', ctypes.c_int32), ('out_h', ctypes.c_int32), ('out_w', ctypes.c_int32), ('algo', ctypes.c_int32)]
+                ('transposed', ctypes.c_int32), ('out_h', ctypes.c_int32), ('out_w', ctypes.c_int32), ('algo', ctypes.c_int32),
+                ('w_plane', ctypes.c_int64)]
 
 
 # name -> argtypes; restype is int for everything except y2_build_info
@@ -59,6 +60,8 @@ SIGNATURES = {
     'y2_abi_version': [],
     'y2_pack_weight': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'y2_prep_weights': [ctypes.POINTER(PrepItem), c_int, c_void_p],
+    'y2_expand_classes': [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_float] + [c_void_p] * 8 + [c_void_p],
+    'y2_iou_rowmax': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'y2_split_bf16x3': [c_void_p, c_void_p, ctypes.c_longlong, c_void_p],
     'y2_gemm_split': [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, c_void_p],
     'y2_multi': [ctypes.POINTER(MultiItem), c_int, c_void_p],
@@ -371,7 +374,7 @@ def _time_conv(L, params, st):
     return t
 
 
-def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None):
+def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, split_plane=0):
     """Measure-don't-guess algorithm + tile selection for one y2_conv_fwd problem: the first time a problem shape is seen,
     every tile configuration of the direct kernel - and, when `wino_w` (y2_wino_weight output) is given, of the Winograd
     path - is timed (HIP events, best of 2 x 3 launches) and the fastest is cached for the process; later calls only
@@ -392,6 +395,7 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None):
         algo, tile = choice
         params.algo, params.tile = algo, tile
         params.w = wino_split.data_ptr() if algo == 4 else wino_w.data_ptr() if algo in (1, 2, 3) else w_direct
+        params.w_plane = split_plane if algo == 4 else 0
         return choice
     if FORCE_ALGO is not None:
         # deterministic algorithm coverage (tests, A/B runs): every eligible layer takes the named algorithm, everything else the
@@ -412,6 +416,8 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None):
     if not AUTOTUNE or DETERMINISTIC or torch.cuda.is_current_stream_capturing():
         # no measurement possible (or, deterministic mode: a timed choice may differ from run to run and with it the rounding): the choices the measurements converge to on MI355X (profiles/r01_detect_b32_layer_table.txt)
         prefer = []
+        if split_ok and params.H * params.W <= 19 * 19:
+            prefer.append((4, 0))       # opt-in split-bf16 mode: the 13x13 (19x19 at 608) layers, 25-30 % ahead of the fp32 GEMMs there
         if wino_ok and implicit_ok and (params.H * params.W >= 52 * 52 or (params.H * params.W >= 26 * 26 and params.Cout <= params.Cin)):
             prefer.append((3, 0))       # fused Winograd with the input transform in its loader: the large maps and the data gradients
         if wino_ok and params.Cin % 32 == 0 and params.H * params.W >= 26 * 26:

@@ -25,7 +25,7 @@ __attribute__((visibility("hidden"))) int y2_internal_wgrad_grouped(const float*
 __attribute__((visibility("hidden"))) int y2_internal_wgrad_needs_zero(long long M, int Cin, int Cout, int groups);
 __attribute__((visibility("hidden"))) int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need);
 // gemm_split.hip: fp32-accurate GEMMs on the bf16 matrix pipe (three bf16 planes per operand, six plane products)
-__attribute__((visibility("hidden"))) int y2_internal_gemm_split(const void* A, const void* B, float* C, long long M, int N, int K, int ldc, int groups, y2_stream_t stream);
+__attribute__((visibility("hidden"))) int y2_internal_gemm_split(const void* A, long long planeA, const void* B, long long planeB, float* C, long long M, int N, int K, int ldc, int groups, y2_stream_t stream);
 __attribute__((visibility("hidden"))) int y2_internal_wino_input_split(const float* x, void* v, int B, int H, int W, int Cin, int ldx, y2_stream_t stream);
 
 // ---- per-device host-side caches (a process may touch several GPUs; symbol addresses and function attributes are per device)

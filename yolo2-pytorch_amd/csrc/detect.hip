@@ -121,6 +121,68 @@ __global__ __launch_bounds__(256) void compact_kernel(const float* __restrict__ 
     if (t == 0) count[b] = base;
 }
 
+// detect.py:69-79 after NMS (a22): gather the kept boxes of every image and, with `fix`, expand them into (box, class) detections -
+// every pair whose score = iou * prob exceeds the class threshold, in row-major (box-major, class-minor) order.  One workgroup per
+// image; ordered compaction with wave ballots like compact_kernel.  kept[b][k] = candidate-list position of the k-th survivor.
+struct ExpandArgs {
+    const float* iou; const float* prob; const float* yx_min; const float* yx_max;      // [B][n], [B][n][C], [B][n][2], [B][n][2]
+    const int32_t* cand; const int32_t* keep; const int32_t* keep_count;                 // [B][n], [B][limit], [B]
+    float* k_iou; float* k_min; float* k_max;                                            // kept boxes: [B][limit], [B][limit][2] x 2
+    float* e_min; float* e_max; float* e_score; long long* e_cls; int32_t* e_count;      // expanded: [B][limit*C][2] x 2, [B][limit*C] x 2, [B]
+    int n, C, limit;
+    float thr;
+};
+
+__global__ __launch_bounds__(256) void expand_classes_kernel(const ExpandArgs a) {
+    __shared__ int wave_cnt[4];
+    __shared__ int base;
+    const int b = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int kc = a.keep_count[b];
+    if (t == 0) base = 0;
+    for (int k = t; k < kc; k += 256) {
+        const int src = a.cand != nullptr ? a.cand[(size_t)b * a.n + a.keep[(size_t)b * a.limit + k]] : a.keep[(size_t)b * a.limit + k];
+        const size_t o = (size_t)b * a.n + src, d = (size_t)b * a.limit + k;
+        a.k_iou[d] = a.iou[o];
+        a.k_min[2 * d] = a.yx_min[2 * o]; a.k_min[2 * d + 1] = a.yx_min[2 * o + 1];
+        a.k_max[2 * d] = a.yx_max[2 * o]; a.k_max[2 * d + 1] = a.yx_max[2 * o + 1];
+    }
+    __syncthreads();
+    if (a.e_count == nullptr) return;
+    const int total = kc * a.C;
+    const size_t cap = (size_t)a.limit * a.C;
+    for (int i0 = 0; i0 < total; i0 += 256) {
+        const int i = i0 + t;
+        bool hit = false;
+        float sc = 0.f;
+        int k = 0, c = 0;
+        size_t o = 0;
+        if (i < total) {
+            k = i / a.C; c = i - k * a.C;
+            const int src = a.cand != nullptr ? a.cand[(size_t)b * a.n + a.keep[(size_t)b * a.limit + k]] : a.keep[(size_t)b * a.limit + k];
+            o = (size_t)b * a.n + src;
+            sc = a.iou[o] * a.prob[o * a.C + c];            // one fp32 multiply, like `iou.unsqueeze(-1) * prob`
+            hit = sc > a.thr;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (hit) {
+            const size_t d = (size_t)b * cap + off + __popcll(m & ((1ull << lane) - 1ull));
+            a.e_min[2 * d] = a.yx_min[2 * o]; a.e_min[2 * d + 1] = a.yx_min[2 * o + 1];
+            a.e_max[2 * d] = a.yx_max[2 * o]; a.e_max[2 * d + 1] = a.yx_max[2 * o + 1];
+            a.e_score[d] = sc;
+            a.e_cls[d] = c;
+        }
+        __syncthreads();
+        if (t == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (t == 0) a.e_count[b] = base;
+}
+
 // ------------------------------------------------------------------------------------------------ IoU
 // utils/iou/torch.py:34-44,47-61 operation order; every op is a separate fp32 rounding.
 __device__ __forceinline__ float iou_one(float ymin1, float xmin1, float ymax1, float xmax1,
@@ -132,6 +194,22 @@ __device__ __forceinline__ float iou_one(float ymin1, float xmin1, float ymax1, 
     const float a2 = (ymax2 - ymin2) * (xmax2 - xmin2);
     const float uni = fmaxf((a1 + a2) - inter, min_union);
     return inter / uni;
+}
+
+// eval.py:67-75: per prediction the best IoU over the ground-truth boxes and its index (first maximum, like torch.max over the IoU matrix).
+__global__ __launch_bounds__(256) void iou_rowmax_kernel(const float* __restrict__ mn1, const float* __restrict__ mx1, const float* __restrict__ mn2, const float* __restrict__ mx2,
+                                                         int N1, int N2, float min_union, float* __restrict__ best, long long* __restrict__ which) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N1) return;
+    const float y0 = mn1[2 * i], x0 = mn1[2 * i + 1], y1 = mx1[2 * i], x1 = mx1[2 * i + 1];
+    float bv = 0.f;
+    int bi = 0;
+    for (int j = 0; j < N2; ++j) {
+        const float v = iou_one(y0, x0, y1, x1, mn2[2 * j], mn2[2 * j + 1], mx2[2 * j], mx2[2 * j + 1], min_union);
+        if (j == 0 || v > bv) { bv = v; bi = j; }
+    }
+    best[i] = bv;
+    which[i] = bi;
 }
 
 __global__ void iou_matrix_kernel(const float* __restrict__ mn1, const float* __restrict__ mx1, const float* __restrict__ mn2, const float* __restrict__ mx2,
@@ -285,6 +363,31 @@ extern "C" int y2_filter_visible(const float* iou, const float* prob, int B, int
         return Y2_EINVAL;
     }
     Y2_LAUNCH("compact_kernel", 0.0, compact_kernel, dim3(B), dim3(256), 0, y2_s(stream), iou, prob_cls, n, fix, thr, count, index);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_expand_classes(const float* iou, const float* prob, const float* yx_min, const float* yx_max, const int32_t* cand, const int32_t* keep,
+                                 const int32_t* keep_count, int B, int n, int C, int limit, float threshold_cls, float* k_iou, float* k_min, float* k_max,
+                                 float* e_min, float* e_max, float* e_score, long long* e_cls, int32_t* e_count, y2_stream_t stream) {
+    if (!iou || !yx_min || !yx_max || !keep || !keep_count || !k_iou || !k_min || !k_max) return Y2_EINVAL;
+    if (B <= 0 || n <= 0 || C < 0 || limit <= 0) return Y2_EINVAL;
+    if (e_count != nullptr && (!prob || C <= 0 || !e_min || !e_max || !e_score || !e_cls)) return Y2_EINVAL;
+    ExpandArgs a;
+    a.iou = iou; a.prob = prob; a.yx_min = yx_min; a.yx_max = yx_max; a.cand = cand; a.keep = keep; a.keep_count = keep_count;
+    a.k_iou = k_iou; a.k_min = k_min; a.k_max = k_max; a.e_min = e_min; a.e_max = e_max; a.e_score = e_score; a.e_cls = e_cls; a.e_count = e_count;
+    a.n = n; a.C = C; a.limit = limit; a.thr = threshold_cls;
+    Y2_LAUNCH("expand_classes_kernel", 0.0, expand_classes_kernel, dim3(B), dim3(256), 0, y2_s(stream), a);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_iou_rowmax(const float* yx_min1, const float* yx_max1, const float* yx_min2, const float* yx_max2, int N1, int N2, float min_union,
+                             float* best, long long* which, y2_stream_t stream) {
+    if (N1 < 0 || N2 <= 0) return Y2_EINVAL;
+    if (N1 == 0) return Y2_OK;
+    if (!yx_min1 || !yx_max1 || !yx_min2 || !yx_max2 || !best || !which) return Y2_EINVAL;
+    Y2_LAUNCH("iou_rowmax_kernel", 0.0, iou_rowmax_kernel, dim3(y2_cdiv(N1, 256)), dim3(256), 0, y2_s(stream), yx_min1, yx_max1, yx_min2, yx_max2, N1, N2, min_union, best, which);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

@@ -346,17 +346,20 @@ extern "C" int y2_split_bf16x3(const float* src, void* dst, long long n, y2_stre
 
 // C[g] (M x N, row stride ldc, fp32) = A[g] (M x K) * B[g]^T (N x K) for `groups` problems; A / B are split planes (see GemmSplitArgs).
 // Library-internal (wino.hip) and behind y2_gemm_split (tests, tools).
-int y2_internal_gemm_split(const void* A, const void* B, float* C, long long M, int N, int K, int ldc, int groups, y2_stream_t stream) {
+int y2_internal_gemm_split(const void* A, long long planeA, const void* B, long long planeB, float* C, long long M, int N, int K, int ldc, int groups, y2_stream_t stream) {
     if (A == nullptr || B == nullptr || C == nullptr || M <= 0 || N <= 0 || K <= 0 || groups < 1 || ldc < N) return Y2_EINVAL;
     if ((K % 32) != 0) return Y2_ENOSUP;
     if (!y2_aligned16(A) || !y2_aligned16(B)) return Y2_EALIGN;
     // a group's three plane slices sit behind ONE buffer descriptor (plane offset = scalar offset): its range must stay below the 2^31 "masked" offset
-    const unsigned long long span_a = (2ull * groups * M * K + (unsigned long long)M * K) * 2ull, span_b = (2ull * groups * N * K + (unsigned long long)N * K) * 2ull;
+    if (planeA <= 0) planeA = (long long)groups * M * K;
+    if (planeB <= 0) planeB = (long long)groups * N * K;
+    if (planeA < (long long)groups * M * K || planeB < (long long)groups * N * K || (planeA & 7) || (planeB & 7)) return Y2_EINVAL;
+    const unsigned long long span_a = (2ull * planeA + (unsigned long long)M * K) * 2ull, span_b = (2ull * planeB + (unsigned long long)N * K) * 2ull;
     if (span_a >= 0x7fffffffull || span_b >= 0x7fffffffull) return Y2_ENOSUP;
     GemmSplitArgs a;
     a.A = static_cast<const unsigned short*>(A); a.B = static_cast<const unsigned short*>(B); a.C = C;
     a.gA = M * K; a.gB = (long long)N * K; a.gC = M * ldc;
-    a.planeA = a.gA * groups; a.planeB = a.gB * groups;
+    a.planeA = planeA; a.planeB = planeB;
     a.M = (int)M; a.N = N; a.K = K; a.ldc = ldc; a.groups = groups;
     a.tiles_m = y2_cdiv(M, GS_BM); a.tiles_n = y2_cdiv(N, GS_BN);
     a.a_bytes = (unsigned)span_a; a.b_bytes = (unsigned)span_b;
@@ -387,7 +390,7 @@ int y2_internal_gemm_split(const void* A, const void* B, float* C, long long M, 
 }
 
 extern "C" int y2_gemm_split(const void* A, const void* B, float* C, long long M, int32_t N, int32_t K, int32_t ldc, int32_t groups, y2_stream_t stream) {
-    return y2_internal_gemm_split(A, B, C, M, N, K, ldc, groups, stream);
+    return y2_internal_gemm_split(A, 0, B, 0, C, M, N, K, ldc, groups, stream);
 }
 
 // Stage 1 of the Winograd path with split output (wino.hip): V planes [3][16][T][Cin] of the chunk's input.

@@ -284,6 +284,7 @@ struct WinoFusedArgs {
     unsigned x_bytes;
     unsigned y_bytes, yp_bytes;      // wino_fused2_kernel stores through buffer descriptors (< 2^31 bytes each, host check)
     int32_t* sched;                  // wino_fused2_kernel: per-XCD counters of the next unclaimed tile (set by the kernel launched in front of it)
+    int sched_static;                // != 0: static stride instead of claiming (Y2_WF_STATIC=1: the A/B of tools/contention.py)
 };
 
 // PG = positions per pipeline stage (one barrier per stage: 16*PG MFMAs per wave between barriers), WF_STAGES = ring depth.
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // could not start with the others (RCCL's all-reduce kernels hold CUs while the data-parallel backward runs, and this
         // kernel needs a whole CU) kept its full share of tiles for a second pass; now it costs one tile.
         int claimed = 0;
-        if (t == 0) claimed = atomicAdd(a.sched + xcd, 1);
+        if (t == 0) claimed = a.sched_static ? (tile - xcd * per_xcd + wgs_per_xcd) : atomicAdd(a.sched + xcd, 1);      // (static stride: A/B runs, tools/contention.py)
         Y2_WF2_SYNC();
         stage(S0{}, &acc[0], T_{}, nks - 1, G1{}, ZL{});
         Y2_WF2_SYNC();
@@ -1005,6 +1006,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     // the split GEMM addresses the three planes of one position's V through one buffer descriptor: 66 * T * Cin bytes below 2^31
     while (split && cb > 1 && (size_t)66 * cb * th * tw * p->Cin >= 0x7fffffffull) cb = (cb + 1) / 2;
     if (split && ((size_t)66 * cb * th * tw * p->Cin >= 0x7fffffffull || (size_t)66 * p->Cout * p->Cin >= 0x7fffffffull)) return Y2_ENOSUP;
+    if (split && p->w_plane != 0 && ((size_t)(2 * p->w_plane + (long long)p->Cout * p->Cin) * 2 >= 0x7fffffffull || p->w_plane < (long long)16 * p->Cout * p->Cin)) return Y2_ENOSUP;
     const int nchunks = y2_cdiv(p->B, cb);
     cb = y2_cdiv(p->B, nchunks);                     // equal chunks
     const long long T = (long long)cb * th * tw;    // tiles of a full chunk
@@ -1066,6 +1068,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
             fa.th = th; fa.tw = tw; fa.T = (int)Tc; fa.tiles_m = y2_cdiv(Tc, 64); fa.tiles_n = y2_cdiv(p->Cout, 64);
             fa.v_bytes = implicit ? 0u : (unsigned)((size_t)16 * Tc * p->Cin * 4); fa.u_bytes = (unsigned)((size_t)16 * p->Cout * p->Cin * 4);
             fa.slope = p->slope; fa.d_tt = d_tt; fa.d_tw = d_tw;
+            { const char* se = getenv("Y2_WF_STATIC"); fa.sched_static = (se != nullptr && atoi(se) != 0) ? 1 : 0; }
             const long long ntiles = (long long)fa.tiles_m * fa.tiles_n;
             if (ntiles > 0x7fffffffLL) return Y2_EINVAL;
             const long long grid = fused_grid;
@@ -1129,7 +1132,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
             // stage 1 again with plane output (the fp32 launch above is skipped: see the `split` test in front of it), stage 2 on the bf16 pipe
             const int rc1 = y2_internal_wino_input_split(ia.x, V, nb, p->H, p->W, p->Cin, p->ldx, stream);
             if (rc1 != Y2_OK) return rc1;
-            const int rc2 = y2_internal_gemm_split(V, p->w, M, Tc, p->Cout, p->Cin, p->Cout, 16, stream);
+            const int rc2 = y2_internal_gemm_split(V, 0, p->w, p->w_plane, M, Tc, p->Cout, p->Cin, p->Cout, 16, stream);
             if (rc2 != Y2_OK) return rc2;
         } else {
         q.W = (int)Tc;

@@ -52,12 +52,23 @@ def filter_visible(config, iou, yx_min, yx_max, prob):
     return (iou[0][idx], yx_min.view(-1, 2)[idx], yx_max.view(-1, 2)[idx], prob.view(-1, C)[idx], prob_cls[0][idx], cls[0][idx].long())
 
 
-def _expand_classes(iou, yx_min, yx_max, prob, threshold_cls):
-    """The `fix` branch of detect.py:73-77: every (kept box, class) pair whose score = iou * prob exceeds the class threshold becomes
-    a detection, in row-major (box, class) order.  Returns (yx_min, yx_max, cls, score) of the pairs."""
-    score = iou.unsqueeze(-1) * prob
-    box, cls = (score > threshold_cls).nonzero(as_tuple=True)
-    return yx_min[box], yx_max[box], cls, score[box, cls]
+def _expand(iou, prob, yx_min, yx_max, cand, keep, keep_count, fix, threshold_cls):
+    """y2_expand_classes: survivors of every image gathered and (fix) expanded into (box, class) detections.  iou [B,n], prob [B,n,C],
+    yx_min / yx_max [B,n,2], cand int32 [B,n] or None, keep int32 [B,limit], keep_count int32 [B]."""
+    B, limit = keep.shape
+    n, C = iou.size(1), prob.size(-1)
+    dev = iou.device
+    new = lambda *s, **kw: torch.empty(*s, device=dev, **kw)
+    k_iou, k_min, k_max = new(B, limit), new(B, limit, 2), new(B, limit, 2)
+    if fix:
+        e_min, e_max, e_score = new(B, limit * C, 2), new(B, limit * C, 2), new(B, limit * C)
+        e_cls, e_count = new(B, limit * C, dtype=torch.int64), new(B, dtype=torch.int32)
+    else:
+        e_min = e_max = e_score = e_cls = e_count = None
+    _hip.check(_hip.lib().y2_expand_classes(_hip.ptr(iou), _hip.ptr(prob), _hip.ptr(yx_min), _hip.ptr(yx_max), _hip.ptr(cand), _hip.ptr(keep), _hip.ptr(keep_count),
+                                            B, n, C, limit, float(threshold_cls), _hip.ptr(k_iou), _hip.ptr(k_min), _hip.ptr(k_max),
+                                            _hip.ptr(e_min), _hip.ptr(e_max), _hip.ptr(e_score), _hip.ptr(e_cls), _hip.ptr(e_count), _hip.stream()), 'y2_expand_classes')
+    return k_iou, k_min, k_max, e_min, e_max, e_score, e_cls, e_count
 
 
 def postprocess(config, iou, yx_min, yx_max, prob):
@@ -67,12 +78,17 @@ def postprocess(config, iou, yx_min, yx_max, prob):
     keep = utils.postprocess.nms(iou, yx_min, yx_max, config.getfloat('detect', 'overlap'))
     if not keep:
         return None
-    keep = torch.tensor(keep, dtype=torch.long, device=iou.device)
-    iou, yx_min, yx_max, prob, cls = iou[keep], yx_min[keep], yx_max[keep], prob[keep], cls[keep]
-    if config.getboolean('detect', 'fix'):
-        yx_min, yx_max, cls, score = _expand_classes(iou, yx_min, yx_max, prob, config.getfloat('detect', 'threshold_cls'))
-        return iou, yx_min, yx_max, cls, score
-    return iou, yx_min, yx_max, cls, iou
+    fix = config.getboolean('detect', 'fix')
+    k = len(keep)
+    dev = iou.device
+    keep_t = torch.tensor(keep, dtype=torch.int32, device=dev).view(1, k)
+    count = torch.tensor([k], dtype=torch.int32, device=dev)
+    k_iou, k_min, k_max, e_min, e_max, e_score, e_cls, e_count = _expand(_hip.f32c(iou).view(1, -1), _hip.f32c(prob).view(1, iou.numel(), -1), _hip.f32c(yx_min).view(1, -1, 2),
+                                                                        _hip.f32c(yx_max).view(1, -1, 2), None, keep_t, count, fix, config.getfloat('detect', 'threshold_cls'))
+    if fix:
+        m = int(e_count.item())
+        return k_iou[0], e_min[0, :m], e_max[0, :m], e_cls[0, :m], e_score[0, :m]
+    return k_iou[0], k_min[0], k_max[0], cls[keep_t[0].long()], k_iou[0]
 
 
 def detect_batch(feature_nhwc, anchors, fix=False, threshold=0.3, threshold_cls=0.005, overlap=0.45, limit=200):
@@ -92,26 +108,26 @@ def detect_batch(feature_nhwc, anchors, fix=False, threshold=0.3, threshold_cls=
 
 
 def postprocess_batch(d, fix=False, threshold_cls=0.005):
-    """a22 (detect.py:69-79) for every image of a detect_batch result; one host sync.
-    Returns a list (per image) of None or (iou, yx_min, yx_max, cls, score) GPU tensors."""
-    B = d['keep'].size(0)
+    """a22 (detect.py:69-79) for every image of a detect_batch result: ONE launch (y2_expand_classes: gather of the survivors and, with
+    `fix`, their expansion into (box, class) detections in row-major order) and one host synchronisation for the counts.
+    Returns a list (per image) of None or (iou, yx_min, yx_max, cls, score) GPU tensors (views of the batch's result buffers)."""
+    keep = d['keep']
+    B, limit = keep.shape
     n = d['iou'].numel() // B
-    counts = d['keep_count'].tolist()
+    k_iou, k_min, k_max, e_min, e_max, e_score, e_cls, e_count = _expand(d['iou'].view(B, n), d['prob'].view(B, n, -1), d['yx_min'].view(B, n, 2), d['yx_max'].view(B, n, 2),
+                                                                        d['index'], keep, d['keep_count'], fix, threshold_cls)
+    counts = (torch.stack([d['keep_count'], e_count]) if fix else d['keep_count'].view(1, B)).tolist()      # the one host round trip
     out = []
-    iou = d['iou'].view(B, n)
-    mn, mx = d['yx_min'].view(B, n, 2), d['yx_max'].view(B, n, 2)
-    prob = d['prob'].view(B, n, -1)
     for b in range(B):
-        if counts[b] == 0:
+        k = counts[0][b]
+        if k == 0:
             out.append(None)
-            continue
-        src = d['index'][b].long()[d['keep'][b, :counts[b]].long()]
-        _iou, _mn, _mx, _prob = iou[b][src], mn[b][src], mx[b][src], prob[b][src]
-        if fix:
-            e_mn, e_mx, cls, score = _expand_classes(_iou, _mn, _mx, _prob, threshold_cls)
-            out.append((_iou, e_mn, e_mx, cls, score))
+        elif fix:
+            m = counts[1][b]
+            out.append((k_iou[b, :k], e_min[b, :m], e_max[b, :m], e_cls[b, :m], e_score[b, :m]))
         else:
-            out.append((_iou, _mn, _mx, d['cls'].view(B, n)[b][src].long(), _iou))
+            src = d['index'][b].long()[keep[b, :k].long()]
+            out.append((k_iou[b, :k], k_min[b, :k], k_max[b, :k], d['cls'].view(B, n)[b][src].long(), k_iou[b, :k]))
     return out
 
 

@@ -24,8 +24,11 @@ def _matching(positive, index):
 
 def matching(data_yx_min, data_yx_max, yx_min, yx_max, threshold):
     """eval.py:67-75: predictions of one class in one image (descending score) against that class's ground truth.  The IoU matrix and
-    its row arg-max run on the device (y2_iou_matrix); only two n-vectors cross to the host for the sequential claim loop."""
+    its row arg-max run on the device in one kernel (y2_iou_rowmax); only two n-vectors cross to the host for the sequential claim loop."""
     if data_yx_min.numel() == 0:
         return np.zeros([yx_min.size(0)], bool)
-    best, which = utils.iou.torch.iou_matrix(yx_min, yx_max, data_yx_min, data_yx_max).max(-1)
-    return _matching((best > threshold).cpu().numpy(), which.cpu().numpy())
+    if not yx_min.is_cuda:
+        best, which = utils.iou.torch.iou_matrix(yx_min, yx_max, data_yx_min, data_yx_max).max(-1)      # CPU tensors: the library's host IoU
+    else:
+        best, which = utils.iou.torch.iou_rowmax(yx_min, yx_max, data_yx_min, data_yx_max)               # one kernel: IoU row + max + first arg-max
+    return _matching((best.cpu().numpy() > np.float32(threshold)), which.cpu().numpy())

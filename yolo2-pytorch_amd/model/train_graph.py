@@ -72,7 +72,8 @@ def _new(dev, *shape, dtype=torch.float32):
     return torch.empty(*shape, dtype=dtype, device=dev)
 
 
-def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=None, slope=1.0, stats=None, y_pool=None, ldp=0, coff=0, out_mode=0, keep_v=False, u=False):
+def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=None, slope=1.0, stats=None, y_pool=None, ldp=0, coff=0, out_mode=0, keep_v=False, u=False,
+          us=None, us_plane=0):
     """One y2_conv_fwd.  keep_v: when the Winograd algorithm is chosen, run it in a workspace of its own and return that tensor -
     its head is the transformed input V, which the weight gradient of the same layer reuses (y2_wino_wgrad v_transformed).
     u: the layer's Winograd filter transform when the caller prepared it (y2_prep_weights), None = not eligible, False = derive it here."""
@@ -91,7 +92,8 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
         u = _hip.wino_weight(wp, cout, cin) if (out_mode == 0 and _hip.wino_eligible(cout, cin, k)) else None
     elif out_mode != 0:
         u = None
-    _hip.autotune_conv(p, x.device, wino_w=u, implicit_ok=not keep_v)
+    # us: bf16 plane triple of u (opt-in split-bf16 mode; planes us_plane elements apart), offered as Y2_ALGO_WINOGRAD_SPLIT
+    _hip.autotune_conv(p, x.device, wino_w=u, implicit_ok=not keep_v, wino_split=us if u is not None else None, split_plane=us_plane)
     kept = None
     if keep_v and p.algo in (1, 2):
         T = B * ((H + 1) // 2) * ((W + 1) // 2)
@@ -119,7 +121,7 @@ def _train_operands(dnn, dev):
     (y2_conv0_fwd reads the state_dict layout) and blocks whose output width is not a multiple of 4 (the 125 / 425-channel head: its
     data gradient runs zero-padded) are left to the per-layer path."""
     from model import yolo2 as _yolo2
-    key = (dev, dnn._weight_versions())       # the convolution weights only: the BatchNorm buffer updates of a forward pass do not move it
+    key = (dev, dnn._weight_versions(), _hip.SPLIT, _hip.WINOGRAD)       # the convolution weights only: the BatchNorm buffer updates of a forward pass do not move it
     cache = getattr(dnn, '_train_cache', None)
     if cache is not None and cache[0] == key:
         return cache[1]
@@ -136,6 +138,9 @@ def _train_operands(dnn, dev):
         return t
     first = dnn._first_block()
     items, ops = [], {}
+    # the Winograd filter transforms of all layers live in ONE arena: in the split-bf16 mode a single y2_split_bf16x3 pass turns it into
+    # the three bf16 planes of every layer's operand (planes `usize` elements apart)
+    wino = []
     for name, blk in dnn.named_modules():
         if not isinstance(blk, _yolo2.Conv2d) or blk is first:
             continue
@@ -144,21 +149,38 @@ def _train_operands(dnn, dev):
         if cout % 4 or cin % 4 or not w.is_contiguous() or w.dtype != torch.float32:
             continue
         n = w.numel()
-        d = dict(wp=buf((name, 'wp'), n), wd=buf((name, 'wd'), n), uf=None, ud=None)
+        d = dict(wp=buf((name, 'wp'), n), wd=buf((name, 'wd'), n), uf=None, ud=None, ufs=None, uds=None, plane=0)
         items.append((w, d['wp'], cout, cin, k, _hip.PREP_FPROP))
         items.append((w, d['wd'], cout, cin, k, _hip.PREP_DGRAD))
         if _hip.wino_eligible(cout, cin, k):
-            d['uf'] = buf((name, 'uf'), 16 * cout * cin)
-            items.append((w, d['uf'], cout, cin, k, _hip.PREP_WINO_FPROP))
+            wino.append((d, 'uf', w, cout, cin, k, _hip.PREP_WINO_FPROP))
         if _hip.wino_eligible(cin, cout, k):          # the data gradient is a convolution with the roles of Cin and Cout exchanged
-            d['ud'] = buf((name, 'ud'), 16 * cout * cin)
-            items.append((w, d['ud'], cout, cin, k, _hip.PREP_WINO_DGRAD))
+            wino.append((d, 'ud', w, cout, cin, k, _hip.PREP_WINO_DGRAD))
         ops[blk] = d
+    usize = sum(16 * cout * cin for _, _, _, cout, cin, _, _ in wino)
+    if usize:
+        arena = buf('u_arena', usize)
+        off = 0
+        for d, tag, w, cout, cin, k, mode in wino:
+            d[tag] = arena[off:off + 16 * cout * cin]
+            items.append((w, d[tag], cout, cin, k, mode))
+            off += 16 * cout * cin
     if items:
         table = (_hip.PrepItem * len(items))()
         for e, (src, dst, cout, cin, k, mode) in zip(table, items):
             e.src, e.dst, e.Cout, e.Cin, e.ksize, e.mode = src.data_ptr(), dst.data_ptr(), cout, cin, k, mode
         _hip.check(_hip.lib().y2_prep_weights(table, len(items), _hip.stream()), 'y2_prep_weights')
+    if usize and _hip.SPLIT:
+        planes = bufs[1].get('u_split')
+        if planes is None or planes.numel() != 3 * usize:
+            planes = bufs[1]['u_split'] = torch.empty(3 * usize, dtype=torch.bfloat16, device=dev)
+        _hip.check(_hip.lib().y2_split_bf16x3(_hip.ptr(arena), _hip.ptr(planes), usize, _hip.stream()), 'y2_split_bf16x3')
+        off = 0
+        for d, tag, w, cout, cin, k, mode in wino:
+            if (cout if tag == 'ud' else cin) % 32 == 0:          # the K dimension of the GEMM (Cin of the convolution that runs)
+                d[tag + 's'] = planes[off:off + 16 * cout * cin]
+            d['plane'] = usize
+            off += 16 * cout * cin
     dnn._train_cache = (key, ops)
     return ops
 
@@ -298,7 +320,8 @@ def _darknet_fwd(ctx, dnn, x, params, frozen):
             _hip.check(L.y2_conv0_fwd(_hip.ptr(xin), _hip.ptr(e.w), None, None, _hip.ptr(z), None, _hip.ptr(estats),
                                       B, h, w, cin, cout, cout, 0, 1.0, st), 'y2_conv0_fwd')
         elif mod in prepared:
-            blk.wino_v = _conv(L, st, xin, prepared[mod]['wp'], z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=True, u=prepared[mod]['uf'])
+            blk.wino_v = _conv(L, st, xin, prepared[mod]['wp'], z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=True, u=prepared[mod]['uf'],
+                               us=prepared[mod]['ufs'], us_plane=prepared[mod]['plane'])
         else:
             wp = _new(dev, e.w.numel())
             _hip.check(L.y2_pack_weight(_hip.ptr(e.w), _hip.ptr(wp), cout, cin, k, 0, st), 'y2_pack_weight')
@@ -389,7 +412,7 @@ def _darknet_bwd(ctx, dout):
     L = _hip.lib()
     st = _hip.stream()
     dnn, blocks = ctx.dnn, ctx.blocks
-    if ctx.prepared and (getattr(dnn, '_train_cache', (None, None))[0] != ctx.prepared_key or ctx.prepared_key != (dout.device, dnn._weight_versions())):
+    if ctx.prepared and (getattr(dnn, '_train_cache', (None, None))[0] != ctx.prepared_key or ctx.prepared_key[:2] != (dout.device, dnn._weight_versions())):
         raise RuntimeError('model.yolo2: a convolution weight was modified (optimizer step, load_state_dict, in-place edit) between this forward and '
                            'its backward; the per-model GEMM operand buffers this graph was recorded against hold other weights now')
     B, cin0, H, W, c_pt, c_l2 = ctx.geom
@@ -556,7 +579,7 @@ def _darknet_bwd(ctx, dout):
             dx = _new(dev, B, h, w, cin)
             ready_ops = ctx.prepared.get(blk.mod)
             if ready_ops is not None:        # rotated / in-out-swapped operands prepared with the forward's (same parameter version)
-                _conv(L, st, dz, ready_ops['wd'], dx, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'])
+                _conv(L, st, dz, ready_ops['wd'], dx, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'], us=ready_ops['uds'], us_plane=ready_ops['plane'])
             else:
                 wsrc = e.w
                 if cop != cout:

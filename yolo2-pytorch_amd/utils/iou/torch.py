@@ -65,3 +65,15 @@ def batch_iou_pair(yx_min1, yx_max1, yx_min2, yx_max2, min=EPS):
     _hip.check(_hip.lib().y2_iou_pair(_hip.ptr(a1), _hip.ptr(b1), _hip.ptr(a2), _hip.ptr(b2), out.numel(), min,
                                       _hip.ptr(out), _hip.stream()), 'y2_iou_pair')
     return out
+
+
+def iou_rowmax(yx_min1, yx_max1, yx_min2, yx_max2, min=EPS):
+    """(max over boxes 2 of the IoU, its first arg-max) per box 1 without the matrix in memory: `iou_matrix(...).max(-1)` of eval.py:69-70
+    as one kernel (y2_iou_rowmax).  GPU tensors; N2 >= 1."""
+    _hip.require_gpu(yx_min1, yx_max1, yx_min2, yx_max2)
+    a1, b1, a2, b2 = (_hip.f32c(t) for t in (yx_min1, yx_max1, yx_min2, yx_max2))
+    n1, n2 = a1.size(0), a2.size(0)
+    best = torch.empty(n1, dtype=torch.float32, device=a1.device)
+    which = torch.empty(n1, dtype=torch.int64, device=a1.device)
+    _hip.check(_hip.lib().y2_iou_rowmax(_hip.ptr(a1), _hip.ptr(b1), _hip.ptr(a2), _hip.ptr(b2), n1, n2, min, _hip.ptr(best), _hip.ptr(which), _hip.stream()), 'y2_iou_rowmax')
+    return best, which
