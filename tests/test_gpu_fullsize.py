@@ -289,3 +289,56 @@ def test_full_resolution_training_step_against_the_oracle_and_its_fp32_floor(net
     for k in g64:
         floor = rms_rel(g32[k], g64[k])
         assert rms_rel(ours[k], g64[k]) <= max(1e-4, 2.5 * floor), (k, rms_rel(ours[k], g64[k]), floor)
+
+
+@pytest.mark.parametrize('arch,n', [('darknet', 2), ('resnet50', 1)])
+def test_608_coco80_full_width_training_step_against_the_oracle_and_its_fp32_floor(arch, n):
+    """BASELINE configs[3] / configs[4] at their largest shape: full-width Darknet-19 and ResNet-50, COCO-80 head (425 channels), 608x608
+    (19x19 grid).  One training step (forward with batch statistics, region loss, backward): loss terms and every parameter gradient
+    against the oracle's fp64 autograd, judged against the oracle's own fp32 run like the 416x416 test above (the gradients in front of
+    a batch-statistics BatchNorm are cancellation residues: fp32 itself is ~1 % rms from fp64 there)."""
+    import model
+    import model.resnet
+    import model.yolo2
+    from oracle import resnet as ores
+    C, S6 = 80, 608
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1'}, 'model': {'pretrained': '0'}})
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    if arch == 'darknet':
+        sd = odark.init_state_dict(5, C, seed=0, head_scale=1 / 40.0)
+        dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, C)
+        fwd = lambda x, s: odark.forward(x, s, training=True)
+    else:
+        sd = ores.init_state_dict(arch, 5, C, seed=0, head_scale=0.25)
+        dnn = getattr(model.resnet, arch)(model.ConfigChannels(cfg, sd), anchors, C)
+        fwd = lambda x, s: ores.forward(x, s, arch, training=True)
+    dnn.load_state_dict(sd, strict=False)
+    inf = model.Inference(cfg, dnn, anchors).to(dev()).train()
+    x = synth.images(n, S6, seed=3)
+    data = synth.norm_data(synth.labels(n, S6, C, seed=4), S6, S6, S6 // 32, S6 // 32)
+    pred = model._inference(inf, x.to(dev()))
+    assert tuple(pred['feature'].shape) == (n, 425, 19, 19)
+    loss, _ = model.loss(anchors, data, pred, 0.6)
+    model.weighted_total(loss, oloss.HPARAM).backward()
+    ours = {k: p.grad.detach().cpu() for k, p in dnn.named_parameters()}
+    torch.set_num_threads(64)
+    ref = {}
+    for name, dt in (('fp64', torch.float64), ('fp32', torch.float32)):
+        sdx = {k: (v.to(dt).requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+        f = fwd(x.to(dt), sdx)
+        lo, _ = oloss.loss(anchors.to(dt), {k: (v.to(dt) if v.is_floating_point() else v) for k, v in data.items()}, ohead.decode(f, anchors.to(dt)), 0.6)
+        oloss.total(lo).backward()
+        ref[name] = ({k: v.grad for k, v in sdx.items() if getattr(v, 'grad', None) is not None}, lo, f.detach())
+    assert rel(pred['feature'], ref['fp64'][2]) <= max(2e-5, 2.5 * rel(ref['fp32'][2], ref['fp64'][2]))
+    for k in loss:
+        np.testing.assert_allclose(loss[k].item(), ref['fp64'][1][k].item(), rtol=5e-5 if arch == 'darknet' else 5e-4)
+    g64, g32 = ref['fp64'][0], ref['fp32'][0]
+    assert set(g64) == set(ours)
+    worst = 0.0
+    for k in g64:
+        floor = rms_rel(g32[k], g64[k])
+        e = rms_rel(ours[k], g64[k])
+        worst = max(worst, e / max(floor, 1e-30))
+        assert e <= max(1e-4, 2.5 * floor), (k, e, floor)
+    print('608x608 COCO-80 %s: worst gradient error / fp32 floor = %.2f' % (arch, worst))
