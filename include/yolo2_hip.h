@@ -327,6 +327,13 @@ int y2_conv_wgrad_ex(const float* x, const float* dz, float* dw, int B, int Hi, 
  * stride ldz, Cout <= 64.  dw is the state_dict layout [Cout][Cin][3][3], pre-zeroed (partials are added atomically). */
 int y2_conv0_wgrad(const float* x_nchw, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, int ldz, y2_stream_t stream);
 
+/* The first layer's weight gradient WITHOUT a materialised dz (model/yolo2.py:78-79: Conv2d(3, 32) + MaxPool2d(2)): the BatchNorm / LeakyReLU /
+ * max-pool backward of y2_bn_act_bwd's second pass runs in this kernel's loader from (z, dy_pool) and the pass-1 sums (call y2_bn_act_bwd
+ * with dz = NULL first: it then computes only `sums`).  Same arguments as y2_bn_act_bwd / y2_conv0_wgrad; H, W even; dw pre-zeroed. */
+int y2_conv0_wgrad_fused(const float* x_nchw, const float* z, const float* scale, const float* shift, const float* mean, const float* invstd,
+                         const float* gamma, float slope, const float* dy_pool, int32_t ldp, const double* sums, float* dw,
+                         int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ldz, int32_t has_bn, y2_stream_t stream);
+
 /* Training-mode nn.BatchNorm2d(momentum 0.01, eps 1e-5) statistics (model/yolo2.py:58): stats = Y2_STATS_REPL copies of
  * [sum z | sum z^2] per channel (fp64, accumulated by y2_conv_fwd / y2_conv0_fwd), count = B*H*W.  Writes the affine (scale, shift) used for
  * normalisation (biased variance), saves mean / invstd for backward and updates the running statistics in place
@@ -345,7 +352,7 @@ int y2_bn_act_fwd(const float* z, const float* scale, const float* shift, float 
  * fmode 1: stored reorg'ed in a [B,H/2,W/2,ldf] buffer at channel foff) and/or dy_pool (gradient of the pooled
  * activation, routed to the first maximal window element like nn.MaxPool2d) to dz (gradient of the raw conv output).
  * sums [2C] (pre-zeroed fp64) receives sum(g) = d beta (or d bias) and sum(g*zhat) = d gamma.  has_bn = 0: plain
- * bias + LeakyReLU block (dz = g); has_bn = 2: BatchNorm with FROZEN statistics (eval()-mode module with autograd recording,
+ * bias + LeakyReLU block (dz = g); dz = NULL: only the sums (pass 1; see y2_conv0_wgrad_fused); has_bn = 2: BatchNorm with FROZEN statistics (eval()-mode module with autograd recording,
  * receptive_field_analyzer.py:67,87): mean / invstd are the running statistics, dz = g * gamma * invstd. */
 int y2_bn_act_bwd(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,
                   float slope, const float* dy_full, int ldf, int foff, int fmode, const float* dy_pool, int ldp, int poff,

@@ -280,3 +280,33 @@ def test_plan_cache_serves_the_multi_scale_schedule():
     for k in range(4):
         small.put(k, {}, 10)
     assert list(small.d) == [2, 3]
+
+
+@pytest.mark.parametrize('B,H,W,cin,cout,has_bn', [(2, 16, 32, 3, 32, 1), (1, 10, 16, 3, 40, 1), (3, 8, 16, 1, 8, 0), (2, 12, 48, 3, 64, 2), (2, 6, 32, 2, 6, 1)])
+def test_first_layer_weight_gradient_without_a_materialised_dz(B, H, W, cin, cout, has_bn):
+    """y2_conv0_wgrad_fused (BatchNorm / LeakyReLU / max-pool backward in the weight-gradient loader, from z, dy_pool and the pass-1 sums of
+    y2_bn_act_bwd with dz = NULL) against the two-kernel form it replaces (y2_bn_act_bwd writing dz, then y2_conv0_wgrad)."""
+    import _hip
+    L, st, d = _hip.lib(), _hip.stream(), dev()
+    g = torch.Generator().manual_seed(B + H + cout)
+    x = torch.randn(B, cin, H, W, generator=g).to(d)
+    z = torch.randn(B, H, W, cout, generator=g).to(d)
+    z[:, ::2, 1::2] = z[:, ::2, ::2]                                  # ties inside pooling windows: the first maximum must win
+    dyp = torch.randn(B, H // 2, W // 2, cout, generator=g).to(d)
+    gamma = (torch.rand(cout, generator=g) + 0.5).to(d)
+    mean, invstd = (torch.randn(cout, generator=g) * 0.1).to(d), (torch.rand(cout, generator=g) + 0.5).to(d)
+    scale, shift = gamma * invstd, (torch.randn(cout, generator=g) * 0.1).to(d)
+    args = lambda dz, sums: (_hip.ptr(z), _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(mean) if has_bn else None, _hip.ptr(invstd) if has_bn else None,
+                             _hip.ptr(gamma) if has_bn else None, 0.1, None, 0, 0, 0, _hip.ptr(dyp), cout, 0, _hip.ptr(sums), _hip.ptr(dz), cout, B, H, W, cout, cout, has_bn, st)
+    sums_a = torch.zeros(2 * cout, dtype=torch.float64, device=d)
+    dz = torch.empty(B, H, W, cout, device=d)
+    _hip.check(L.y2_bn_act_bwd(*args(dz, sums_a)), 'two-pass')
+    want = torch.zeros(cout, cin, 3, 3, device=d)
+    _hip.check(L.y2_conv0_wgrad(_hip.ptr(x), _hip.ptr(dz), _hip.ptr(want), B, H, W, cin, cout, cout, st), 'conv0_wgrad')
+    sums_b = torch.zeros(2 * cout, dtype=torch.float64, device=d)
+    _hip.check(L.y2_bn_act_bwd(*args(None, sums_b)), 'sums only')
+    assert rel(sums_b, sums_a.cpu()) <= 1e-5      # (fp32 block partials added in completion order)
+    got = torch.zeros(cout, cin, 3, 3, device=d)
+    _hip.check(L.y2_conv0_wgrad_fused(_hip.ptr(x), _hip.ptr(z), _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(mean) if has_bn else None, _hip.ptr(invstd) if has_bn else None,
+                                      _hip.ptr(gamma) if has_bn else None, 0.1, _hip.ptr(dyp), cout, _hip.ptr(sums_b), _hip.ptr(got), B, H, W, cin, cout, cout, has_bn, st), 'fused')
+    assert rel(got, want.cpu()) <= 2e-6, rel(got, want.cpu())

@@ -502,6 +502,160 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const W0Args a) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ first layer, dz on the fly
+// The same reduction with the BatchNorm / LeakyReLU / 2x2 max-pool backward of y2_bn_act_bwd (pass 2) applied in the LOADER: the gradient
+// of the first layer's raw convolution output (1.4 GB at batch 64, written by y2_bn_act_bwd and read exactly once, here) never exists.
+// A wave walks image row PAIRS (one row of pooling windows); lane (co, half) owns column `half` of every window: it loads its two z
+// values per window, gets the other column's activations from lane ^ 32 (ds_bpermute), finds the window's first maximum in nn.MaxPool2d's
+// scan order, routes the pooled gradient, applies the LeakyReLU derivative and the BatchNorm backward with the pass-1 sums, and feeds the
+// two rows' dz into two MFMA steps (K = the two pixels of a window row, as in conv0_wgrad_kernel).
+namespace {
+
+struct W0FArgs {
+    const float* x; const float* z; const float* scale; const float* shift; const float* mean; const float* invstd; const float* gamma;
+    const float* dy_pool; const double* sums; float* dw;
+    float* partial;
+    int B, H, W, Cin, Cout, ldz, ldp, pairs_total, has_bn;
+    unsigned z_bytes, p_bytes;
+    float slope;
+    double n;
+};
+
+template <int IB>
+__global__ __launch_bounds__(256) void conv0_wgrad_fused_kernel(const W0FArgs a) {
+    __shared__ float red[4][IB * 32 * 33];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int K = a.Cin * 9;
+    const bool jok = l31 < K;
+    const int c = jok ? l31 / 9 : 0;
+    const int ky = jok ? (l31 % 9) / 3 : 0, kx = jok ? l31 % 3 : 0;
+    float sc[IB], sh[IB], mu[IB], is[IB], gs[IB], ma[IB], mb[IB];
+    bool cok[IB];
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        const int co = i * 32 + l31;
+        cok[i] = co < a.Cout;
+        const int cc = cok[i] ? co : 0;
+        sc[i] = a.scale ? a.scale[cc] : 1.f; sh[i] = a.shift ? a.shift[cc] : 0.f;
+        mu[i] = a.has_bn ? a.mean[cc] : 0.f; is[i] = a.has_bn ? a.invstd[cc] : 1.f;
+        if (a.has_bn == 1) { gs[i] = a.gamma[cc] * is[i]; ma[i] = (float)(a.sums[cc] / a.n); mb[i] = (float)(a.sums[a.Cout + cc] / a.n); }
+        else if (a.has_bn == 2) { gs[i] = a.gamma[cc] * is[i]; ma[i] = 0.f; mb[i] = 0.f; }
+        else { gs[i] = 1.f; ma[i] = 0.f; mb[i] = 0.f; }
+    }
+    f32x16 acc[IB];
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int Hh = a.H >> 1, Wh = a.W >> 1;
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z), 0, a.z_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy_pool), 0, a.p_bytes, 0x00020000);
+    for (int pair = wid; pair < a.pairs_total; pair += nw) {          // pair = b*(H/2) + r: image rows 2r, 2r+1
+        const int b = pair / Hh, r = pair - b * Hh;
+        const int y0 = 2 * r;
+        const int yy0 = y0 + ky - 1, yy1 = yy0 + 1;
+        const bool yok0 = jok && (unsigned)yy0 < (unsigned)a.H, yok1 = jok && (unsigned)yy1 < (unsigned)a.H;
+        const float* xr0 = a.x + (((size_t)b * a.Cin + c) * a.H + (yok0 ? yy0 : 0)) * a.W;
+        const float* xr1 = a.x + (((size_t)b * a.Cin + c) * a.H + (yok1 ? yy1 : 0)) * a.W;
+        // z and dy_pool go through buffer descriptors: ONE per-lane byte offset per batch, the 16 pixels of the batch differ in the scalar
+        // offset (pointer arithmetic per load held 100 more registers and halved the occupancy).  Host: W % 16 == 0, tensors < 4 GB.
+        const unsigned zrow = (unsigned)(((size_t)(b * a.H + y0) * a.W + half) * a.ldz * 4u) + (unsigned)l31 * 4u;
+        const unsigned prow = (unsigned)(((size_t)(b * Hh + r) * Wh) * a.ldp * 4u) + (unsigned)l31 * 4u;
+        const unsigned zstep = 2u * (unsigned)a.ldz * 4u, z1off = (unsigned)a.W * (unsigned)a.ldz * 4u, pstep = (unsigned)a.ldp * 4u;
+        for (int x0 = 0; x0 < a.W; x0 += 16) {                       // 8 windows = 16 pixels per row and batch of loads
+            // phase 1: every load of the batch goes out before anything is consumed (40 loads in flight per wave)
+            float z0[IB][8], z1[IB][8], dp[IB][8], bv0[8], bv1[8];
+            const unsigned zb = zrow + (unsigned)x0 * (unsigned)a.ldz * 4u, pb = prow + (unsigned)(x0 >> 1) * pstep;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int px = x0 + 2 * s + half;
+#pragma unroll
+                for (int i = 0; i < IB; ++i) {
+                    z0[i][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, (int)(zb + i * 128u), (int)(s * zstep), 0));
+                    z1[i][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, (int)(zb + i * 128u), (int)(s * zstep + z1off), 0));
+                    dp[i][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (int)(pb + i * 128u), (int)(s * pstep), 0));
+                }
+                const int xx = px + kx - 1;
+                const bool xok = (unsigned)xx < (unsigned)a.W;
+                bv0[s] = (xok && yok0) ? xr0[xx] : 0.f;
+                bv1[s] = (xok && yok1) ? xr1[xx] : 0.f;
+            }
+            // phase 2: pooling-window arg-max, LeakyReLU derivative, BatchNorm backward -> dz of the two rows -> MFMA
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int i = 0; i < IB; ++i) {
+                    const float u0 = z0[i][s] * sc[i] + sh[i], u1 = z1[i][s] * sc[i] + sh[i];
+                    const float v0 = u0 > 0.f ? u0 : u0 * a.slope, v1 = u1 > 0.f ? u1 : u1 * a.slope;
+                    const float o0 = __shfl_xor(v0, 32), o1 = __shfl_xor(v1, 32);          // the window's other column
+                    // scan order q = 0: (row 0, col 0), 1: (row 0, col 1), 2: (row 1, col 0), 3: (row 1, col 1); first maximum wins
+                    const float q0 = half ? o0 : v0, q1 = half ? v0 : o0, q2 = half ? o1 : v1, q3 = half ? v1 : o1;
+                    float best = q0; int arg = 0;
+                    if (q1 > best) { best = q1; arg = 1; }
+                    if (q2 > best) { best = q2; arg = 2; }
+                    if (q3 > best) { best = q3; arg = 3; }
+                    const float g0 = (arg == half) ? dp[i][s] : 0.f, g1 = (arg == 2 + half) ? dp[i][s] : 0.f;
+                    const float ge0 = g0 * (u0 > 0.f ? 1.f : a.slope), ge1 = g1 * (u1 > 0.f ? 1.f : a.slope);
+                    const float zh0 = (z0[i][s] - mu[i]) * is[i], zh1 = (z1[i][s] - mu[i]) * is[i];
+                    // (lanes of channels / pixels that do not exist loaded zeros and hold zero constants only where it matters: mask them)
+                    const bool ok = (x0 + 2 * s + half) < a.W && cok[i];
+                    const float d0 = ok ? gs[i] * (ge0 - ma[i] - zh0 * mb[i]) : 0.f;
+                    const float d1 = ok ? gs[i] * (ge1 - ma[i] - zh1 * mb[i]) : 0.f;
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, bv0[s], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, bv1[s], acc[i], 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[wave][co * 33 + l31] = acc[i][r];
+        }
+    __syncthreads();
+    for (int e = t; e < IB * 32 * 32; e += 256) {
+        const int co = e >> 5, j = e & 31;
+        if (co < a.Cout && j < K) {
+            const float v = red[0][co * 33 + j] + red[1][co * 33 + j] + red[2][co * 33 + j] + red[3][co * 33 + j];
+            if (a.partial != nullptr) a.partial[(size_t)blockIdx.x * a.Cout * K + (size_t)co * K + j] = v;
+            else atomicAdd(a.dw + (size_t)co * K + j, v);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int y2_conv0_wgrad_fused(const float* x_nchw, const float* z, const float* scale, const float* shift, const float* mean, const float* invstd,
+                                    const float* gamma, float slope, const float* dy_pool, int ldp, const double* sums, float* dw,
+                                    int B, int H, int W, int Cin, int Cout, int ldz, int has_bn, y2_stream_t stream) {
+    if (!x_nchw || !z || !dy_pool || !dw || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || ldz < Cout || ldp < Cout) return Y2_EINVAL;
+    if (has_bn < 0 || has_bn > 2 || (has_bn && (!mean || !invstd || !gamma)) || (has_bn == 1 && !sums)) return Y2_EINVAL;
+    if ((H & 1) || (W & 1)) return Y2_EINVAL;
+    if (Cin < 1 || Cin > 3 || Cout > 64 || (W & 15)) return Y2_ENOSUP;
+    const unsigned long long zb = (unsigned long long)B * H * W * ldz * 4ull, pb = (unsigned long long)B * (H / 2) * (W / 2) * ldp * 4ull;
+    if (zb >= 0xffff0000ull) return Y2_ENOSUP;        // 32-bit buffer offsets
+    W0FArgs a;
+    a.z_bytes = (unsigned)zb; a.p_bytes = (unsigned)pb;
+    a.x = x_nchw; a.z = z; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.dy_pool = dy_pool; a.sums = sums; a.dw = dw;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldz = ldz; a.ldp = ldp; a.pairs_total = B * (H / 2); a.has_bn = has_bn; a.slope = slope;
+    a.n = (double)B * H * W;
+    const int grid = a.pairs_total < 4 * 4 * Y2_NUM_CU ? y2_cdiv(a.pairs_total, 4) : 4 * Y2_NUM_CU;
+    a.partial = nullptr;
+    if (y2_det.on) {
+        if ((size_t)grid * Cout * Cin * 9 * sizeof(float) > y2_det.bytes) return Y2_EINVAL;
+        a.partial = y2_det.ws;
+    }
+    const double flops = 2.0 * (double)B * H * W * 9 * Cin * Cout;
+    if (Cout <= 32) Y2_LAUNCH("conv0_wgrad_fused_kernel", flops, (conv0_wgrad_fused_kernel<1>), dim3(grid), dim3(256), 0, y2_s(stream), a);
+    else Y2_LAUNCH("conv0_wgrad_fused_kernel", flops, (conv0_wgrad_fused_kernel<2>), dim3(grid), dim3(256), 0, y2_s(stream), a);
+    Y2_LAUNCH_CHECK();
+    if (a.partial != nullptr) return y2_det_reduce_f32(a.partial, grid, (long long)Cout * Cin * 9, (long long)Cout * Cin * 9, nullptr, dw, y2_s(stream));
+    return Y2_OK;
+}
+
 extern "C" int y2_conv0_wgrad(const float* x_nchw, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, int ldz, y2_stream_t stream) {
     if (!x_nchw || !dz || !dw || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || ldz < Cout) return Y2_EINVAL;
     if (Cin < 1 || Cin > 3 || Cout > 64) return Y2_ENOSUP;

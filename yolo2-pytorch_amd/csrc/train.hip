@@ -608,7 +608,8 @@ extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float*
                                 float slope, const float* dy_full, int ldf, int foff, int fmode, const float* dy_pool, int ldp, int poff,
                                 const float* dy_full2, int ld2, const float* residual, int ldr, float* dres, int lddr,
                                 double* sums, float* dz, int ldd, int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream) {
-    if (!z || (!dy_full && !dy_pool) || !sums || !dz || B <= 0 || H <= 0 || W <= 0 || C <= 0) return Y2_EINVAL;
+    if (!z || (!dy_full && !dy_pool) || !sums || B <= 0 || H <= 0 || W <= 0 || C <= 0) return Y2_EINVAL;      // dz == NULL: the sums only (pass 1)
+    if (dz == nullptr && dres != nullptr) return Y2_EINVAL;
     if (has_bn < 0 || has_bn > 2 || (has_bn && (!mean || !invstd || !gamma))) return Y2_EINVAL;
     const bool pool = dy_pool != nullptr;
     if ((pool || fmode == 1) && ((H & 1) || (W & 1))) return Y2_EINVAL;
@@ -619,7 +620,7 @@ extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float*
     a.B = B; a.H = H; a.W = W; a.C = C; a.ldz = ldz; a.ldf = ldf; a.foff = foff; a.fmode = fmode; a.ldp = ldp; a.poff = poff; a.ldd = ldd;
     a.slope = slope; a.n = (double)B * H * W; a.has_bn = has_bn;
     a.dy_full2 = dy_full2; a.ld2 = ld2; a.res = residual; a.ldr = ldr; a.dres = dres; a.lddr = lddr;
-    const bool vec = (!dy_full2 || (!(ld2 & 3) && y2_aligned16(dy_full2))) && (!residual || (!(ldr & 3) && y2_aligned16(residual))) && (!dres || (!(lddr & 3) && y2_aligned16(dres))) && !(C & 3) && !(ldz & 3) && !(ldd & 3) && y2_aligned16(z) && y2_aligned16(dz) &&
+    const bool vec = (!dy_full2 || (!(ld2 & 3) && y2_aligned16(dy_full2))) && (!residual || (!(ldr & 3) && y2_aligned16(residual))) && (!dres || (!(lddr & 3) && y2_aligned16(dres))) && !(C & 3) && !(ldz & 3) && (!dz || (!(ldd & 3) && y2_aligned16(dz))) && y2_aligned16(z) &&
                      (!dy_full || (!(ldf & 3) && !(foff & 3) && y2_aligned16(dy_full))) && (!pool || (!(ldp & 3) && !(poff & 3) && y2_aligned16(dy_pool)));
     const int Cg = vec ? C / 4 : C;
     const long long pix = (long long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
@@ -642,7 +643,7 @@ extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float*
             const int rc_ = y2_det_reduce_f32(a.partial, (int)prow, (long long)2 * C, (long long)2 * C, sums, nullptr, s);            \
             if (rc_ != Y2_OK) return rc_;                                                                            \
         }                                                                                                            \
-        Y2_LAUNCH("bn_act_bwd_kernel", 0.0, (bn_act_bwd_kernel<POOL, CV, true>), dim3(grid), dim3(256), 0, s, a, total);               \
+        if (dz != nullptr) Y2_LAUNCH("bn_act_bwd_kernel", 0.0, (bn_act_bwd_kernel<POOL, CV, true>), dim3(grid), dim3(256), 0, s, a, total);               \
     } while (0)
     if (pool) { if (vec) Y2_BWD(true, 4); else Y2_BWD(true, 1); }
     else { if (vec) Y2_BWD(false, 4); else Y2_BWD(false, 1); }

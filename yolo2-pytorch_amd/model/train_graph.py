@@ -36,6 +36,7 @@ def _side_stream(dev):
     return s
 
 
+FUSE_CONV0 = os.environ.get('Y2_FUSE_CONV0', '1') != '0'      # 0: materialise the first layer's dz and run the two-kernel form (A/B runs)
 DEBUG_TAP = None        # tools/debug: callable(block name, dz, dx) invoked per block of the Darknet backward
 
 SYNC_POSITIVES = True   # data parallel: all-reduce the positive count so the cls mean is over the global batch
@@ -504,8 +505,12 @@ def _darknet_bwd(ctx, dout):
         # the wgrad / dgrad DMA kernels want channel counts that are multiples of 4: an unaligned Cout (the 125 / 425 channel head)
         # is handled in a zero-padded channel space here; unaligned widths elsewhere were padded by the forward (_pad_layout)
         cop = (cout + 3) // 4 * 4
-        dz = dzs[i] if i in dzs else _new(dev, B, h, w, cop)
         sf, sp = src_full[i], src_pool[i]
+        # first layer (model/yolo2.py:78-79: conv + pool, nothing below it needs a data gradient): its dz is consumed by the weight gradient
+        # alone, which forms it on the fly from (z, dy_pool) and the pass-1 sums - no dz tensor (1.4 GB at batch 64), no second pass
+        fuse0 = (FUSE_CONV0 and blk.first and i in wg and sf is None and sp is not None and not (h & 1) and not (w & 15)
+                 and B * h * w * cout * 4 < 0xffff0000)
+        dz = None if fuse0 else (dzs[i] if i in dzs else _new(dev, B, h, w, cop))
         if DEBUG_TAP is not None:
             DEBUG_TAP(blk.name + ':in', blk.z, blk.shift, sf, sp)
         _hip.check(L.y2_bn_act_bwd(_hip.ptr(blk.z), _hip.ptr(blk.scale), _hip.ptr(blk.shift), _hip.ptr(blk.mean), _hip.ptr(blk.invstd),
@@ -535,6 +540,12 @@ def _darknet_bwd(ctx, dout):
             return dw
 
         def weight_grad(st_w):
+            if i in wg and blk.first and fuse0:
+                dw0 = wg[i][0]
+                _hip.check(L.y2_conv0_wgrad_fused(_hip.ptr(ctx.x), _hip.ptr(blk.z), _hip.ptr(blk.scale), _hip.ptr(blk.shift), _hip.ptr(blk.mean), _hip.ptr(blk.invstd),
+                                                  _hip.ptr(e.gamma) if blk.has_bn else None, blk.slope, _hip.ptr(sp), cout, _hip.ptr(sums), _hip.ptr(dw0),
+                                                  B, h, w, cin, cout, cout, (2 if ctx.frozen else 1) if blk.has_bn else 0, st_w), 'y2_conv0_wgrad_fused')
+                return real(dw0)
             if i in wg and blk.first:
                 dw0 = wg[i][0]
                 _hip.check(L.y2_conv0_wgrad(_hip.ptr(ctx.x), _hip.ptr(dz), _hip.ptr(dw0), B, h, w, cin, cout, cop, st_w), 'y2_conv0_wgrad')
@@ -563,7 +574,7 @@ def _darknet_bwd(ctx, dout):
             with torch.cuda.stream(side):
                 side.wait_event(ev)
                 gw = weight_grad(_hip.stream())
-                for tns in (dz, blk.x, blk.wino_v, ctx.x):       # read on the side stream: the allocator must not recycle them under it
+                for tns in (dz, blk.x, blk.wino_v, ctx.x) + ((blk.z, sp) if fuse0 else ()):       # read on the side stream: the allocator must not recycle them under it
                     if tns is not None:
                         tns.record_stream(side)
                 done = torch.cuda.Event()
@@ -591,7 +602,7 @@ def _darknet_bwd(ctx, dout):
                 wd = _new(dev, wsrc.numel())
                 _hip.check(L.y2_pack_weight(_hip.ptr(wsrc), _hip.ptr(wd), cop, cin, k, 1, st), 'y2_pack_weight')
                 _conv(L, st, dz, wd, dx, B, h, w, cop, cop, cin, k, cin)
-            if DEBUG_TAP is not None:
+            if DEBUG_TAP is not None and dz is not None:
                 DEBUG_TAP(blk.name, dz, dx, None, None)
             # route dx
             if blk.name == 'layers3.0':
