@@ -64,6 +64,7 @@ def parse_args():
     ap.add_argument('--train-batch', type=int, default=64, help='per-GPU batch of the train leg (BASELINE configs[2])')
     ap.add_argument('--rotate', type=int, default=4, help='number of different resident input batches the timed steps rotate over')
     ap.add_argument('--no-graph', action='store_true', help='launch the detect step eagerly instead of replaying captured hipGraphs')
+    ap.add_argument('--streams', type=int, default=2, help='HIP streams the detect steps are pipelined over (2: batch i+1 starts while the last workgroups of batch i drain; 1: strictly serial)')
     ap.add_argument('--no-train', action='store_true')
     ap.add_argument('--no-detect', action='store_true')
     ap.add_argument('--no-direct-leg', action='store_true', help='skip the Winograd-off measurements')
@@ -250,29 +251,50 @@ def detect_leg(args, ctx):
         with torch.no_grad():
             return detect.detect_batch(dnn.forward_nhwc(xs[i % len(xs)]), anchors, **kw)
 
-    def measure(steps, warmup, want_table):
+    def measure(steps, warmup, want_table, want_streams=None):
         for i in range(warmup):
             eager(i)
         ctx.sync()
         table = kernel_table(eager, min(steps, 8)) if want_table else None
         runs = None
+        nstreams = max(1, min(args.streams if want_streams is None else want_streams, len(xs))) if (not args.no_graph and args.model == 'darknet') else 1
         if not args.no_graph:
-            try:      # one captured graph per resident batch (they share the plan's intermediate buffers; replays are serial)
-                runs = [detect.GraphedDetector(dnn, anchors, x, static_input=True, **kw) for x in xs]
+            try:      # one captured graph per resident batch; graph i runs in buffer slot i % nstreams on stream i % nstreams: graphs of one
+                      # slot share intermediate buffers and are serial on their stream, different slots overlap
+                runs = [detect.GraphedDetector(dnn, anchors, x, static_input=True, slot=i % nstreams, **kw) if nstreams > 1 else
+                        detect.GraphedDetector(dnn, anchors, x, static_input=True, **kw) for i, x in enumerate(xs)]
             except Exception as e:
                 print('hipGraph capture failed (%s); eager launches' % e, file=sys.stderr)
-                runs = None
-        fn = (lambda i: runs[i % len(runs)].run()) if runs is not None else eager
+                runs, nstreams = None, 1
+        streams = [torch.cuda.Stream() for _ in range(nstreams)] if nstreams > 1 else None
+
+        def replay(i):
+            g = i % len(runs)
+            if streams is None:
+                runs[g].run()
+            else:
+                with torch.cuda.stream(streams[g % nstreams]):
+                    runs[g].run()
+        fn = replay if runs is not None else eager
+        measure.nstreams = nstreams
         for i in range(2 * len(xs)):
             fn(i)
         dt, host = ctx.timed(fn, steps)
         return dt, host, table, runs is not None
 
     dt, host, table, graphed = measure(args.steps, args.warmup, ctx.world == 1)
+    pipelined = getattr(measure, 'nstreams', 1)
+    serial_dt = None
+    if pipelined > 1 and ctx.world == 1:          # the same graphs strictly one after the other: the latency of a step, reported beside the throughput
+        serial_steps = min(args.steps, 24)
+        serial_dt = measure(serial_steps, 0, False, want_streams=1)[0] / serial_steps
+        measure.nstreams = pipelined
     images = args.batch * args.steps * ctx.world
     out = {'images_per_sec': round(images / dt, 2), 'ms_per_step': round(dt / args.steps * 1e3, 4), 'steps': args.steps,
-           'host_ms_per_step': round(host / args.steps * 1e3, 4), 'launch': 'hipGraph replay' if graphed else 'eager',
-           'resident_batches_rotated': len(xs), 'per_gpu_batch': args.batch,
+           'host_ms_per_step': round(host / args.steps * 1e3, 4),
+           'launch': ('hipGraph replay, steps pipelined over %d streams (private buffers per stream)' % measure.nstreams if getattr(measure, 'nstreams', 1) > 1 else 'hipGraph replay') if graphed else 'eager',
+           'resident_batches_rotated': len(xs), 'per_gpu_batch': args.batch, 'streams': pipelined,
+           'serial_ms_per_step': None if serial_dt is None else round(serial_dt * 1e3, 4), 'serial_images_per_sec': None if serial_dt is None else round(args.batch / serial_dt, 2),
            'parallelism': 'replicas x%d (no collective)' % ctx.world if ctx.world > 1 else 'single GPU'}
     roof = None
     if table is not None:
@@ -718,7 +740,8 @@ def main():
             extra.update(multiscale_images_per_sec=ms['images_per_sec'], multiscale_ms_per_step_mean=ms['ms_per_step_mean'], multiscale_switch_cost_ms_mean=ms['switch_cost_ms_mean'],
                          multiscale_switch_cost_ms_max=ms['switch_cost_ms_max'], multiscale_first_visit_ms_mean=ms['first_visit_ms_mean'])
         if ok(det):
-            extra.update(detect_images_per_sec=det['images_per_sec'], detect_ms_per_step=det['ms_per_step'])
+            extra.update(detect_images_per_sec=det['images_per_sec'], detect_ms_per_step=det['ms_per_step'], detect_streams=det.get('streams'),
+                         detect_serial_images_per_sec=det.get('serial_images_per_sec'), detect_serial_ms_per_step=det.get('serial_ms_per_step'))
         if roof is not None:
             if 'conv_chain' in roof:
                 extra.update(conv_chain_ms_per_step=roof['conv_chain']['ms_per_step'], conv_chain_frac=roof['conv_chain']['frac'])

@@ -310,3 +310,34 @@ def test_first_layer_weight_gradient_without_a_materialised_dz(B, H, W, cin, cou
     _hip.check(L.y2_conv0_wgrad_fused(_hip.ptr(x), _hip.ptr(z), _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(mean) if has_bn else None, _hip.ptr(invstd) if has_bn else None,
                                       _hip.ptr(gamma) if has_bn else None, 0.1, _hip.ptr(dyp), cout, _hip.ptr(sums_b), _hip.ptr(got), B, H, W, cin, cout, cout, has_bn, st), 'fused')
     assert rel(got, want.cpu()) <= 2e-6, rel(got, want.cpu())
+
+
+def test_detectors_in_different_slots_overlap_on_two_streams():
+    """Serving-style pipelining: two captured detect steps with private intermediate buffers (slot 0 / 1) replayed concurrently on two HIP
+    streams give exactly the results of serial replays (no shared scratch, tile counters or outputs)."""
+    import detect
+    sd = odark.init_state_dict(5, 20, seed=0, channels=NARROW, head_scale=1 / 8.0)
+    inf, anchors = build(sd)
+    inf.eval()
+    xs = [synth.images(4, 160, seed=s).to(dev()) for s in (1, 2)]
+    kw = dict(fix=True, threshold_cls=0.005, overlap=0.45, limit=200)
+    serial = []
+    with torch.no_grad():
+        for x in xs:
+            d = detect.detect_batch(inf.dnn.forward_nhwc(x), anchors, **kw)
+            serial.append({k: v.clone() for k, v in d.items()})
+    runs = [detect.GraphedDetector(inf.dnn, anchors, x, static_input=True, slot=i, **kw) for i, x in enumerate(xs)]
+    streams = [torch.cuda.Stream() for _ in runs]
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for r, s in zip(runs, streams):
+            with torch.cuda.stream(s):
+                r.run()
+    torch.cuda.synchronize()
+    for r, want in zip(runs, serial):
+        for k in ('iou', 'yx_min', 'yx_max', 'prob', 'count', 'keep_count'):
+            assert torch.equal(r.result[k], want[k]), k
+        kc = want['keep_count'].tolist()
+        for b, c in enumerate(kc):
+            assert torch.equal(r.result['keep'][b, :c], want['keep'][b, :c])
+    assert len(inf.dnn._plans.d) == 2          # one plan per slot

@@ -10,13 +10,16 @@ import json
 import re
 import sys
 
-FAMILY = re.compile(r'conv_fwd_dma_kernel|conv_splitk_fixup_kernel|wino_(input|output|fused2?|tile_table)_kernel|conv0_kernel')
+FAMILY = re.compile(r'conv_fwd_dma_kernel|conv_splitk_fixup_kernel|wino_(input|output|fused2?|tile_table)_kernel|conv0_kernel|gemm_split_kernel|wino_input_split_kernel')
+TRAIN = len(sys.argv) > 2 and sys.argv[2] == 'train'       # every kernel of the training step; steps = loss_fwd_kernel dispatches
+if TRAIN:
+    FAMILY = re.compile(r'.')
 rows = []
 for line in open(sys.argv[1]):
     m = re.match(r'(\S+)\s+(\S+)\s+dispatches=\s*(\d+)\s+mean_per_dispatch=([0-9.eE+-]+)', line)
     if m:
         rows.append((m.group(1), m.group(2), int(m.group(3)), float(m.group(4))))
-steps = max([n for k, c, n, v in rows if 'conv0_kernel' in k and c == 'FETCH_SIZE'] + [1])
+steps = max([n for k, c, n, v in rows if ('loss_fwd_kernel' if TRAIN else 'conv0_kernel') in k and c == 'FETCH_SIZE'] + [1])
 tot = {'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0}
 launches = 0
 for k, c, n, v in rows:
@@ -26,7 +29,8 @@ for k, c, n, v in rows:
             launches += n
 fetch, write = tot['FETCH_SIZE'] / steps, tot['WRITE_SIZE'] / steps
 print(json.dumps({
-    'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile.sh) on `bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3` (autotune cache pre-populated); conv0 + conv_fwd_dma_kernel family + split-K fix-up + all Winograd kernels',
+    'source': ('rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile_r3.sh) on `tools/train_steady.py` (autotune cache pre-populated): every kernel of the training step' if TRAIN else
+               'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile_r3.sh) on `bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3 --no-split-leg --no-multiscale` (autotune cache pre-populated); conv0 + conv_fwd_dma_kernel family + split-K fix-up + all Winograd kernels'),
     'kernel_launches_profiled': launches, 'steps_profiled': steps,
     'fetch_size_bytes_raw_per_step': fetch, 'write_size_bytes_raw_per_step': write,
     'correction': 'gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE uncorrected; counters are L2 memory-side requests, Infinity-Cache hits included',

@@ -139,14 +139,16 @@ class GraphedDetector(object):
     The graph bakes in the pointers of the packed / folded weights: after the parameters change (optimizer step, load_state_dict,
     a training forward) a replay would use stale weights, so `run` checks the plugin's cache key and refuses."""
 
-    def __init__(self, dnn, anchors, example, fix=True, threshold=0.3, threshold_cls=0.005, overlap=0.45, limit=200, warmup=2, static_input=False):
+    def __init__(self, dnn, anchors, example, fix=True, threshold=0.3, threshold_cls=0.005, overlap=0.45, limit=200, warmup=2, static_input=False, slot=0):
+        """slot: detectors captured in different slots own different intermediate buffers (model.yolo2.Darknet.forward_nhwc) and may be
+        replayed concurrently on different streams; detectors of one slot share them and must be replayed one after the other."""
         self.static_x = example if static_input else example.clone()
         self.dnn = dnn
         kw = dict(fix=fix, threshold=threshold, threshold_cls=threshold_cls, overlap=overlap, limit=limit)
 
         def step():
             with torch.no_grad():
-                return detect_batch(dnn.forward_nhwc(self.static_x), anchors, **kw)
+                return detect_batch(dnn.forward_nhwc(self.static_x, slot) if slot else dnn.forward_nhwc(self.static_x), anchors, **kw)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):          # warm-up on a side stream: one-time attribute/symbol calls, plan + weight packing

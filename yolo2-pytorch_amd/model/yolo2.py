@@ -218,10 +218,12 @@ class Darknet(nn.Module):
         p.tile = 0
         return p, 2.0 * cin * cout * blk.kernel_size ** 2 * B * H * W
 
-    def _plan(self, prep, dev, B, cin0, H, W):
+    def _plan(self, prep, dev, B, cin0, H, W, slot=0):
         """Execution plan for one input shape: intermediate NHWC buffers (never exposed, reused across calls) and the
         y2_conv_params array of the 22 generic convolutions (model/yolo2.py:76-113 in execution order)."""
-        key = (str(dev), B, cin0, H, W, _hip.tune_epoch(), _hip.WINOGRAD, _hip.FORCE_ALGO, _hip.SPLIT)
+        # slot: plans of the same shape with PRIVATE intermediate buffers and scratch, so that two batches can be in flight on two streams
+        # (detect.GraphedDetector(slot=...): the tail of one batch's kernels overlaps the head of the next batch's)
+        key = (str(dev), B, cin0, H, W, _hip.tune_epoch(), _hip.WINOGRAD, _hip.FORCE_ALGO, _hip.SPLIT, slot)
         plan = self._plans.get(key)
         if plan is not None:
             if plan['prep'] is not prep:
@@ -305,7 +307,10 @@ class Darknet(nn.Module):
         for p, u, blk in zip(plist, ulist, blks):
             _hip.autotune_conv(p, dev, wino_w=u, wino_split=prep.get('split', {}).get(blk))      # per-layer algorithm + tile choice by measurement (cached per problem shape)
         need = max([_hip.lib().y2_conv_fwd_workspace_bytes(ctypes.byref(p)) for p in plist] + [0])
-        ws = _hip.workspace(dev, need) if need > 0 else None
+        if slot == 0:
+            ws = _hip.workspace(dev, need) if need > 0 else None
+        else:
+            ws = new(int(need) // 4 + 4) if need > 0 else None      # (the per-device scratch is shared by everything that runs on ONE stream)
         for p in plist:
             p.workspace, p.workspace_bytes = (ws.data_ptr(), ws.numel() * 4) if ws is not None else (None, 0)
         arr = (_hip.ConvParams * len(plist))(*plist)
@@ -318,9 +323,10 @@ class Darknet(nn.Module):
         self._plans.put(key, plan, nbytes[0])
         return plan
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, slot=0):
         """x [B,Cin,H,W] NCHW fp32 on the GPU -> head image [B, H/32, W/32, A*(5+C)] (NHWC, contiguous).
-        Inference path (folded BatchNorm): one y2_conv0_fwd + one y2_conv_fwd_batch call."""
+        Inference path (folded BatchNorm): one y2_conv0_fwd + one y2_conv_fwd_batch call.  `slot`: which private set of intermediate
+        buffers to run in (calls that may overlap on different streams must use different slots)."""
         _hip.require_gpu(x)
         L = _hip.lib()
         x = _hip.f32c(x)
@@ -329,7 +335,7 @@ class Darknet(nn.Module):
             raise ValueError('input size must be a multiple of 32 (got %dx%d)' % (H, W))
         dev = x.device
         prep = self._prepare_eval(dev)
-        plan = self._plan(prep, dev, B, cin0, H, W)
+        plan = self._plan(prep, dev, B, cin0, H, W, slot)
         st = _hip.stream()
         blk0 = self.layers1[0]
         wp, scale, shift, _ = prep[blk0]
