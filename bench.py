@@ -488,6 +488,8 @@ def train_leg(args, ctx):
         out['roofline'] = roofline_from(table, 'training step, batch %d: fprop / dgrad / wgrad kernels with their executed FLOPs; per-kernel durations measured single-stream '
                                                '(the timed step runs the weight gradients on a side stream, Y2_BWD_STREAMS=%d)' % (B, streams))
         out['roofline']['kernel_ms_sum_single_stream'] = round(sum(e['ms'] for e in table.values()), 3)
+        if B == 64 and S == 416 and args.model == 'darknet' and args.classes == 20:
+            out['roofline']['traffic'], out['roofline']['traffic_source'] = static_traffic('train_b64')
     del step, last, keep
     torch.cuda.empty_cache()
     return out
@@ -728,7 +730,7 @@ def main():
             extra.update(train_images_per_sec=tr['images_per_sec'], train_ms_per_step=tr['ms_per_step'], train_host_ms_per_step=tr['host_ms_per_step'])
             r = tr.get('roofline')
             if r:
-                extra.update(train_mfma_frac=r['all_mfma_kernels']['frac'], train_mfma_ms_per_step=r['all_mfma_kernels']['ms_per_step'],
+                extra.update(train_traffic_bytes_per_step=r.get('traffic'), train_mfma_frac=r['all_mfma_kernels']['frac'], train_mfma_ms_per_step=r['all_mfma_kernels']['ms_per_step'],
                              train_kernel_ms_sum_single_stream=r.get('kernel_ms_sum_single_stream'), train_dominant_kernel=r['kernel'], train_dominant_frac=r['frac'],
                              train_dominant_avg_launch_us=r['avg_launch_us'])
         if ok(conv3):

@@ -19,6 +19,11 @@ grep -E '^\{' $O/det_trace.log | tail -1 > $O/detect_b32_bench_under_trace.json
 prof trn_trace "" $TRN
 python3 $R/tools/rocprof_summary.py stats $(find $O/trn_trace -name '*.db' | head -1) > $O/train_b64_kernel_stats.txt
 grep -E '^\{' $O/trn_trace.log | tail -1 > $O/train_b64_steady_under_trace.json
+# the same steps with the weight gradients on the MAIN stream: per-kernel durations without co-running kernels - what bench.py's train
+# roofline table reports (the two-stream schedule of the timed step inflates the durations of kernels that overlap)
+Y2_BWD_STREAMS=1 prof trn_trace1 "" $TRN
+python3 $R/tools/rocprof_summary.py stats $(find $O/trn_trace1 -name '*.db' | head -1) > $O/train_b64_single_stream_kernel_stats.txt
+grep -E '^\{' $O/trn_trace1.log | tail -1 > $O/train_b64_single_stream_under_trace.json
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   i=$((i+1)); prof det_pmc$i "$set" $DET; prof trn_pmc$i "$set" $TRN
