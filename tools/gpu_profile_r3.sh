@@ -15,6 +15,7 @@ prof() {  # tag, pmc-set-or-empty, command...
 }
 prof det_trace "" $DET
 python3 $R/tools/rocprof_summary.py stats $(find $O/det_trace -name '*.db' | head -1) > $O/detect_b32_kernel_stats.txt
+python3 $R/tools/rocprof_summary.py by_grid $(find $O/det_trace -name '*.db' | head -1) > $O/detect_b32_kernel_stats_by_grid.txt
 grep -E '^\{' $O/det_trace.log | tail -1 > $O/detect_b32_bench_under_trace.json
 prof trn_trace "" $TRN
 python3 $R/tools/rocprof_summary.py stats $(find $O/trn_trace -name '*.db' | head -1) > $O/train_b64_kernel_stats.txt
@@ -23,6 +24,7 @@ grep -E '^\{' $O/trn_trace.log | tail -1 > $O/train_b64_steady_under_trace.json
 # roofline table reports (the two-stream schedule of the timed step inflates the durations of kernels that overlap)
 Y2_BWD_STREAMS=1 prof trn_trace1 "" $TRN
 python3 $R/tools/rocprof_summary.py stats $(find $O/trn_trace1 -name '*.db' | head -1) > $O/train_b64_single_stream_kernel_stats.txt
+python3 $R/tools/rocprof_summary.py by_grid $(find $O/trn_trace1 -name '*.db' | head -1) > $O/train_b64_single_stream_kernel_stats_by_grid.txt
 grep -E '^\{' $O/trn_trace1.log | tail -1 > $O/train_b64_single_stream_under_trace.json
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do

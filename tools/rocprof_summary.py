@@ -62,8 +62,26 @@ def listing(path, start_frac=0.0, count=400):
         print('%-62s wgs=%7d dur=%9.1fus gap=%7.1fus' % (short, gx // max(wx, 1) * max(gy, 1), (en - st) / 1e3, gap))
 
 
+def stats_by_grid(path):
+    """Per (kernel, workgroup count): launches of one template instance that do different jobs (a grouped Winograd GEMM and a 1x1
+    convolution run the same conv_fwd_dma_kernel instantiation) are told apart by their grids."""
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    t = tables(cur)
+    kd = [x for x in t if x.startswith('rocpd_kernel_dispatch')][0]
+    ks = [x for x in t if x.startswith('rocpd_info_kernel_symbol')][0]
+    rows = list(cur.execute(f"select s.kernel_name, d.grid_size_x / max(d.workgroup_size_x, 1) * max(d.grid_size_y, 1), count(*), sum(d.end-d.start)/1e3, avg(d.end-d.start)/1e3, "
+                            f"min(d.end-d.start)/1e3, max(d.end-d.start)/1e3 from {kd} d join {ks} s on d.kernel_id=s.id group by s.kernel_name, 2 order by 4 desc"))
+    tot = sum(r[3] for r in rows)
+    print('%-92s %8s %6s %12s %10s %10s %10s %6s' % ('kernel', 'wgs', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', '%'))
+    for r in rows:
+        print('%-92s %8d %6d %12.1f %10.1f %10.1f %10.1f %6.2f' % (r[0].replace('_ZN12_GLOBAL__N_1', '').replace('.kd', '')[:92], r[1], r[2], r[3], r[4], r[5], r[6], 100 * r[3] / tot))
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'list':
+    if sys.argv[1] == 'by_grid':
+        stats_by_grid(sys.argv[2])
+    elif sys.argv[1] == 'list':
         listing(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.0, int(sys.argv[4]) if len(sys.argv) > 4 else 400)
     elif sys.argv[1] == 'stats':
         stats(sys.argv[2])
