@@ -255,6 +255,14 @@ def detect_leg(args, ctx):
         for i in range(warmup):
             eager(i)
         ctx.sync()
+        if ctx.world > 1 and not getattr(measure, 'synced', False):
+            # replicas: every rank measured its own algorithm choices during the warm-up; near-ties resolve differently and the job's rate
+            # is the slowest replica's - adopt rank 0's table (the plans are rebuilt on it by the next call)
+            import train as y2train
+            measure.synced = True
+            measure.tune_synced = y2train.sync_tune(ctx.dev)
+            eager(0)
+            ctx.sync()
         table = kernel_table(eager, min(steps, 8)) if want_table else None
         runs = None
         nstreams = max(1, min(args.streams if want_streams is None else want_streams, len(xs))) if (not args.no_graph and args.model == 'darknet') else 1
@@ -296,6 +304,8 @@ def detect_leg(args, ctx):
            'resident_batches_rotated': len(xs), 'per_gpu_batch': args.batch, 'streams': pipelined,
            'serial_ms_per_step': None if serial_dt is None else round(serial_dt * 1e3, 4), 'serial_images_per_sec': None if serial_dt is None else round(args.batch / serial_dt, 2),
            'parallelism': 'replicas x%d (no collective)' % ctx.world if ctx.world > 1 else 'single GPU'}
+    if ctx.world > 1:
+        out['autotune_choices_synced'] = getattr(measure, 'tune_synced', None)
     roof = None
     if table is not None:
         roof = roofline_from(table, 'detect step, batch %d (eager launches of the same kernels the timed hipGraph replays)' % args.batch)

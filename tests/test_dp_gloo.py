@@ -126,6 +126,14 @@ def worker(rank, world, port, tmp):
     cnt = torch.tensor([float(rank + 1)])
     assert red(cnt) and cnt.item() == 3.0
     assert getattr(m(x[shard]), train_graph.DP_TAG, None) is None       # the bare module's outputs carry none
+    # replicated inference: every rank adopts rank 0's measured algorithm table
+    import _hip
+    _hip._TUNE.clear()
+    _hip._TUNE[(32, 13, 13, 1024, 'cpu')] = [rank + 1, 5]
+    epoch = _hip.tune_epoch()
+    assert train.sync_tune(torch.device('cpu')) == 1
+    assert _hip._TUNE[(32, 13, 13, 1024, 'cpu')] == [1, 5]
+    assert (_hip.tune_epoch() != epoch) == (rank != 0)          # plans built on the old choices are invalidated where the table changed
     if rank == 0:
         open(os.path.join(tmp, 'ok'), 'w').write('ok')
     dist.barrier()

@@ -307,6 +307,33 @@ class DataParallelRCCL(nn.Module):
         return out
 
 
+def sync_tune(dev=None, group=None):
+    """Every rank adopts rank 0's measured algorithm table (replicated inference, or any model without the wrapper): the same collective
+    DataParallelRCCL runs per new input shape.  Returns the number of entries adopted (None without torch.distributed)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return None
+    import _hip
+    dev = torch.device('cuda', torch.cuda.current_device()) if (dev is None and torch.cuda.is_available()) else dev
+    first = dist.get_rank(group) == 0
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    table = None
+    if first:
+        try:
+            table = _hip.export_tune()
+        except Exception as e:
+            logging.warning('autotune choices not exported: %s' % e)
+    box = [table]
+    if dev is None or dev.type != 'cuda' or dist.get_backend(group) == 'gloo':
+        dist.broadcast_object_list(box, src=src, group=group)
+    else:
+        dist.broadcast_object_list(box, src=src, group=group, device=dev)
+    if box[0] is None or dev is None:
+        return None
+    if not first:
+        _hip.import_tune(box[0], dev)
+    return len(box[0])
+
+
 def init_distributed():
     """One process per GPU: reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set by torch.distributed.run."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
