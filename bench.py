@@ -45,7 +45,7 @@ PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0     # opt-in split mode: six bf1
 
 
 def kernel_peak(name):
-    return PEAK_SPLIT_TFLOPS if name.startswith('gemm_split') else PEAK_FP32_MFMA_TFLOPS
+    return PEAK_BF16_MFMA_TFLOPS / 3.0 if name.startswith('gemm_split_f16') else PEAK_SPLIT_TFLOPS if name.startswith('gemm_split') else PEAK_FP32_MFMA_TFLOPS
 FLOPS_FWD_PER_IMG = 29.360e9           # sum over the 23 convs of 2*Cin*Cout*k*k*H*W at 416x416, VOC-20
 FLOPS_TRAIN_PER_IMG = 87.78e9          # fwd + wgrad + dgrad (all but the first conv)
 
@@ -334,33 +334,39 @@ def detect_leg(args, ctx):
                 _hip.WINOGRAD = True
                 dnn._plan_cache = None
         if _hip.WINOGRAD and not _hip.SPLIT and args.model == 'darknet' and not args.no_split_leg:
-            # opt-in precision mode, reported BESIDE the fp32-MFMA headline: the Winograd GEMMs of the layers where it measures faster run
-            # on the bf16 pipe from three bf16 planes per fp32 operand (six plane products); same parity tests (tests/test_gpu_split.py,
-            # the forced 'split' plan of tests/test_gpu_fullsize.py)
+            # opt-in precision modes, reported BESIDE the fp32-MFMA headline: the Winograd GEMMs of the layers where it measures faster run on the
+            # bf16 / fp16 matrix pipe from split operands (bf16x6: three bf16 planes, six plane products; f16x3: two scaled fp16 planes, three
+            # products); same parity tests (tests/test_gpu_split.py, every test of tests/test_gpu_fullsize.py in each mode)
             with torch.no_grad():
                 ref_feat = dnn.forward_nhwc(xs[0]).clone()
-            _hip.SPLIT = True
-            dnn._cache = None
-            dnn._plan_cache = None
-            try:
-                sdt, _, stable, _ = measure(min(args.steps, 20), 3, True)
-                with torch.no_grad():
-                    got = dnn.forward_nhwc(xs[0])
-                plan = dnn._plan_cache[1]
-                sroof = roofline_from(stable, 'the same step in the split-bf16 mode')
-                gs = [r for r in sroof['top_kernels'] if r['kernel'].startswith('gemm_split')]
-                roof['split_bf16x6'] = {'dtype': 'f32 operands as 3 bf16 planes, 6 plane products per multiply on the bf16 MFMA pipe (fp32 accumulate); transforms fp32',
-                                        'images_per_sec': round(args.batch * min(args.steps, 20) / sdt, 2), 'ms_per_step': round(sdt / min(args.steps, 20) * 1e3, 4),
-                                        'layers_on_split_gemm': int(sum(1 for i in range(plan['n']) if plan['arr'][i].algo == 4)),
-                                        'feature_max_abs_diff_over_rms_vs_fp32_mfma_plan': float(((got - ref_feat).abs().max() / ref_feat.pow(2).mean().sqrt()).item()),
-                                        'gemm_split_kernel': gs[0] if gs else None, 'kernel_ms_per_step': sroof['kernel_ms_per_step'],
-                                        'parity': 'same tests as the fp32 path: tests/test_gpu_split.py (GEMM / conv vs fp64), tests/test_gpu_fullsize.py forced plan "split" (2e-5 x rms vs fp64 at batch 32)'}
-            except Exception as e:
-                roof['split_bf16x6'] = {'error': '%s: %s' % (type(e).__name__, e)}
-            finally:
-                _hip.SPLIT = False
+            for mode, tag, peak in (('bf16', 'split_bf16x6', PEAK_BF16_MFMA_TFLOPS / 6.0), ('f16', 'split_f16x3', PEAK_BF16_MFMA_TFLOPS / 3.0)):
+                _hip.SPLIT = mode
                 dnn._cache = None
                 dnn._plan_cache = None
+                try:
+                    sdt, _, stable, _ = measure(min(args.steps, 20), 3, True)
+                    with torch.no_grad():
+                        got = dnn.forward_nhwc(xs[0])
+                    plan = dnn._plan_cache[1]
+                    sroof = roofline_from(stable, 'the same step in the %s mode' % tag)
+                    gs = [r for r in sroof['top_kernels'] if r['kernel'].startswith('gemm_split')]
+                    roof[tag] = {'dtype': ('f32 operands as 3 bf16 planes, 6 plane products per multiply on the bf16 MFMA pipe' if mode == 'bf16' else
+                                           'f32 operands as 2 fp16 planes (fixed power-of-two scales), 3 plane products per multiply on the fp16 MFMA pipe') + ' (fp32 accumulate); transforms fp32',
+                                 'images_per_sec': round(args.batch * min(args.steps, 20) / sdt, 2), 'ms_per_step': round(sdt / min(args.steps, 20) * 1e3, 4),
+                                 'layers_on_split_gemm': int(sum(1 for i in range(plan['n']) if plan['arr'][i].algo in (4, 5))),
+                                 'feature_max_abs_diff_over_rms_vs_fp32_mfma_plan': float(((got - ref_feat).abs().max() / ref_feat.pow(2).mean().sqrt()).item()),
+                                 'gemm_split_kernel': gs[0] if gs else None, 'gemm_peak_tflops': round(peak, 1), 'kernel_ms_per_step': sroof['kernel_ms_per_step'],
+                                 'parity': 'same tests as the fp32 path: tests/test_gpu_split.py (GEMM / conv vs fp64), tests/test_gpu_fullsize.py in this mode (2e-5 x rms vs fp64 at batch 32, 1e-4 IoU, bit-exact NMS on identical inputs)'}
+                    if gs:
+                        roof[tag]['gemm_split_kernel'] = dict(gs[0], frac=round(gs[0]['executed_tflops'] / peak, 4))
+                    if mode == 'f16':
+                        roof[tag]['operand_left_fp16_range'] = bool(_hip.split_overflowed())
+                except Exception as e:
+                    roof[tag] = {'error': '%s: %s' % (type(e).__name__, e)}
+                finally:
+                    _hip.SPLIT = ''
+                    dnn._cache = None
+                    dnn._plan_cache = None
     state = {k: v.detach().cpu() for k, v in dnn.state_dict().items()} if (ctx.world == 1 and args.cpu_sample > 0 and args.model == 'darknet') else None
     del inf, dnn
     torch.cuda.empty_cache()
@@ -410,7 +416,7 @@ def conv3x3_leg(args, ctx):
             ms += e0.elapsed_time(e1) / reps
             a = 2.0 * p.Cin * p.Cout * 9 * p.B * p.H * p.W
             alg += a
-            exe += 2.0 * p.Cin * p.Cout * 16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2, 3, 4) else a
+            exe += 2.0 * p.Cin * p.Cout * 16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2, 3, 4, 5) else a
             layers += 1
         return {'layers': layers, 'ms': round(ms, 4), 'executed_tflops': round(exe / ms / 1e9, 2), 'mfma_utilisation': round(exe / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
                 'direct_equiv_tflops': round(alg / ms / 1e9, 2), 'algorithmic_gflop': round(alg / 1e9, 1), 'executed_gflop': round(exe / 1e9, 1)}
@@ -759,12 +765,13 @@ def main():
                 extra.update(conv_chain_ms_per_step=roof['conv_chain']['ms_per_step'], conv_chain_frac=roof['conv_chain']['frac'])
             if isinstance(roof.get('direct_only'), dict) and 'frac' in roof['direct_only']:
                 extra['detect_direct_only_frac'] = roof['direct_only']['all_mfma_kernels']['frac']
-            sp = roof.get('split_bf16x6')
-            if isinstance(sp, dict) and 'images_per_sec' in sp:
-                extra.update(split_bf16x6_detect_images_per_sec=sp['images_per_sec'], split_bf16x6_detect_ms_per_step=sp['ms_per_step'],
-                             split_bf16x6_feature_diff_over_rms=sp['feature_max_abs_diff_over_rms_vs_fp32_mfma_plan'], split_bf16x6_layers=sp['layers_on_split_gemm'])
-                if sp.get('gemm_split_kernel'):
-                    extra.update(split_bf16x6_gemm_tflops=sp['gemm_split_kernel']['executed_tflops'], split_bf16x6_gemm_frac_of_bf16x6_peak=sp['gemm_split_kernel']['frac'])
+            for tag in ('split_bf16x6', 'split_f16x3'):
+                sp = roof.get(tag)
+                if isinstance(sp, dict) and 'images_per_sec' in sp:
+                    extra.update({tag + '_detect_images_per_sec': sp['images_per_sec'], tag + '_detect_ms_per_step': sp['ms_per_step'],
+                                  tag + '_feature_diff_over_rms': sp['feature_max_abs_diff_over_rms_vs_fp32_mfma_plan'], tag + '_layers': sp['layers_on_split_gemm']})
+                    if sp.get('gemm_split_kernel'):
+                        extra.update({tag + '_gemm_tflops': sp['gemm_split_kernel']['executed_tflops'], tag + '_gemm_frac_of_its_peak': sp['gemm_split_kernel']['frac']})
             for r in roof.get('top_kernels', []):
                 if r['frac'] is not None:       # one scalar per MFMA kernel of the detect step: frac_<kernel>
                     extra['frac_' + r['kernel'].replace('[', '_').replace(']', '').replace('<', '_').replace('>', '').replace(',', '_')] = r['frac']
@@ -785,7 +792,7 @@ def main():
         if ms is not None:
             out['multiscale'] = ms
         if roof is not None:
-            tables = {k: roof.pop(k) for k in ('top_kernels', 'definition', 'split_bf16x6', 'direct_only', 'conv_chain', 'all_mfma_kernels') if k in roof}
+            tables = {k: roof.pop(k) for k in ('top_kernels', 'definition', 'split_bf16x6', 'split_f16x3', 'direct_only', 'conv_chain', 'all_mfma_kernels') if k in roof}
             out['detect_kernel_table'] = tables
             roof.update(extra)
             out['roofline'] = roof

@@ -150,6 +150,21 @@ typedef struct y2_conv_params {
                                       accuracy at 2.67x the fp32-MFMA rate.  w = y2_split_bf16x3 of the y2_wino_weight output; Cin % 32 == 0.
                                       Opt-in precision mode of the Python layer (Y2_SPLIT_BF16=1); never chosen by the library itself. */
 
+#define Y2_ALGO_WINOGRAD_SPLIT_F16 5 /* as SPLIT with fp16 plane PAIRS (hi = fp16(s x), lo = fp16(s x - hi): 2 x 11 bits + the residual's sign) and three
+                                      products (hi x hi, hi x lo, lo x hi): half the matrix instructions and 4 instead of 6 operand bytes of SPLIT.
+                                      fp16 has 5 exponent bits: the operands carry fixed power-of-two scales (V x 2^-4, w x 2^8 - pass 256 to
+                                      y2_split_f16x2 for w; the product is rescaled exactly) so that |V| up to 10^6 and |w| up to 255 stay finite;
+                                      beyond that the result is Inf / NaN, and operands far BELOW 1 (gradients) lose their low plane to fp16's subnormals - unlike every
+                                      other algorithm.  For activations (inference, training forward).  Opt-in (Y2_SPLIT_F16=1). */
+
+/* Two fp16 planes of src * scale (scale a power of two): dst = [2][n] fp16 (4 n bytes).  The weight operand of Y2_ALGO_WINOGRAD_SPLIT_F16 (scale 256). */
+int y2_split_f16x2(const float* src, void* dst, long long n, float scale, y2_stream_t stream);
+/* 1 if any value handed to the fp16 split since the last reset was outside fp16's range (the affected results hold Inf / NaN), else 0; reset != 0
+ * clears the flag.  Synchronises the device (a check for the end of an epoch / a benchmark, not for the hot path). */
+int y2_split_f16_overflow(int reset);
+/* y2_gemm_split for fp16 plane pairs A = [2][groups][M][K], B = [2][groups][N][K]; C = (A B^T) * out_scale. */
+int y2_gemm_split_f16(const void* A, const void* B, float* C, long long M, int32_t N, int32_t K, int32_t ldc, int32_t groups, float out_scale, y2_stream_t stream);
+
 /* Three bf16 planes of an fp32 array (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round to nearest even):
  * dst = [3][n] bf16 (6 n bytes), n % 4 == 0, src 16-B aligned.  The weight operand of Y2_ALGO_WINOGRAD_SPLIT. */
 int y2_split_bf16x3(const float* src, void* dst, long long n, y2_stream_t stream);

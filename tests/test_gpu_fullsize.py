@@ -32,10 +32,11 @@ def rel(got, ref):
     return (got.double().cpu() - ref.cpu()).abs().max().item() / max(rms, 1e-30)
 
 
-@pytest.fixture(scope='module', params=['fp32-mfma', 'split-bf16x6'])
+@pytest.fixture(scope='module', params=['fp32-mfma', 'split-bf16x6', 'split-f16x3'])
 def net(request):
-    """Every test of this module runs twice: with the fp32-input MFMA kernels only, and with the opt-in split-bf16 precision mode
-    (Y2_SPLIT_BF16: the Winograd GEMMs of the 13x13 layers on the bf16 pipe from three bf16 planes per operand) - same truth, same tolerances."""
+    """Every test of this module runs three times: with the fp32-input MFMA kernels only, and with each opt-in split precision mode
+    (Y2_SPLIT_BF16: the Winograd GEMMs of the 13x13 layers on the bf16 pipe from three bf16 planes per operand; Y2_SPLIT_F16: on the fp16 pipe
+    from two scaled fp16 planes) - same truth, same tolerances."""
     import _hip
     import model
     import model.yolo2
@@ -46,7 +47,7 @@ def net(request):
     dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, 20)
     dnn.load_state_dict(sd, strict=False)
     saved = _hip.SPLIT
-    _hip.SPLIT = request.param == 'split-bf16x6'
+    _hip.SPLIT = {'fp32-mfma': '', 'split-bf16x6': 'bf16', 'split-f16x3': 'f16'}[request.param]
     yield model.Inference(cfg, dnn, anchors).to(dev()).eval(), anchors, sd
     _hip.SPLIT = saved
 
@@ -65,7 +66,7 @@ def batch(net):
             feat = inf.dnn.forward_nhwc(x.to(dev())).clone()      # [B,13,13,125] NHWC
         plan = inf.dnn._plan_cache[1]
         if _hip.SPLIT:
-            assert sum(1 for i in range(plan['n']) if plan['arr'][i].algo == 4) >= 6      # the 13x13 layers
+            assert sum(1 for i in range(plan['n']) if plan['arr'][i].algo == _hip.split_algo()) >= 6      # the 13x13 layers
     finally:
         _hip.AUTOTUNE = saved
     return x, feat
@@ -95,7 +96,7 @@ def test_full_batch_matches_fp64_oracle_on_sampled_images(net, batch, truth):
         assert rel(got[j:j + 1], truth[j:j + 1]) <= 2e-5, (i, rel(got[j:j + 1], truth[j:j + 1]))
 
 
-@pytest.mark.parametrize('algo', ['direct', 'winograd', 'fused', 'implicit', 'split'])
+@pytest.mark.parametrize('algo', ['direct', 'winograd', 'fused', 'implicit', 'split', 'split16'])
 def test_full_batch_under_each_forced_algorithm(net, batch, truth, algo, monkeypatch):
     """Deterministic algorithm coverage of the whole-model path: with autotune out of the picture every eligible 3x3 layer runs the
     direct implicit GEMM / the three-kernel Winograd / the fused Winograd kernel (the rest stays direct), at the full batch-32
@@ -103,9 +104,9 @@ def test_full_batch_under_each_forced_algorithm(net, batch, truth, algo, monkeyp
     import _hip
     inf, anchors, sd = net
     x, feat = batch
-    monkeypatch.setattr(_hip, 'FORCE_ALGO', algo)
-    if algo == 'split':
-        monkeypatch.setattr(_hip, 'SPLIT', True)     # the opt-in precision mode (bf16 plane triples): same truth, same tolerance
+    monkeypatch.setattr(_hip, 'FORCE_ALGO', 'split' if algo == 'split16' else algo)
+    if algo in ('split', 'split16'):
+        monkeypatch.setattr(_hip, 'SPLIT', 'f16' if algo == 'split16' else 'bf16')     # the opt-in precision modes: same truth, same tolerance
     inf.dnn._cache = None                            # (the split weight operands are prepared with the others)
     inf.dnn._plan_cache = None
     try:
@@ -113,7 +114,7 @@ def test_full_batch_under_each_forced_algorithm(net, batch, truth, algo, monkeyp
             f = inf.dnn.forward_nhwc(x.to(dev())).clone()
         plan = inf.dnn._plan_cache[1]
         algos = [plan['arr'][i].algo for i in range(plan['n'])]
-        want = {'direct': 0, 'winograd': 1, 'fused': 2, 'implicit': 3, 'split': 4}[algo]
+        want = {'direct': 0, 'winograd': 1, 'fused': 2, 'implicit': 3, 'split': 4, 'split16': 5}[algo]
         assert (max(algos) == want) and (algo == 'direct' or algos.count(want) >= 10), algos     # 13 eligible layers (Cin >= 64)
     finally:
         inf.dnn._plan_cache = None

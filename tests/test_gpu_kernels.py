@@ -57,8 +57,8 @@ def run_conv(x_nchw, w, scale, shift, slope, k, pool=False, both=False, tile=0, 
         u = torch.empty(16 * w.numel() // 9, device=d)
         _hip.check(L.y2_wino_weight(_hip.ptr(wp), _hip.ptr(u), cout, cin, _hip.stream()), 'wino_weight')
         wp, p.algo = u, int(wino)          # 1 = Winograd, 2 = Winograd with fused GEMM + output transform
-        if int(wino) == 4:                 # ... 4 = three-kernel Winograd with the GEMMs on the bf16 pipe (plane triples)
-            wp = _hip.split_planes(u)
+        if int(wino) in (4, 5):            # ... 4 / 5 = three-kernel Winograd with the GEMMs on the bf16 / fp16 pipe (plane tuples)
+            wp = _hip.split_planes(u, 'f16' if int(wino) == 5 else 'bf16')
     p.x, p.w = x.data_ptr(), wp.data_ptr()
     p.scale = sc.data_ptr() if sc is not None else None
     p.shift = sh.data_ptr() if sh is not None else None

@@ -71,14 +71,15 @@ def test_conv_split_mode_is_as_accurate_as_fp32_winograd(B, cin, cout, H, W, bk,
     pool = H % 2 == 0 and W % 2 == 0
     z, want = ref_conv(x, w, scale, shift, 0.1, 3)
     errs = {}
-    for algo in (1, 4):
+    for algo in (1, 4, 5):
         out = run_conv(x, w, scale, shift, 0.1, 3, pool=pool, both=pool, wino=algo)
         errs[algo] = rel_err(out['y'].permute(0, 3, 1, 2), want)
         if pool:
             assert rel_err(out['y_pool'].permute(0, 3, 1, 2), F.max_pool2d(want, 2)) <= 8e-5
-    print('conv %dx%d Cin %d Cout %d: split %.3g, fp32 Winograd %.3g' % (H, W, cin, cout, errs[4], errs[1]))
-    assert errs[4] <= 8e-5
-    assert errs[4] <= max(1.5 * errs[1], 4e-6), errs
+    print('conv %dx%d Cin %d Cout %d: split bf16x6 %.3g, split f16x3 %.3g, fp32 Winograd %.3g' % (H, W, cin, cout, errs[4], errs[5], errs[1]))
+    for algo in (4, 5):
+        assert errs[algo] <= 8e-5
+        assert errs[algo] <= max(1.5 * errs[1], 4e-6), errs
 
 
 def test_training_step_in_split_mode_matches_oracle_autograd(monkeypatch):
@@ -97,13 +98,13 @@ def test_training_step_in_split_mode_matches_oracle_autograd(monkeypatch):
     x = synth.images(B, S, seed=1)
     data = synth.norm_data(synth.labels(B, S, 20, seed=2), S, S, S // 32, S // 32)
     grads = {}
-    for mode in ('fp32', 'split'):
-        monkeypatch.setattr(_hip, 'SPLIT', mode == 'split')
-        monkeypatch.setattr(_hip, 'FORCE_ALGO', 'split' if mode == 'split' else 'winograd')
+    for mode in ('fp32', 'split', 'split16'):
+        monkeypatch.setattr(_hip, 'SPLIT', {'fp32': '', 'split': 'bf16', 'split16': 'f16'}[mode])
+        monkeypatch.setattr(_hip, 'FORCE_ALGO', 'winograd' if mode == 'fp32' else 'split')
         inf, anchors = R.build(sd)
         inf.train()
         calls = []
-        if mode == 'split':
+        if mode != 'fp32':
             L = _hip.lib()
             orig = L.y2_conv_fwd
 
@@ -114,9 +115,9 @@ def test_training_step_in_split_mode_matches_oracle_autograd(monkeypatch):
         pred = model._inference(inf, x.to(dev()))
         loss, _ = model.loss(anchors, data, pred, 0.6)
         model.weighted_total(loss, oloss.HPARAM).backward()
-        if mode == 'split':
+        if mode != 'fp32':
             monkeypatch.undo()
-            assert calls.count(4) >= 8, calls            # fprop and dgrad of the 64-channel 3x3 layers (layers2.*, layers3.0)
+            assert calls.count(4 if mode == 'split' else 5) >= (8 if mode == 'split' else 5), calls     # fprop (and, bf16 mode, dgrad) of the 64-channel 3x3 layers
         sd64, lo, stats, f = R.oracle_step(sd, x, data, anchors, True)
         for k in lo:
             np.testing.assert_allclose(loss[k].item(), lo[k].item(), rtol=1e-4)
@@ -124,3 +125,45 @@ def test_training_step_in_split_mode_matches_oracle_autograd(monkeypatch):
         grads[mode] = {k: p.grad.detach().cpu() for k, p in inf.dnn.named_parameters()}
     for k in grads['fp32']:
         assert rel_err(grads['split'][k], grads['fp32'][k]) <= 1e-4, k
+        assert rel_err(grads['split16'][k], grads['fp32'][k]) <= 1e-4, k
+
+
+@pytest.mark.parametrize('M,N,K,groups', [(128, 128, 32, 1), (300, 200, 96, 3), (1568, 1024, 512, 2), (64, 64, 1280, 16), (5408, 512, 1024, 1)])
+def test_gemm_split_f16_matches_fp64(M, N, K, groups):
+    """The fp16 plane-pair GEMM with its power-of-two operand scales: values spread over six decades inside one reduction (what the fixed scales
+    must absorb), against fp64 and the error of a CPU fp32 GEMM."""
+    import _hip
+    L = _hip.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(groups, M, K, generator=g) * 4.0                # transformed activations: up to +-4 x the activation range
+    A[:, :, ::7] *= 100.0
+    A[:, :, 1::5] *= 1e-3
+    B = torch.randn(groups, N, K, generator=g) * 0.03               # transformed weights
+    B[:, ::3] *= 1e-2
+    Ad, Bd = A.to(dev()), B.to(dev())
+    As = torch.empty(2 * A.numel(), dtype=torch.float16, device=dev())
+    Bs = torch.empty(2 * B.numel(), dtype=torch.float16, device=dev())
+    _hip.check(L.y2_split_f16x2(_hip.ptr(Ad), _hip.ptr(As), A.numel(), 0.0625, _hip.stream()), 'split A')
+    _hip.check(L.y2_split_f16x2(_hip.ptr(Bd), _hip.ptr(Bs), B.numel(), 256.0, _hip.stream()), 'split B')
+    C = torch.full((groups, M, N), -7.0, device=dev())
+    _hip.check(L.y2_gemm_split_f16(_hip.ptr(As), _hip.ptr(Bs), _hip.ptr(C), M, N, K, N, groups, 0.0625, _hip.stream()), 'y2_gemm_split_f16')
+    want = torch.einsum('gmk,gnk->gmn', A.double(), B.double())
+    f32 = torch.einsum('gmk,gnk->gmn', A, B)
+    e_split, e_f32 = rel_err(C.cpu(), want), rel_err(f32, want)
+    print('gemm_split_f16 %dx%dx%d x%d: max|err|/rms %.3g (CPU fp32 GEMM %.3g)' % (M, N, K, groups, e_split, e_f32))
+    assert e_split <= max(2.0 * e_f32, 1e-6), (e_split, e_f32)
+
+
+def test_f16_split_reports_operands_outside_its_range():
+    """The fp16 plane mode has fp16's exponent range (times its fixed scales): an operand beyond it must be REPORTED (y2_split_f16_overflow),
+    values inside it must not raise the flag."""
+    import _hip
+    _hip.split_overflowed()                                         # clear
+    ok = torch.randn(4096).mul_(50.0).to(dev())
+    _hip.split_planes(ok, 'f16')
+    assert not _hip.split_overflowed()
+    bad = ok.clone()
+    bad[77] = 300.0                                                 # x 256 (the weight-operand scale) > 65504
+    _hip.split_planes(bad, 'f16')
+    assert _hip.split_overflowed()
+    assert not _hip.split_overflowed()                              # reading cleared it

@@ -18,7 +18,7 @@ L, st = _hip.lib(), _hip.stream()
 B = args.batch
 LAYERS = [('104x104 64->128', 104, 64, 128), ('52x52 128->256', 52, 128, 256), ('26x26 256->512', 26, 256, 512), ('13x13 512->1024', 13, 512, 1024),
           ('13x13 1024->1024', 13, 1024, 1024), ('13x13 1280->1024', 13, 1280, 1024)]
-print('%-20s %10s %10s %10s %10s %10s %10s   (ms; executed Winograd TFLOP/s in brackets)' % ('layer', 'direct', 'wino', 'fused', 'split32x8', 'split32x4', 'split16x4'))
+print('%-20s %10s %10s %10s %10s %10s %10s %10s   (ms; executed Winograd TFLOP/s in brackets)' % ('layer', 'direct', 'wino', 'fused', 'split32x8', 'split32x4', 'f16x3 x8', 'f16x3 x4'))
 for name, H, cin, cout in LAYERS:
     g = torch.Generator().manual_seed(H + cin)
     x = torch.randn(B, H, H, cin, generator=g).to(dev)
@@ -26,13 +26,14 @@ for name, H, cin, cout in LAYERS:
     wp = torch.empty(w.numel(), device=dev)
     _hip.check(L.y2_pack_weight(_hip.ptr(w), _hip.ptr(wp), cout, cin, 3, 0, st), 'pack')
     u = _hip.wino_weight(wp, cout, cin)
-    us = _hip.split_planes(u)
+    us = _hip.split_planes(u, 'bf16')
+    uh = _hip.split_planes(u, 'f16')
     y = torch.empty(B, H, H, cout, device=dev)
     scale, shift = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
     exe = 2.0 * cin * cout * 16 * B * ((H + 1) // 2) ** 2
     row = []
     ref = None
-    for algo, wt, env in ((0, wp, None), (1, u, None), (2, u, None), (4, us, ('32', '8')), (4, us, ('32', '4')), (4, us, ('16', '4'))):
+    for algo, wt, env in ((0, wp, None), (1, u, None), (2, u, None), (4, us, ('32', '8')), (4, us, ('32', '4')), (5, uh, ('32', '8')), (5, uh, ('32', '4'))):
         if env:
             os.environ['Y2_SPLIT_BK'], os.environ['Y2_SPLIT_WAVES'] = env
         p = _hip.ConvParams()
@@ -54,4 +55,4 @@ for name, H, cin, cout in LAYERS:
             e1.record(); e1.synchronize()
             best = min(best, e0.elapsed_time(e1) / 5)
         row.append('%.3f[%3.0f]%s' % (best, (exe if algo else exe * 36 / 16) / best / 1e9, '' if err < 5e-5 else ' ERR %.1e' % err))
-    print('%-20s %10s %10s %10s %10s %10s %10s' % tuple([name] + row))
+    print('%-20s %10s %10s %10s %10s %10s %10s %10s' % tuple([name] + row))

@@ -63,6 +63,9 @@ SIGNATURES = {
     'y2_expand_classes': [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_float] + [c_void_p] * 8 + [c_void_p],
     'y2_iou_rowmax': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'y2_split_bf16x3': [c_void_p, c_void_p, ctypes.c_longlong, c_void_p],
+    'y2_split_f16x2': [c_void_p, c_void_p, ctypes.c_longlong, c_float, c_void_p],
+    'y2_split_f16_overflow': [c_int],
+    'y2_gemm_split_f16': [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, c_float, c_void_p],
     'y2_gemm_split': [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, c_void_p],
     'y2_multi': [ctypes.POINTER(MultiItem), c_int, c_void_p],
     'y2_small_dot': [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
@@ -333,19 +336,46 @@ if TUNE_CACHE and os.path.exists(TUNE_CACHE):
 WINOGRAD = os.environ.get('Y2_WINOGRAD', '1') != '0'     # 0: never pick the Winograd F(2x2,3x3) algorithm
 FORCE_ALGO = os.environ.get('Y2_FORCE_ALGO') or None     # 'direct' | 'winograd' | 'fused' | 'implicit' | 'split': no autotune, that algorithm wherever the library accepts it
 if FORCE_ALGO not in (None, 'direct', 'winograd', 'fused', 'implicit', 'split'):
-    raise ValueError('Y2_FORCE_ALGO must be direct, winograd, fused, implicit or split (got %r)' % FORCE_ALGO)
-# Opt-in precision mode: the Winograd GEMMs may run on the bf16 matrix pipe with three bf16 planes per fp32 operand and six plane
-# products per multiply (Y2_ALGO_WINOGRAD_SPLIT, csrc/gemm_split.hip): fp32-level accuracy (same parity tests), 2.67x the fp32-MFMA rate.
-SPLIT = os.environ.get('Y2_SPLIT_BF16', '0') == '1' or FORCE_ALGO == 'split'
+    raise ValueError('Y2_FORCE_ALGO must be direct, winograd, fused, implicit or split (got %r)' % FORCE_ALGO)      # ('split': the algorithm of the current split mode)
+# Opt-in precision modes: the Winograd GEMMs may run on the bf16 / fp16 matrix pipe from split operands (csrc/gemm_split.hip): fp32-level
+# accuracy (the same parity tests run in these modes).  SPLIT = 'bf16' (True): three bf16 planes per fp32 operand, six plane products
+# (Y2_ALGO_WINOGRAD_SPLIT; fp32's exponent range); 'f16': two fp16 planes, three products, operands scaled by fixed powers of two
+# (Y2_ALGO_WINOGRAD_SPLIT_F16; finite for |transformed activation| < 10^6 and |transformed weight| < 255 only).
+SPLIT = 'f16' if os.environ.get('Y2_SPLIT_F16', '0') == '1' else ('bf16' if (os.environ.get('Y2_SPLIT_BF16', '0') == '1' or FORCE_ALGO == 'split') else '')
+F16_U_SCALE = 256.0
 
 
-def split_planes(t):
-    """y2_split_bf16x3 of a contiguous fp32 GPU tensor: [3][numel] bf16 (hi, mid, lo planes)."""
+def split_mode():
+    """None, 'bf16' or 'f16' (SPLIT may be set to True by callers: the bf16 mode)."""
+    return None if not SPLIT else ('f16' if SPLIT == 'f16' else 'bf16')
+
+
+def split_overflowed(reset=True):
+    """True when an operand of the fp16 split mode left fp16's range since the last reset (y2_split_f16_overflow; synchronises)."""
+    rc = lib().y2_split_f16_overflow(int(bool(reset)))
+    if rc < 0:
+        check(rc, 'y2_split_f16_overflow')
+    return rc == 1
+
+
+def split_algo():
+    return 5 if split_mode() == 'f16' else 4
+
+
+def split_planes(t, mode=None):
+    """The plane tuple of a contiguous fp32 GPU tensor for the current (or given) split mode: y2_split_bf16x3 -> [3][numel] bf16 (hi, mid, lo),
+    y2_split_f16x2 -> [2][numel] fp16 of t * 256 (the weight-operand scale of Y2_ALGO_WINOGRAD_SPLIT_F16)."""
     require_gpu(t)
     t = f32c(t)
+    if (mode or split_mode()) == 'f16':
+        out = torch.empty(2 * t.numel(), dtype=torch.float16, device=t.device)
+        check(lib().y2_split_f16x2(ptr(t), ptr(out), t.numel(), F16_U_SCALE, stream()), 'y2_split_f16x2')
+        return out
     out = torch.empty(3 * t.numel(), dtype=torch.bfloat16, device=t.device)
     check(lib().y2_split_bf16x3(ptr(t), ptr(out), t.numel(), stream()), 'y2_split_bf16x3')
     return out
+
+
 IMPLICIT = os.environ.get('Y2_WINO_IMPLICIT', '1') != '0'  # 0: never offer Y2_ALGO_WINOGRAD_IMPLICIT (A/B runs)
 WINO_MIN_CIN = 32                                        # below this the transforms cost more than the GEMM saves (measured; 32: the 208x208 layer, one K slab per tile of the fused kernels)
 
@@ -388,23 +418,23 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
     split_ok = bool(wino_ok and SPLIT and wino_split is not None and params.Cin % 32 == 0)
     key = (params.B, params.H, params.W, params.Cin, params.ldx, params.Cout, params.ksize, bool(params.y), bool(params.y_pool),
            bool(params.stats), params.out_mode, params.stride, params.pad_plus1, bool(params.residual), params.transposed, params.out_h, params.out_w, str(dev),
-           bool(wino_ok), bool(implicit_ok and IMPLICIT)) + (('split',) if split_ok else ())
+           bool(wino_ok), bool(implicit_ok and IMPLICIT)) + (('split', split_mode()) if split_ok else ())
     implicit_ok = bool(implicit_ok and IMPLICIT) and params.Cin % 32 == 0
     w_direct = params.w
 
     def apply(choice):
         algo, tile = choice
         params.algo, params.tile = algo, tile
-        params.w = wino_split.data_ptr() if algo == 4 else wino_w.data_ptr() if algo in (1, 2, 3) else w_direct
-        params.w_plane = split_plane if algo == 4 else 0
+        params.w = wino_split.data_ptr() if algo in (4, 5) else wino_w.data_ptr() if algo in (1, 2, 3) else w_direct
+        params.w_plane = split_plane if algo in (4, 5) else 0
         return choice
     if FORCE_ALGO is not None:
         # deterministic algorithm coverage (tests, A/B runs): every eligible layer takes the named algorithm, everything else the
         # direct kernel with the library's own tile choice; no measurement, no cache
-        want = {'direct': None, 'winograd': (1, 5), 'fused': (2, 0), 'implicit': (3, 0), 'split': (4, 0)}[FORCE_ALGO]
+        want = {'direct': None, 'winograd': (1, 5), 'fused': (2, 0), 'implicit': (3, 0), 'split': (split_algo(), 0)}[FORCE_ALGO]
         if want is not None and want[0] == 3 and not implicit_ok:
             want = (2, 0)               # where the transformed input must stay behind: the fused kernel that reads it
-        if want is not None and want[0] == 4 and not split_ok:
+        if want is not None and want[0] in (4, 5) and not split_ok:
             want = (1, 5) if wino_ok else None
         if want is not None and wino_ok and (want[0] == 1 or params.Cin % 32 == 0):
             apply(want)
@@ -418,7 +448,7 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
         # no measurement possible (or, deterministic mode: a timed choice may differ from run to run and with it the rounding): the choices the measurements converge to on MI355X (profiles/r01_detect_b32_layer_table.txt)
         prefer = []
         if split_ok and params.H * params.W <= 19 * 19:
-            prefer.append((4, 0))       # opt-in split-bf16 mode: the 13x13 (19x19 at 608) layers, 25-30 % ahead of the fp32 GEMMs there
+            prefer.append((split_algo(), 0))       # opt-in split mode: the 13x13 (19x19 at 608) layers, 25-30 % ahead of the fp32 GEMMs there
         if wino_ok and implicit_ok and (params.H * params.W >= 52 * 52 or (params.H * params.W >= 26 * 26 and params.Cout <= params.Cin)):
             prefer.append((3, 0))       # fused Winograd with the input transform in its loader: the large maps and the data gradients
         if wino_ok and params.Cin % 32 == 0 and params.H * params.W >= 26 * 26:
@@ -442,7 +472,7 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
         if implicit_ok:
             cands.append((3, 0))        # ... with the input transform in its loader (no transformed input in memory either)
         if split_ok:
-            cands.append((4, 0))        # three-kernel Winograd with the GEMMs on the bf16 pipe (opt-in precision mode)
+            cands.append((split_algo(), 0))        # three-kernel Winograd with the GEMMs on the bf16 / fp16 pipe (opt-in precision modes)
     best, best_t = (0, 0), float('inf')
     stats_save = params.stats
     params.stats = None          # timing launches must not accumulate statistics twice

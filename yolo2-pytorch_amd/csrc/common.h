@@ -25,8 +25,12 @@ __attribute__((visibility("hidden"))) int y2_internal_wgrad_grouped(const float*
 __attribute__((visibility("hidden"))) int y2_internal_wgrad_needs_zero(long long M, int Cin, int Cout, int groups);
 __attribute__((visibility("hidden"))) int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need);
 // gemm_split.hip: fp32-accurate GEMMs on the bf16 matrix pipe (three bf16 planes per operand, six plane products)
-__attribute__((visibility("hidden"))) int y2_internal_gemm_split(const void* A, long long planeA, const void* B, long long planeB, float* C, long long M, int N, int K, int ldc, int groups, y2_stream_t stream);
-__attribute__((visibility("hidden"))) int y2_internal_wino_input_split(const float* x, void* v, int B, int H, int W, int Cin, int ldx, y2_stream_t stream);
+__attribute__((visibility("hidden"))) int y2_internal_gemm_split(const void* A, long long planeA, const void* B, long long planeB, float* C, long long M, int N, int K, int ldc, int groups, int planes,
+                                                                  float out_scale, y2_stream_t stream);
+__attribute__((visibility("hidden"))) int y2_internal_wino_input_split(const float* x, void* v, int B, int H, int W, int Cin, int ldx, int planes, float scale, y2_stream_t stream);
+// fixed power-of-two operand scales of the fp16 split variant (Y2_ALGO_WINOGRAD_SPLIT_F16): V * 2^-4 (|V| up to 10^6 stays finite), U * 2^8
+// (y2_split_f16x2's caller), product rescaled by 2^-4 in the GEMM epilogue
+constexpr float Y2_F16_V_SCALE = 0.0625f, Y2_F16_U_SCALE = 256.f, Y2_F16_OUT_SCALE = 0.0625f;
 
 // ---- per-device host-side caches (a process may touch several GPUs; symbol addresses and function attributes are per device)
 constexpr int Y2_MAX_DEVICES = 64;

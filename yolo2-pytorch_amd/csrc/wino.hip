@@ -987,13 +987,15 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     if ((p->scale != nullptr && !y2_aligned16(p->scale)) || (p->shift != nullptr && !y2_aligned16(p->shift))) return Y2_ENOSUP;
     const bool implicit = p->algo == Y2_ALGO_WINOGRAD_IMPLICIT;      // fused, and the input transform happens in the fused kernel's loader
     const bool fused = p->algo == Y2_ALGO_WINOGRAD_FUSED || implicit;
-    const bool split = p->algo == Y2_ALGO_WINOGRAD_SPLIT;            // three kernels, the 16 GEMMs on the bf16 matrix pipe (gemm_split.hip): V and w are bf16 plane triples
+    const bool split16 = p->algo == Y2_ALGO_WINOGRAD_SPLIT_F16;      // ... as fp16 plane PAIRS (three products, operands scaled by fixed powers of two)
+    const bool split = p->algo == Y2_ALGO_WINOGRAD_SPLIT || split16; // three kernels, the 16 GEMMs on the bf16 / fp16 matrix pipe (gemm_split.hip): V and w are plane tuples
+    const int np = split16 ? 2 : 3;
     if ((fused || split) && (p->Cin % 32) != 0) return Y2_ENOSUP;
     if (implicit && p->Cin < 32) return Y2_ENOSUP;
     const int th = (p->H + 1) / 2, tw = (p->W + 1) / 2;
     // Batch chunks bound the workspace (V = 4x the input, M = 4x the output of a chunk); see wino_chunk_bytes().
     const size_t img_bytes = implicit ? (size_t)th * tw * sizeof(int32_t) :
-                             split ? (size_t)16 * th * tw * ((size_t)p->Cin * 6 + (size_t)p->Cout * 4) :
+                             split ? (size_t)16 * th * tw * ((size_t)p->Cin * 2 * np + (size_t)p->Cout * 4) :
                                      (size_t)16 * th * tw * ((size_t)p->Cin + (fused ? 0 : p->Cout)) * sizeof(float);
     int cb = (int)(wino_chunk_bytes() / (img_bytes > 0 ? img_bytes : 1));
     if (cb < 1) cb = 1;
@@ -1011,7 +1013,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
     cb = y2_cdiv(p->B, nchunks);                     // equal chunks
     const long long T = (long long)cb * th * tw;    // tiles of a full chunk
     if (T * (p->Cin / 4) >= 0xffffffffLL || T * (p->Cout / 4) >= 0xffffffffLL || T > 0x7fffffff) return Y2_ENOSUP;
-    const size_t vbytes = implicit ? 0 : align256((size_t)16 * T * p->Cin * (split ? 6 : sizeof(float)));
+    const size_t vbytes = implicit ? 0 : align256((size_t)16 * T * p->Cin * (split ? 2 * np : sizeof(float)));
     const size_t mbytes = fused ? align256((size_t)(T + 63) * sizeof(int32_t)) + WF_DUMP_BYTES + 256 :      // ... + the 8 tile counters
                                  align256((size_t)16 * T * p->Cout * sizeof(float));   // fused: tile decode table + 1 KB dump area
     if (fused && (vbytes >= 0x7fffffffull || (size_t)16 * p->Cout * p->Cin * 4 >= 0x7fffffffull)) return Y2_ENOSUP;
@@ -1130,9 +1132,9 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
         }
         if (split) {
             // stage 1 again with plane output (the fp32 launch above is skipped: see the `split` test in front of it), stage 2 on the bf16 pipe
-            const int rc1 = y2_internal_wino_input_split(ia.x, V, nb, p->H, p->W, p->Cin, p->ldx, stream);
+            const int rc1 = y2_internal_wino_input_split(ia.x, V, nb, p->H, p->W, p->Cin, p->ldx, np, Y2_F16_V_SCALE, stream);
             if (rc1 != Y2_OK) return rc1;
-            const int rc2 = y2_internal_gemm_split(V, 0, p->w, p->w_plane, M, Tc, p->Cout, p->Cin, p->Cout, 16, stream);
+            const int rc2 = y2_internal_gemm_split(V, 0, p->w, p->w_plane, M, Tc, p->Cout, p->Cin, p->Cout, 16, np, split16 ? Y2_F16_OUT_SCALE : 1.f, stream);
             if (rc2 != Y2_OK) return rc2;
         } else {
         q.W = (int)Tc;

@@ -159,11 +159,14 @@ class GraphedDetector(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.result = step()
-        self._versions = dnn._versions()
+        # what the captured pointers were derived from: the tensors themselves (kept alive here) with their version counters - the check in
+        # run() is one attribute read per tensor, no module-tree walk (it sits in the replay path)
+        self._watched = [(t, t.data_ptr(), t._version) for t in list(dnn.parameters()) + list(dnn.buffers())]
 
     def run(self, x=None):
-        if self.dnn._versions() != self._versions:
-            raise RuntimeError('GraphedDetector: the parameters changed since capture (the graph holds the old packed weights); capture a new one')
+        for t, ptr, ver in self._watched:
+            if t._version != ver or t.data_ptr() != ptr:
+                raise RuntimeError('GraphedDetector: the parameters changed since capture (the graph holds the old packed weights); capture a new one')
         if x is not None and x.data_ptr() != self.static_x.data_ptr():
             self.static_x.copy_(x)
         self.graph.replay()

@@ -122,7 +122,7 @@ def _train_operands(dnn, dev):
     (y2_conv0_fwd reads the state_dict layout) and blocks whose output width is not a multiple of 4 (the 125 / 425-channel head: its
     data gradient runs zero-padded) are left to the per-layer path."""
     from model import yolo2 as _yolo2
-    key = (dev, dnn._weight_versions(), _hip.SPLIT, _hip.WINOGRAD)       # the convolution weights only: the BatchNorm buffer updates of a forward pass do not move it
+    key = (dev, dnn._weight_versions(), _hip.split_mode(), _hip.WINOGRAD)       # the convolution weights only: the BatchNorm buffer updates of a forward pass do not move it
     cache = getattr(dnn, '_train_cache', None)
     if cache is not None and cache[0] == key:
         return cache[1]
@@ -171,11 +171,16 @@ def _train_operands(dnn, dev):
         for e, (src, dst, cout, cin, k, mode) in zip(table, items):
             e.src, e.dst, e.Cout, e.Cin, e.ksize, e.mode = src.data_ptr(), dst.data_ptr(), cout, cin, k, mode
         _hip.check(_hip.lib().y2_prep_weights(table, len(items), _hip.stream()), 'y2_prep_weights')
-    if usize and _hip.SPLIT:
+    if usize and _hip.split_mode():
+        f16 = _hip.split_mode() == 'f16'
+        np_, dt = (2, torch.float16) if f16 else (3, torch.bfloat16)
         planes = bufs[1].get('u_split')
-        if planes is None or planes.numel() != 3 * usize:
-            planes = bufs[1]['u_split'] = torch.empty(3 * usize, dtype=torch.bfloat16, device=dev)
-        _hip.check(_hip.lib().y2_split_bf16x3(_hip.ptr(arena), _hip.ptr(planes), usize, _hip.stream()), 'y2_split_bf16x3')
+        if planes is None or planes.numel() != np_ * usize or planes.dtype != dt:
+            planes = bufs[1]['u_split'] = torch.empty(np_ * usize, dtype=dt, device=dev)
+        if f16:
+            _hip.check(_hip.lib().y2_split_f16x2(_hip.ptr(arena), _hip.ptr(planes), usize, _hip.F16_U_SCALE, _hip.stream()), 'y2_split_f16x2')
+        else:
+            _hip.check(_hip.lib().y2_split_bf16x3(_hip.ptr(arena), _hip.ptr(planes), usize, _hip.stream()), 'y2_split_bf16x3')
         off = 0
         for d, tag, w, cout, cin, k, mode in wino:
             if (cout if tag == 'ud' else cin) % 32 == 0:          # the K dimension of the GEMM (Cin of the convolution that runs)
@@ -590,7 +595,10 @@ def _darknet_bwd(ctx, dout):
             dx = _new(dev, B, h, w, cin)
             ready_ops = ctx.prepared.get(blk.mod)
             if ready_ops is not None:        # rotated / in-out-swapped operands prepared with the forward's (same parameter version)
-                _conv(L, st, dz, ready_ops['wd'], dx, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'], us=ready_ops['uds'], us_plane=ready_ops['plane'])
+                # (the fp16 split mode is for activations: its fixed operand scales assume O(1) values, and gradients are 1e-5 and smaller -
+                # their fp16 planes would be subnormal; data gradients stay on the fp32 / bf16-split algorithms)
+                dg_split = ready_ops['uds'] if _hip.split_mode() == 'bf16' else None
+                _conv(L, st, dz, ready_ops['wd'], dx, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'], us=dg_split, us_plane=ready_ops['plane'])
             else:
                 wsrc = e.w
                 if cop != cout:

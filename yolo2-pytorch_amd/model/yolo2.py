@@ -169,7 +169,7 @@ class Darknet(nn.Module):
 
     def _prepare_eval(self, device):
         """Pack weights to [Cout][tap][Cin] and fold BN once per parameter version (y2_pack_weight / y2_bn_fold)."""
-        ver = (device, self._versions())
+        ver = (device, self._versions(), _hip.split_mode())
         if self._cache is not None and self._cache[0] == ver:
             return self._cache[1]
         L = _hip.lib()
@@ -223,7 +223,7 @@ class Darknet(nn.Module):
         y2_conv_params array of the 22 generic convolutions (model/yolo2.py:76-113 in execution order)."""
         # slot: plans of the same shape with PRIVATE intermediate buffers and scratch, so that two batches can be in flight on two streams
         # (detect.GraphedDetector(slot=...): the tail of one batch's kernels overlaps the head of the next batch's)
-        key = (str(dev), B, cin0, H, W, _hip.tune_epoch(), _hip.WINOGRAD, _hip.FORCE_ALGO, _hip.SPLIT, slot)
+        key = (str(dev), B, cin0, H, W, _hip.tune_epoch(), _hip.WINOGRAD, _hip.FORCE_ALGO, _hip.split_mode(), slot)
         plan = self._plans.get(key)
         if plan is not None:
             if plan['prep'] is not prep:
@@ -231,7 +231,7 @@ class Darknet(nn.Module):
                 # operand pointers of the packed / folded / transformed weights move
                 for p, blk in zip(plan['arr'], plan['blks']):
                     wp, scale, shift, u = prep[blk]
-                    p.w = (prep['split'][blk] if p.algo == 4 else u if p.algo in (1, 2, 3) else wp).data_ptr()
+                    p.w = (prep['split'][blk] if p.algo in (4, 5) else u if p.algo in (1, 2, 3) else wp).data_ptr()
                     p.scale = scale.data_ptr() if scale is not None else None
                     p.shift = shift.data_ptr() if shift is not None else None
                 plan['prep'] = prep
@@ -315,7 +315,7 @@ class Darknet(nn.Module):
             p.workspace, p.workspace_bytes = (ws.data_ptr(), ws.numel() * 4) if ws is not None else (None, 0)
         arr = (_hip.ConvParams * len(plist))(*plist)
         # multiply-adds the MFMA pipe really executes: a Winograd layer runs 16 GEMMs over ceil(H/2)*ceil(W/2) tiles per image
-        executed = sum(2.0 * p.Cin * p.Cout * (16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2, 3, 4) else p.ksize ** 2 * p.B * p.H * p.W)
+        executed = sum(2.0 * p.Cin * p.Cout * (16 * p.B * ((p.H + 1) // 2) * ((p.W + 1) // 2) if p.algo in (1, 2, 3, 4, 5) else p.ksize ** 2 * p.B * p.H * p.W)
                        for p in plist)
         plan = dict(key=key, arr=arr, n=len(plist), first=first, head_index=head_index, head_shape=head_shape, flops=flops, flops_executed=executed,
                     algos=[int(p.algo != 0) for p in plist], blks=blks, prep=prep,
