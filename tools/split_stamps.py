@@ -14,21 +14,22 @@ M, N, K, G = [int(v) for v in sys.argv[1:5]] if len(sys.argv) >= 5 else (1568, 1
 dev = torch.device('cuda:0')
 L, st = _hip.lib(), _hip.stream()
 g = torch.Generator().manual_seed(0)
-A = _hip.split_planes(torch.randn(G, M, K, generator=g).to(dev))
-B = _hip.split_planes((torch.randn(G, N, K, generator=g) * 0.05).to(dev))
+F16 = os.environ.get('STAMPS_F16', '0') == '1'
+A = _hip.split_planes(torch.randn(G, M, K, generator=g).to(dev) * (1 / 256.0 if F16 else 1.0), 'f16' if F16 else 'bf16')     # (split_planes scales by 256 in the f16 mode)
+B = _hip.split_planes((torch.randn(G, N, K, generator=g) * 0.05).to(dev), 'f16' if F16 else 'bf16')
 C = torch.empty(G, M, N, device=dev)
 stamps = torch.zeros(256, dtype=torch.int64, device=dev)
 os.environ['Y2_GS_STAMPS_PTR'] = str(stamps.data_ptr())
-for bk, nw in (('32', '8'), ('32', '4'), ('16', '4')):
+for bk, nw in ((('32', '8'), ('32', '4')) if F16 else (('32', '8'), ('32', '4'), ('16', '4'))):
     os.environ['Y2_SPLIT_BK'] = bk
     os.environ['Y2_SPLIT_WAVES'] = nw
     for _ in range(3):
-        _hip.check(L.y2_gemm_split(_hip.ptr(A), _hip.ptr(B), _hip.ptr(C), M, N, K, N, G, st), 'gemm')
+        _hip.check(L.y2_gemm_split_f16(_hip.ptr(A), _hip.ptr(B), _hip.ptr(C), M, N, K, N, G, 1.0, st) if F16 else L.y2_gemm_split(_hip.ptr(A), _hip.ptr(B), _hip.ptr(C), M, N, K, N, G, st), 'gemm')
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        _hip.check(L.y2_gemm_split(_hip.ptr(A), _hip.ptr(B), _hip.ptr(C), M, N, K, N, G, st), 'gemm')
+        _hip.check(L.y2_gemm_split_f16(_hip.ptr(A), _hip.ptr(B), _hip.ptr(C), M, N, K, N, G, 1.0, st) if F16 else L.y2_gemm_split(_hip.ptr(A), _hip.ptr(B), _hip.ptr(C), M, N, K, N, G, st), 'gemm')
     e1.record(); e1.synchronize()
     ms = e0.elapsed_time(e1) / 5
     raw = stamps.cpu().tolist()
@@ -46,4 +47,4 @@ for bk, nw in (('32', '8'), ('32', '4'), ('16', '4')):
     if nst > 4:
         mid = rows[2:-1]
         print('   mean of stages 2..%d: wait %.0f, barrier %.0f, compute %.0f, loop %.0f  (MFMA floor per stage: %d)' %
-              (nst - 2, sum(r[0] for r in mid) / len(mid), sum(r[1] for r in mid) / len(mid), sum(r[2] for r in mid) / len(mid), sum(r[3] for r in mid) / len(mid), 48 * 32 * int(bk) // 32 * 4 // int(nw)))
+              (nst - 2, sum(r[0] for r in mid) / len(mid), sum(r[1] for r in mid) / len(mid), sum(r[2] for r in mid) / len(mid), sum(r[3] for r in mid) / len(mid), (24 if F16 else 48) * 32 * int(bk) // 32 * 4 // int(nw)))
