@@ -106,6 +106,17 @@ class ResNet(nn.Module):
             raise ValueError('unexpected parameter name %s' % name)
         return '.'.join(comp)
 
+    @property
+    def _plan_cache(self):
+        """(tools / bench) the most recently used plan as (key, plan), None before the first forward."""
+        plan = self._plans.latest()
+        return None if plan is None else (plan['key'], plan)
+
+    @_plan_cache.setter
+    def _plan_cache(self, value):
+        assert value is None
+        self._plans.clear()
+
     # ------------------------------------------------------------------ preparation: packed weights + folded BN
     def _versions(self):
         # torch version counters (raw-pointer writers - utils.optim, y2_bn_finalize - advance them through _hip.wrote)
