@@ -143,8 +143,7 @@ def test_eval_mode_forward_is_differentiable_with_frozen_batchnorm(widths):
     check_grads(inf, sd64, tol=2e-4)
     for k, v in inf.dnn.named_buffers():
         assert torch.equal(v, before[k]), k
-    with pytest.raises(RuntimeError, match='input image'):
-        inf.dnn(x.to(dev()).requires_grad_(True))
+
 
 
 def test_two_training_forwards_before_one_backward():
@@ -341,3 +340,51 @@ def test_detectors_in_different_slots_overlap_on_two_streams():
         for b, c in enumerate(kc):
             assert torch.equal(r.result['keep'][b, :c], want['keep'][b, :c])
     assert len(inf.dnn._plans.d) == 2          # one plan per slot
+
+
+@pytest.mark.parametrize('arch,training', [('darknet', False), ('darknet', True), ('tiny', False), ('resnet18', False), ('resnet18', True)])
+def test_gradient_with_respect_to_the_image(arch, training):
+    """receptive_field_analyzer.py:67,87 back-propagates to the INPUT (in eval mode): d(feature element)/d(image) and every parameter gradient of
+    the same backward against the oracle's autograd - Darknet-19, tiny-yolo and a ResNet, eval (frozen BatchNorm) and train mode."""
+    import model
+    import model.resnet
+    import model.yolo2
+    from oracle import resnet as ores
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1'}, 'model': {'pretrained': '0'}})
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    if arch == 'darknet':
+        w = dict(NARROW)
+        w['layers1.5'] = 8
+        sd = odark.init_state_dict(5, 20, seed=0, channels=w, head_scale=1 / 8.0)
+        dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, 20)
+        fwd = lambda x, s: odark.forward(x, s, training=training)
+    elif arch == 'tiny':
+        sd = odark.init_tiny_state_dict(5, 20, seed=0, div=8, head_scale=0.25)
+        dnn = model.yolo2.Tiny(model.ConfigChannels(cfg, sd), anchors, 20)
+        fwd = lambda x, s: odark.tiny_forward(x, s, training=training)
+    else:
+        sd = ores.init_state_dict(arch, 5, 20, seed=0, width=8, head_scale=0.25)
+        dnn = getattr(model.resnet, arch)(model.ConfigChannels(cfg, sd), anchors, 20)
+        fwd = lambda x, s: ores.forward(x, s, arch, training=training)
+    dnn.load_state_dict(sd, strict=False)
+    dnn = dnn.to(dev())
+    dnn.train(training)
+    x = synth.images(2, 96, seed=1)
+    xd = x.to(dev()).requires_grad_(True)
+    f = dnn(xd)
+    probe = torch.randn(f.shape, generator=torch.Generator().manual_seed(3))      # a fixed cotangent: sum(feature * probe)
+    (f * probe.to(dev())).sum().backward()
+    assert xd.grad is not None and xd.grad.shape == x.shape
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    x64 = x.double().requires_grad_(True)
+    (fwd(x64, sd64) * probe.double()).sum().backward()
+    sd32 = {k: v.clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    x32 = x.clone().requires_grad_(True)
+    (fwd(x32, sd32) * probe).sum().backward()
+    floor = rel(x32.grad, x64.grad)
+    assert rel(xd.grad, x64.grad) <= max(2e-4, 3 * floor), (rel(xd.grad, x64.grad), floor)
+    ours = dict(dnn.named_parameters())
+    for k, v in sd64.items():
+        if v.requires_grad:
+            assert rel(ours[k].grad, v.grad) <= max(2e-3, 3 * rel(sd32[k].grad, v.grad)), k

@@ -513,8 +513,9 @@ def _darknet_bwd(ctx, dout):
         sf, sp = src_full[i], src_pool[i]
         # first layer (model/yolo2.py:78-79: conv + pool, nothing below it needs a data gradient): its dz is consumed by the weight gradient
         # alone, which forms it on the fly from (z, dy_pool) and the pass-1 sums - no dz tensor (1.4 GB at batch 64), no second pass
+        need_dx = bool(getattr(ctx, 'need_dx', False))
         fuse0 = (FUSE_CONV0 and blk.first and i in wg and sf is None and sp is not None and not (h & 1) and not (w & 15)
-                 and B * h * w * cout * 4 < 0xffff0000)
+                 and B * h * w * cout * 4 < 0xffff0000 and not need_dx)
         dz = None if fuse0 else (dzs[i] if i in dzs else _new(dev, B, h, w, cop))
         if DEBUG_TAP is not None:
             DEBUG_TAP(blk.name + ':in', blk.z, blk.shift, sf, sp)
@@ -590,6 +591,18 @@ def _darknet_bwd(ctx, dout):
         else:
             ready(weight, weight_grad(st))
         blk.wino_v = None
+        if blk.first and need_dx:
+            # gradient with respect to the image: the first layer's data gradient in a 4-channel NHWC space (its 3 -> 4 zero-padded input
+            # channels are the OUTPUT channels of this convolution), then the plugin's NCHW layout - a rare path (receptive-field analysis)
+            cin4 = (cin + 3) // 4 * 4
+            wpad = torch.zeros(cop, cin4, k, k, dtype=torch.float32, device=dev)
+            wpad[:cout, :cin] = e.w
+            wd = _new(dev, wpad.numel())
+            _hip.check(L.y2_pack_weight(_hip.ptr(wpad), _hip.ptr(wd), cop, cin4, k, 1, st), 'y2_pack_weight')
+            dx4 = _new(dev, B, h, w, cin4)
+            _conv(L, st, dz, wd, dx4, B, h, w, cop, cop, cin4, k, cin4)
+            ctx_dx = dx4[..., :cin].permute(0, 3, 1, 2).contiguous()
+            grads['__x__'] = ctx_dx
         if not blk.first:
             # data gradient -> the producer's gradient source
             dx = _new(dev, B, h, w, cin)
@@ -647,7 +660,7 @@ def _darknet_bwd(ctx, dout):
         ready(prm, t)
     flush_weight_grads()
     L.y2_prof_set_tag(0)
-    out = [None, None]
+    out = [None, grads.get('__x__')]
     for pid in ctx.param_ids:
         out.append(grads.get(pid))
     ctx.blocks = None
@@ -658,9 +671,7 @@ def _darknet_bwd(ctx, dout):
 class DarknetTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dnn, x, *params):
-        if x.requires_grad:
-            raise RuntimeError('model.yolo2: the gradient with respect to the input image is not implemented (the first layer has no data-gradient '
-                               'kernel); detach the input')
+        ctx.need_dx = x.requires_grad          # gradient with respect to the image (receptive_field_analyzer.py:87): one more data-gradient convolution
         return _darknet_fwd(ctx, dnn, x, params, frozen=False)
 
     @staticmethod
@@ -675,9 +686,7 @@ class _Tape(object):
 class DarknetEvalGradFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dnn, x, *params):
-        if x.requires_grad:
-            raise RuntimeError('model.yolo2: the gradient with respect to the input image is not implemented (the first layer has no data-gradient '
-                               'kernel); detach the input')
+        ctx.need_dx = x.requires_grad
         ctx.dnn, ctx.x, ctx.params = dnn, x.detach(), params
         ctx.key = dnn._versions()
         return dnn.forward_nhwc(x.detach())
@@ -687,6 +696,7 @@ class DarknetEvalGradFn(torch.autograd.Function):
         if ctx.dnn._versions() != ctx.key:
             raise RuntimeError('model.yolo2: parameters or buffers were modified between an eval-mode forward and its backward')
         tape = _Tape()
+        tape.need_dx = ctx.need_dx
         _darknet_fwd(tape, ctx.dnn, ctx.x, ctx.params, frozen=True)      # recompute with frozen BatchNorm statistics, keeping the activations
         return _darknet_bwd(tape, dout)
 
@@ -956,8 +966,7 @@ class ResNetTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, frozen, *params):
         _hip.require_gpu(x)
-        if x.requires_grad:
-            raise RuntimeError('model: the gradient with respect to the input image is not implemented; detach the input')
+        ctx.need_dx = x.requires_grad
         L = _hip.lib()
         st = _hip.stream()
         x = _hip.f32c(x.detach())
@@ -970,6 +979,7 @@ class ResNetTrainFn(torch.autograd.Function):
         cpad = (cin0 + 3) // 4 * 4
         x4 = _new(dev, B, H, W, cpad)
         _hip.check(L.y2_nchw_to_nhwc(_hip.ptr(x), _hip.ptr(x4), B, cin0, H, W, cpad, st), 'y2_nchw_to_nhwc')
+        ctx.x4, ctx.cin0 = x4, cin0
 
         def conv_bn(conv, bn, xin, ldx, h, w, stride, pad, slope, residual=None, first=False, momentum=None):
             op = _ROp()
@@ -1120,13 +1130,13 @@ class ResNetTrainFn(torch.autograd.Function):
             _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cop, cin, k, st), 'y2_unpack_weight_grad')
             ready(op.conv.weight, dw if (cop == cout and cin == op.cin) else dw[:cout, :op.cin].contiguous())
             op.z = None
-            if op.first:
+            if op.first and not ctx.need_dx:
                 continue
-            # ---- data gradient
+            # ---- data gradient (of the first layer only when the image's gradient is wanted: its result is the 4-channel NHWC image gradient)
             wsrc = _hip.f32c(op.conv.weight.detach())
-            if cop != cout:
+            if cop != cout or wsrc.shape[1] != cin:          # zero rows for padded output channels, zero columns for the stem's padded input channels
                 wpad = torch.zeros(cop, cin, k, k, dtype=torch.float32, device=dev)
-                wpad[:cout] = wsrc
+                wpad[:cout, :wsrc.shape[1]] = wsrc
                 wsrc = wpad
             wd = _new(dev, wsrc.numel())
             _hip.check(L.y2_pack_weight(_hip.ptr(wsrc), _hip.ptr(wd), cop, cin, k, 1, st), 'y2_pack_weight')
@@ -1136,7 +1146,12 @@ class ResNetTrainFn(torch.autograd.Function):
             else:
                 _gen_conv(L, st, dz, wd, dx, B, ho, wo, cop, cop, cin, k, op.stride, op.pad, transposed=True, out_hw=(op.h, op.w))
             G.setdefault(id(op.x), []).append(dx)
-        out = [None, None, None]
+        dx_img = None
+        if ctx.need_dx:
+            gx = G.pop(id(ctx.x4), None)
+            if gx:
+                dx_img = gx[0][..., :ctx.cin0].permute(0, 3, 1, 2).contiguous()
+        out = [None, dx_img, None]
         for pid in ctx.param_ids:
             out.append(grads.get(pid))
         ctx.ops = None
