@@ -96,7 +96,7 @@ def test_full_batch_matches_fp64_oracle_on_sampled_images(net, batch, truth):
         assert rel(got[j:j + 1], truth[j:j + 1]) <= 2e-5, (i, rel(got[j:j + 1], truth[j:j + 1]))
 
 
-@pytest.mark.parametrize('algo', ['direct', 'winograd', 'fused', 'implicit', 'split', 'split16'])
+@pytest.mark.parametrize('algo', ['direct', 'winograd', 'fused', 'implicit', 'fused3', 'implicit3', 'split', 'split16'])
 def test_full_batch_under_each_forced_algorithm(net, batch, truth, algo, monkeypatch):
     """Deterministic algorithm coverage of the whole-model path: with autotune out of the picture every eligible 3x3 layer runs the
     direct implicit GEMM / the three-kernel Winograd / the fused Winograd kernel (the rest stays direct), at the full batch-32
@@ -114,8 +114,10 @@ def test_full_batch_under_each_forced_algorithm(net, batch, truth, algo, monkeyp
             f = inf.dnn.forward_nhwc(x.to(dev())).clone()
         plan = inf.dnn._plan_cache[1]
         algos = [plan['arr'][i].algo for i in range(plan['n'])]
-        want = {'direct': 0, 'winograd': 1, 'fused': 2, 'implicit': 3, 'split': 4, 'split16': 5}[algo]
+        want = {'direct': 0, 'winograd': 1, 'fused': 2, 'implicit': 3, 'fused3': 2, 'implicit3': 3, 'split': 4, 'split16': 5}[algo]
         assert (max(algos) == want) and (algo == 'direct' or algos.count(want) >= 10), algos     # 13 eligible layers (Cin >= 64)
+        if algo.endswith('3'):      # the two-workgroups-per-CU kernel (y2_conv_params.tile = 3) on every layer it accepts (Cin >= 64)
+            assert sum(1 for i in range(plan['n']) if plan['arr'][i].algo == want and plan['arr'][i].tile == 3) >= 10
     finally:
         inf.dnn._plan_cache = None
         inf.dnn._cache = None

@@ -177,12 +177,18 @@ def test_conv_fwd_winograd_matches_fp64_reference(B, cin, cout, H, W, tile, pool
     (2, 64, 64, 2, 7, 0, False),
     (3, 32, 64, 30, 26, 0, True),         # Cin = 32: a tile is a single K slab (the 208x208 layer of Darknet-19), pooled output
     (2, 32, 40, 13, 9, 32, False),        # ... ragged map, channel window, Cout not a multiple of 64
+    (33, 128, 200, 30, 26, 0, True),      # 6435 tiles x 4 channel tiles on 512 workgroup slots (gen 3), last channel tile ragged
 ])
-def test_conv_fwd_implicit_is_bit_identical_to_fused(B, cin, cout, H, W, pad_ch, pool):
+@pytest.mark.parametrize('gen', [0, 3])
+def test_conv_fwd_implicit_is_bit_identical_to_fused(B, cin, cout, H, W, pad_ch, pool, gen):
     """Y2_ALGO_WINOGRAD_IMPLICIT runs the same GEMM and the same output transform as Y2_ALGO_WINOGRAD_FUSED; what changes is where
     B^T d B is computed (registers of the fused kernel's loader instead of wino_input_kernel + memory), with the same operations in
-    the same order.  So the two must agree bit for bit: output, pooled output and the fp64 statistics up to the order of the atomics."""
+    the same order.  So the two must agree bit for bit: output, pooled output and the fp64 statistics up to the order of the atomics.
+    gen = 3: the same pair as wino_fused3_kernel (y2_conv_params.tile = 3; 32-tile x 64-channel units, two workgroups per CU, 16x16x4
+    MFMAs): bit-identical to each other, and equal to the second-generation kernels up to the order of the K sum."""
     import _hip
+    if gen == 3 and cin < 64:
+        pytest.skip('the third-generation kernel needs two K slabs (Cin >= 64); below that tile = 3 runs the second-generation kernel')
     L, d = _hip.lib(), dev()
     g = torch.Generator().manual_seed(B * 131 + cin + cout + H * W)
     ldx = cin + pad_ch
@@ -204,6 +210,7 @@ def test_conv_fwd_implicit_is_bit_identical_to_fused(B, cin, cout, H, W, pad_ch,
             yp = torch.full((B, H // 2, W // 2, cout), -7.0, device=d)
             p.y_pool, p.ldp, p.poff = yp.data_ptr(), cout, 0
         p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize, p.slope, p.algo = B, H, W, cin, ldx, cout, 3, 0.1, algo
+        p.tile = gen
         need = _hip.conv_workspace(p, d)
         assert need >= 0
         if algo == 3:
@@ -220,13 +227,20 @@ def test_conv_fwd_implicit_is_bit_identical_to_fused(B, cin, cout, H, W, pad_ch,
     x_nchw = xw[..., pad_ch:].permute(0, 3, 1, 2).cpu()
     z, ref = ref_conv(x_nchw, w.cpu(), sc.cpu(), sh.cpu(), 0.1, 3)
     assert rel_err(res[3][0][..., 4:].permute(0, 3, 1, 2), ref) <= 4 * CONV_TOL
+    if pool:
+        assert rel_err(res[3][1].permute(0, 3, 1, 2), F.max_pool2d(ref, 2)) <= 4 * CONV_TOL
+    s1, s2 = z.sum((0, 2, 3)), (z * z).sum((0, 2, 3))
+    np.testing.assert_allclose(res[3][2][:cout].numpy(), s1.numpy(), rtol=1e-5, atol=2e-5 * float(s2.max().sqrt()))
+    np.testing.assert_allclose(res[3][2][cout:].numpy(), s2.numpy(), rtol=2e-5)
 
 
-@pytest.mark.parametrize('algo', [1, 2])
+@pytest.mark.parametrize('algo', [1, 2, 23])      # 23: the fused algorithm with tile = 3 (third-generation kernel)
 @pytest.mark.parametrize('pool', [False, True])
 def test_conv_fwd_winograd_batch_chunks(pool, monkeypatch, algo):
     """Y2_WINO_CHUNK_MB bounds the Winograd workspace by running the three stages per batch chunk: 5 images in chunks of 2+2+1
     (ragged last chunk) must give the same output and the same BN statistics as one chunk."""
+    tile = 3 if algo > 3 else 0
+    algo = algo // 10 if algo > 3 else algo
     B, cin, cout, H, W = (5 if algo == 1 else 13), 64, 96, 14 if pool else 13, 10 if pool else 11      # fused: no product tensor, smaller chunks
     g = torch.Generator().manual_seed(77)
     x = torch.randn(B, cin, H, W, generator=g)
@@ -236,7 +250,7 @@ def test_conv_fwd_winograd_batch_chunks(pool, monkeypatch, algo):
     per_image = 16 * ((H + 1) // 2) * ((W + 1) // 2) * (cin + (cout if algo == 1 else 0)) * 4
     assert per_image < (1 << 20) < B * per_image              # 1 MB holds fewer than the B images of this layer
     monkeypatch.setenv('Y2_WINO_CHUNK_MB', '1')
-    out = run_conv(x, w, scale, shift, 0.1, 3, pool=pool, both=pool, wino=algo, stats=True)
+    out = run_conv(x, w, scale, shift, 0.1, 3, pool=pool, both=pool, wino=algo, stats=True, tile=tile)
     assert rel_err(out['y'].permute(0, 3, 1, 2), ref) <= 4 * CONV_TOL
     if pool:
         assert rel_err(out['y_pool'].permute(0, 3, 1, 2), F.max_pool2d(ref, 2)) <= 4 * CONV_TOL

@@ -61,9 +61,10 @@ def main():
         p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         ref = None
         row = '%-18s' % ('%dx%d %d->%d' % (H, H, cin, cout))
+        diffs = []
         for v in variants:
-            os.environ['Y2_WF_VARIANT'] = str(v if v != 100 else 3)
-            p.algo = 3 if v == 100 else (1 if v == 200 else (0 if v == 300 else 2))      # 200: three-kernel Winograd (64x128 GEMM tiles), 300: direct
+            os.environ['Y2_WF_VARIANT'] = str(3 if v == 100 else (32 if v == 136 else v))      # 136: third-generation kernel, implicit
+            p.algo = 3 if v in (100, 136) else (1 if v == 200 else (0 if v == 300 else 2))      # 200: three-kernel Winograd (64x128 GEMM tiles), 300: direct
             p.tile = 5 if v == 200 else 0
             p.w = wp.data_ptr() if v == 300 else u.data_ptr()
             y.fill_(float('nan'))
@@ -79,7 +80,7 @@ def main():
             if args.stamps:
                 T = B * ((H + 1) // 2) ** 2
                 a256 = lambda n: (n + 255) // 256 * 256
-                off = (0 if v == 100 else a256(16 * T * cin * 4)) + a256((T + 63) * 4) + 1024
+                off = (0 if v in (100, 136) else a256(16 * T * cin * 4)) + a256((T + 63) * 4) + 1024
                 raw = ws.view(torch.uint8)[off:off + 8000].cpu().numpy().view('uint64')
                 d = [int(raw[i + 1]) - int(raw[i]) if raw[i + 1] and raw[i] else 0 for i in range(0, 160)]
                 nst = 4 * (cin // 32)
@@ -117,7 +118,9 @@ def main():
                         tk.append(ms.value)
                 best = min(tk)
             row += '%8.4f%s' % (best, ' ' if same else '*')
-        print(row, flush=True)
+            if not same:
+                diffs.append('v%d: max|d|/rms %.2e' % (v, ((out[0] - ref[0]).abs().max() / ref[0].pow(2).mean().sqrt()).item()))
+        print(row + ('   ' + '; '.join(diffs) if diffs else ''), flush=True)
     print('(time includes wino_input_kernel; executed GFLOP per launch = 2*16*T*Cin*Cout)')
 
 

@@ -334,9 +334,9 @@ if TUNE_CACHE and os.path.exists(TUNE_CACHE):
 
 
 WINOGRAD = os.environ.get('Y2_WINOGRAD', '1') != '0'     # 0: never pick the Winograd F(2x2,3x3) algorithm
-FORCE_ALGO = os.environ.get('Y2_FORCE_ALGO') or None     # 'direct' | 'winograd' | 'fused' | 'implicit' | 'split': no autotune, that algorithm wherever the library accepts it
-if FORCE_ALGO not in (None, 'direct', 'winograd', 'fused', 'implicit', 'split'):
-    raise ValueError('Y2_FORCE_ALGO must be direct, winograd, fused, implicit or split (got %r)' % FORCE_ALGO)      # ('split': the algorithm of the current split mode)
+FORCE_ALGO = os.environ.get('Y2_FORCE_ALGO') or None     # 'direct' | 'winograd' | 'fused' | 'implicit' | 'fused3' | 'implicit3' | 'split': no autotune, that algorithm wherever the library accepts it
+if FORCE_ALGO not in (None, 'direct', 'winograd', 'fused', 'implicit', 'fused3', 'implicit3', 'split'):
+    raise ValueError('Y2_FORCE_ALGO must be direct, winograd, fused, implicit, fused3, implicit3 or split (got %r)' % FORCE_ALGO)      # ('split': the algorithm of the current split mode; '...3': the two-workgroups-per-CU kernel)
 # Opt-in precision modes: the Winograd GEMMs may run on the bf16 / fp16 matrix pipe from split operands (csrc/gemm_split.hip): fp32-level
 # accuracy (the same parity tests run in these modes).  SPLIT = 'bf16' (True): three bf16 planes per fp32 operand, six plane products
 # (Y2_ALGO_WINOGRAD_SPLIT; fp32's exponent range); 'f16': two fp16 planes, three products, operands scaled by fixed powers of two
@@ -431,9 +431,9 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
     if FORCE_ALGO is not None:
         # deterministic algorithm coverage (tests, A/B runs): every eligible layer takes the named algorithm, everything else the
         # direct kernel with the library's own tile choice; no measurement, no cache
-        want = {'direct': None, 'winograd': (1, 5), 'fused': (2, 0), 'implicit': (3, 0), 'split': (split_algo(), 0)}[FORCE_ALGO]
+        want = {'direct': None, 'winograd': (1, 5), 'fused': (2, 0), 'implicit': (3, 0), 'fused3': (2, 3), 'implicit3': (3, 3), 'split': (split_algo(), 0)}[FORCE_ALGO]
         if want is not None and want[0] == 3 and not implicit_ok:
-            want = (2, 0)               # where the transformed input must stay behind: the fused kernel that reads it
+            want = (2, want[1])         # where the transformed input must stay behind: the fused kernel that reads it
         if want is not None and want[0] in (4, 5) and not split_ok:
             want = (1, 5) if wino_ok else None
         if want is not None and wino_ok and (want[0] == 1 or params.Cin % 32 == 0):
@@ -450,6 +450,8 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
         if split_ok and params.H * params.W <= 19 * 19:
             prefer.append((split_algo(), 0))       # opt-in split mode: the 13x13 (19x19 at 608) layers, 25-30 % ahead of the fp32 GEMMs there
         if wino_ok and implicit_ok and (params.H * params.W >= 52 * 52 or (params.H * params.W >= 26 * 26 and params.Cout <= params.Cin)):
+            if 64 <= params.Cin <= 128:
+                prefer.append((3, 3))   # ... its two-workgroups-per-CU form where the K loop is short (11-13 % ahead on the 104x104 / 52x52 layers)
             prefer.append((3, 0))       # fused Winograd with the input transform in its loader: the large maps and the data gradients
         if wino_ok and params.Cin % 32 == 0 and params.H * params.W >= 26 * 26:
             prefer.append((2, 0))       # fused Winograd on the 104x104 ... 26x26 layers
@@ -471,6 +473,10 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
             cands.append((2, 0))        # fused GEMM + output transform (no product tensor): pays on the 52x52 layers
         if implicit_ok:
             cands.append((3, 0))        # ... with the input transform in its loader (no transformed input in memory either)
+        if params.Cin % 32 == 0 and params.Cin >= 64:
+            cands.append((2, 3))        # the same two as 32 x 64 units, two workgroups per CU (wino_fused3_kernel): short K loops, small grids
+            if implicit_ok:
+                cands.append((3, 3))
         if split_ok:
             cands.append((split_algo(), 0))        # three-kernel Winograd with the GEMMs on the bf16 / fp16 pipe (opt-in precision modes)
     best, best_t = (0, 0), float('inf')

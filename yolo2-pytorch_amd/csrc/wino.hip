@@ -875,6 +875,332 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef Y2_STAMP
 }
 
+// ---- fused kernel, third generation: TWO workgroups per CU.  wino_fused2_kernel runs one wave per SIMD (256 accumulator
+// registers), so nothing covers its stage barriers, its epilogue (MFMA pipe idle for ~6k cycles per tile) or the register-path
+// loader of the implicit variant.  Here a workgroup owns 32 tiles x 64 channels x 16 positions: 4 waves (2 x 2), wave tile 16 tiles
+// x 32 channels as 2 blocks of v_mfma_f32_16x16x4_f32 (same 64 FLOP / cycle / SIMD as 32x32x2) = 16 positions x 2 blocks x 4 =
+// 128 accumulator registers, two waves per SIMD, and the second workgroup's MFMAs run under the first one's barrier waits,
+// fragment reads, claims and epilogue.  The output transform stays in-lane (a lane holds all 16 positions of its 4 tile rows x 2
+// channels).  Stage = 2 positions x 32 input channels: A = V[p][32 tiles][32] (4 KB) + B = U[p][64 channels][32] (8 KB) per position,
+// 24 KB per stage, 3-deep ring (72 KB per workgroup): the pieces of stage i+2 are issued at the top of stage i, so two stages of
+// LDS-DMA are in flight and a stage waits with vmcnt(6), not vmcnt(0).  Same 128-B rows and XOR chunk swizzle as the other
+// kernels: a ds_read_b128 lane group (MI355X_MICROARCH.md, LDS) sees 16 distinct 16-B slots.
+// The K sum runs in another order than in the 32x32x2 kernels (4 channels per MFMA instead of 2): results agree with the other
+// Winograd algorithms to fp32 rounding, not bit for bit; the DMA'd-V and the implicit variant of THIS kernel are bit-identical.
+constexpr int F3_TM = 32;
+constexpr int F3_POS_FLOATS = (F3_TM + 64) * 32;      // one position's A + B slab (12 KB)
+constexpr int F3_STAGE_FLOATS = 2 * F3_POS_FLOATS;    // two positions per stage
+constexpr int F3_NST = 3;
+
+template <int VAR, int OUT>     // VAR bit 2: implicit input transform; OUT as in wino_fused2_kernel
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_fused3_kernel(const WinoFusedArgs a) {
+    constexpr bool HAS_Y = (OUT & 1) != 0, HAS_POOL = (OUT & 2) != 0, HAS_STATS = (OUT & 4) != 0;
+    constexpr bool RAWIN = (VAR & 4) != 0;
+    constexpr unsigned OOB = 0x80000000u, OOB_COL = 0x40000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int xcd = blockIdx.x % Y2_NUM_XCD, wg_in_xcd = blockIdx.x / Y2_NUM_XCD;
+    const int wgs_per_xcd = gridDim.x / Y2_NUM_XCD;
+    const int per_xcd = (ntiles + Y2_NUM_XCD - 1) / Y2_NUM_XCD;
+    const int xcd_end = min(ntiles, (xcd + 1) * per_xcd);
+    int tile = xcd * per_xcd + wg_in_xcd;
+    if (tile >= xcd_end) return;
+
+    // operand ownership: thread t moves chunk (lane & 7) of row t >> 3 of the A slab (LDS-DMA, or - implicit - built from the 4x4
+    // input patch of that tile) and of rows t >> 3, 32 + (t >> 3) of the B slab
+    const int rowA = t >> 3;
+    const int lchunk = (lane & 7) ^ ((rowA >> 1) & 7);
+    unsigned a_off = OOB, b_off[2] = {OOB, OOB};
+    unsigned rowoff[4], coloff[4];               // RAWIN: byte offsets of the rows / columns of the thread's patch (see wino_fused2_kernel)
+    int fm0 = 0, fn0 = 0;
+    auto place_a = [&](int tl, bool ok) {        // the input side of tile tl (ok == false: nothing left - every load returns zeros)
+        fm0 = (tl / a.tiles_n) * F3_TM;
+        const int m = fm0 + rowA;
+        const bool mok = ok && m < a.T;
+        if (!RAWIN) {
+            a_off = mok ? (unsigned)(((size_t)m * a.Cin + 4 * lchunk) * 4) : OOB;
+        } else {
+            const uint32_t mm = mok ? (uint32_t)m : 0u;
+            const int b = (int)y2_div(mm, a.d_tt);
+            const int rr = (int)mm - b * a.th * a.tw;
+            const int ty = (int)y2_div((uint32_t)rr, a.d_tw);
+            const int tx = rr - ty * a.tw;
+            const unsigned pix_bytes = (unsigned)a.ldx * 4u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int yy = 2 * ty - 1 + r, xx = 2 * tx - 1 + r;
+                rowoff[r] = (mok && (unsigned)yy < (unsigned)a.H) ? (unsigned)((b * a.H + yy) * a.W) * pix_bytes : OOB;
+                coloff[r] = (unsigned)xx < (unsigned)a.W ? (unsigned)xx * pix_bytes + 16u * (unsigned)lchunk : OOB_COL;
+            }
+        }
+    };
+    auto place_b = [&](int tl) {
+        fn0 = (tl % a.tiles_n) * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = fn0 + rowA + 32 * i;
+            b_off[i] = n < a.Cout ? (unsigned)(((size_t)n * a.Cin + 4 * lchunk) * 4) : OOB;
+        }
+    };
+    place_a(tile, true);
+    place_b(tile);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RAWIN ? a.x : a.v), 0, RAWIN ? a.x_bytes : a.v_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.v), 0, a.v_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
+    const unsigned v_plane = (unsigned)((size_t)a.T * a.Cin * 4), u_plane = (unsigned)((size_t)a.Cout * a.Cin * 4);
+
+    // LDS-DMA piece j of stage (kslab, g) into ring slot `slot`: j = 3 * pp + w, w = 0: the A rows (not RAWIN), 1, 2: the B rows
+    auto piece = [&](int kslab, int g, int slot, int j) {
+        const int pp = j / 3, w = j % 3;
+        int p = 2 * g + pp;
+        asm volatile("" : "+s"(p));
+        float* sa = smem + slot * F3_STAGE_FLOATS + pp * F3_POS_FLOATS + wave * (8 * 32);
+        if (w == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)sa, 16, (int)a_off, (int)((unsigned)p * v_plane + (unsigned)kslab * 128u), 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(sa + w * 32 * 32), 16, (int)b_off[w - 1], (int)((unsigned)p * u_plane + (unsigned)kslab * 128u), 0, 0);
+    };
+    auto fetch = [&](int kslab, int g, int slot) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (!RAWIN || (j % 3) != 0) piece(kslab, g, slot, j);
+    };
+    // RAWIN.  V[4g + j] = column combination j of s_g, s_g = row combination g of the 4x4 patch (the operations and their order are
+    // wino_input_kernel's: bit-identical V).  A stage holds positions (g, 2h), (g, 2h + 1): the even stage of a pair forms s_g, writes
+    // V[.][0..1] and keeps V[.][2..3] for the odd one.  The patch lives in two register rows: px = row 0, after s_0 row 1;
+    // py = row 2, after s_2 row 3 (s_0 = px - py, s_1 = px + py, s_2 = py - px, s_3 = px - py); behind s_3 both are re-loaded for the
+    // next K slab.  Every re-load is two stages ahead of its first use: 16 loads per thread per K slab.
+    f32x4 px[4], py[4], vh[2];
+    auto raw_one = [&](f32x4* dst, int row, int c, int kslab) {
+        unsigned voff;
+        asm volatile("v_add_u32 %0, %1, %2" : "=v"(voff) : "v"(rowoff[row]), "v"(coloff[c]));
+        dst[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff, kslab * 128, 0));
+    };
+    auto col_combine = [&](const f32x4* q, int j) -> f32x4 {
+        return j == 0 ? y2_pk_sub(q[0], q[2]) : (j == 1 ? y2_pk_add(q[1], q[2]) : (j == 2 ? y2_pk_sub(q[2], q[1]) : y2_pk_sub(q[1], q[3])));
+    };
+    // the loader's share of fetch stage (kslab, fg) into ring slot `slot` (behind the four B pieces: in the vmcnt order the re-loaded
+    // patch rows come AFTER them); kslab_next: the K slab behind the fetch stage's
+    auto raw_fetch = [&](auto FG_, auto DRAIN_, int kslab, int kslab_next, int slot) {
+        constexpr int fg = decltype(FG_)::value;
+        constexpr bool drain = decltype(DRAIN_)::value;
+        constexpr int g = fg >> 1;
+        float* const wbuf = smem + slot * F3_STAGE_FLOATS + t * 4;
+        if ((fg & 1) == 0) {
+            f32x4 sv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sv[c] = g == 1 ? y2_pk_add(px[c], py[c]) : (g == 2 ? y2_pk_sub(py[c], px[c]) : y2_pk_sub(px[c], py[c]));
+            const f32x4 v0 = col_combine(sv, 0), v1 = col_combine(sv, 1);
+            if (!drain) {
+                *reinterpret_cast<f32x4*>(wbuf) = v0;
+                *reinterpret_cast<f32x4*>(wbuf + F3_POS_FLOATS) = v1;
+            }
+            vh[0] = col_combine(sv, 2);
+            vh[1] = col_combine(sv, 3);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (g == 0) { raw_one(px, 1, c, kslab); }
+                else if (g == 2) { raw_one(py, 3, c, kslab); }
+                else if (g == 3) { raw_one(px, 0, c, kslab_next); raw_one(py, 2, c, kslab_next); }
+            }
+        } else if (!drain) {
+            *reinterpret_cast<f32x4*>(wbuf) = vh[0];
+            *reinterpret_cast<f32x4*>(wbuf + F3_POS_FLOATS) = vh[1];
+        }
+    };
+
+    f32x4 acc[16][2];
+    const int sw = (l15 >> 1) & 7;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        offA[h] = (wm * 16 + l15) * 32 + (((4 * h + kq) ^ sw) << 2);
+        offB[h] = (32 + wn * 32 + l15) * 32 + (((4 * h + kq) ^ sw) << 2);
+    }
+    const int nks = a.Cin / 32;                   // host: >= 2
+    int slot = 0;                                 // ring slot of the stage being consumed
+    int claimed = 0;
+    bool more = false;
+    volatile int* const sched_lds = reinterpret_cast<volatile int*>(smem + F3_NST * F3_STAGE_FLOATS);
+
+    // One stage = two halves of 16 input channels (6 ds_read_b128 + 16 MFMAs each).  The stage barrier sits in the MIDDLE: the first
+    // half runs on fragments read during the previous stage, then the wave waits for its own pieces of stage i+1 (issued a whole
+    // stage ago), the barrier publishes everybody's - and says that nobody reads ring slot i-1 any more - , the pieces of stage
+    // i+2 go out into that slot, the first-half fragments of stage i+1 are read, and the second half's MFMAs cover their latency.
+    f32x4 a0[2], b0[2][2];                      // first-half fragments of the stage about to run [position][block]
+    auto reads = [&](const float* sb, int h, f32x4* av, f32x4 (*bv)[2]) {
+#if defined(Y2_F3EXP) && (Y2_F3EXP & 2)
+        if (a.T < 0)
+#endif
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            av[pp] = *reinterpret_cast<const f32x4*>(sb + pp * F3_POS_FLOATS + offA[h]);
+            bv[pp][0] = *reinterpret_cast<const f32x4*>(sb + pp * F3_POS_FLOATS + offB[h]);
+            bv[pp][1] = *reinterpret_cast<const f32x4*>(sb + pp * F3_POS_FLOATS + offB[h] + 16 * 32);
+        }
+    };
+    // fk: K slab of fetch stage i+2; fkn: the K slab behind it (RAWIN re-loads); DRAIN: the workgroup's last two stages fetch nothing
+    // (no LDS-DMA may be in flight when it ends).  The order inside a half is the compiler's: pinning it with scheduling barriers
+    // (pieces and loader steps behind individual MFMAs, as in wino_fused2_kernel) measured 3-5 % slower and spilled accumulators.
+    auto stage = [&](auto G_, auto ZC_, auto DRAIN_, int fk, int fkn) {
+        constexpr int G = decltype(G_)::value;
+        constexpr bool zc = decltype(ZC_)::value;
+        constexpr bool drain = decltype(DRAIN_)::value;
+        constexpr int FG = (G + 2) & 7;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 a1[2], b1[2][2];
+        if (RAWIN) reads(smem + slot * F3_STAGE_FLOATS, 0, a0, b0);      // (the loader's registers: no fragments carried across its work)
+        reads(smem + slot * F3_STAGE_FLOATS, 1, a1, b1);
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) {
+            const int s = idx >> 2, pp = (idx >> 1) & 1, blk = idx & 1;
+            acc[2 * G + pp][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[pp][s], b0[pp][blk][s], (zc && s == 0) ? zero4 : acc[2 * G + pp][blk], 0, 0, 0);
+        }
+        if (!RAWIN) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            // behind the pieces of stage i+1 sit only the patch rows re-loaded at the previous fetch point (fetch stage G + 1): they may stay in flight
+            constexpr int PFG = (G + 1) & 7;
+            if (PFG == 0 || PFG == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else if (PFG == 6) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const int fslot = slot == 0 ? 2 : slot - 1;
+        slot = slot == 2 ? 0 : slot + 1;
+#if defined(Y2_F3EXP) && (Y2_F3EXP & 1)
+        if (a.T < 0)
+#endif
+        if (!drain) fetch(fk, FG, fslot);
+        if (RAWIN) raw_fetch(std::integral_constant<int, FG>{}, DRAIN_, fk, fkn, fslot);
+        else reads(smem + slot * F3_STAGE_FLOATS, 0, a0, b0);
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) {
+            const int s = idx >> 2, pp = (idx >> 1) & 1, blk = idx & 1;
+            acc[2 * G + pp][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[pp][s], b1[pp][blk][s], acc[2 * G + pp][blk], 0, 0, 0);
+        }
+    };
+#define Y2_G(n) std::integral_constant<int, n>{}
+    // the 8 stages of K slab ks.  The slab before the last one claims the workgroup's next tile from the XCD's counter (thread 0;
+    // handed over through LDS across stage barriers); the last slab's fetch stream moves on to that tile: its patch rows from fetch
+    // stage 6 on, its operand rows in the last two stages.
+    auto slab = [&](auto ZC_, int ks) {
+        const bool pen = ks == nks - 2, last = ks == nks - 1;
+        if (last) {
+            tile = xcd * per_xcd + __builtin_amdgcn_readfirstlane(*sched_lds);
+            more = tile < xcd_end;
+        }
+        const int fk2 = last ? 0 : ks + 1;
+        using NO = std::false_type;
+        stage(Y2_G(0), ZC_, NO{}, ks, fk2);
+        stage(Y2_G(1), ZC_, NO{}, ks, fk2);
+        stage(Y2_G(2), ZC_, NO{}, ks, fk2);
+        if (RAWIN && last) place_a(tile, more);      // (row 3 of this tile's last K slab has just been requested: the patch offsets move on)
+        stage(Y2_G(3), ZC_, NO{}, ks, fk2);
+        stage(Y2_G(4), ZC_, NO{}, ks, fk2);
+        if (pen && t == 0) claimed = a.sched_static ? (tile - xcd * per_xcd + wgs_per_xcd) : atomicAdd(a.sched + xcd, 1);
+        stage(Y2_G(5), ZC_, NO{}, ks, fk2);
+        if (pen && t == 0) *sched_lds = claimed;
+        if (last && !more) {
+            stage(Y2_G(6), ZC_, std::true_type{}, fk2, fk2);
+            stage(Y2_G(7), ZC_, std::true_type{}, fk2, fk2);
+        } else {
+            if (last) { if (!RAWIN) place_a(tile, true); place_b(tile); }
+            stage(Y2_G(6), ZC_, NO{}, fk2, fk2);
+            stage(Y2_G(7), ZC_, NO{}, fk2, fk2);
+        }
+    };
+
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, HAS_Y ? a.y_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ryp = __builtin_amdgcn_make_buffer_rsrc(a.y_pool, 0, HAS_POOL ? a.yp_bytes : 0, 0x00020000);
+    const int so_x = a.ldy * 4, so_y = a.W * a.ldy * 4;
+
+    // prologue: stages 0 and 1 of the first tile, the first-half fragments of stage 0
+    if (RAWIN) {
+        f32x4 sv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { raw_one(px, 0, c, 0); raw_one(py, 2, c, 0); }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sv[c] = y2_pk_sub(px[c], py[c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) raw_one(px, 1, c, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(smem + (j >> 1) * F3_STAGE_FLOATS + (j & 1) * F3_POS_FLOATS + t * 4) = col_combine(sv, j);
+    }
+    fetch(0, 0, 0);
+    fetch(0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    reads(smem, 0, a0, b0);
+    for (;;) {
+        const int em0 = fm0, en0 = fn0;            // this tile's origin (the fetch cursor moves on during its last K slab)
+        slab(std::true_type{}, 0);                 // (never the last slab: nks >= 2) the accumulators start from the MFMA's zero operand
+        for (int ks = 1; ks < nks; ++ks) slab(std::false_type{}, ks);
+        // ---- epilogue: A^T M A in registers, affine + LeakyReLU, pooling, statistics, stores - branch-free (see wino_fused2_kernel).
+        //      Accumulator register `reg` of block `blk` of the 16 positions belongs to tile row 4 * kq + reg, channel 16 * blk + l15.
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const int trow0 = em0 + wm * 16 + 4 * kq;
+        const i32x4 prow = *reinterpret_cast<const i32x4*>(a.tile_pix + trow0);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int pn = en0 + wn * 32 + 16 * blk + l15;
+            const bool nok = pn < a.Cout;
+            const float psc = (a.scale != nullptr && nok) ? a.scale[pn] : 1.f;
+            const float psh = (a.shift != nullptr && nok) ? a.shift[pn] : 0.f;
+            const unsigned chan_off = (unsigned)(a.coff + pn) * 4u, pool_off = (unsigned)(a.poff + pn) * 4u;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sm[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sm[0][j] = acc[0 + j][blk][r] + acc[4 + j][blk][r] + acc[8 + j][blk][r];
+                    sm[1][j] = acc[4 + j][blk][r] - acc[8 + j][blk][r] - acc[12 + j][blk][r];
+                }
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    o[2 * i + 0] = sm[i][0] + sm[i][1] + sm[i][2];
+                    o[2 * i + 1] = sm[i][1] - sm[i][2] - sm[i][3];
+                }
+                const int e = prow[r];
+                const int tt = trow0 + r;
+                const bool ok = nok && tt < a.T;
+                const bool y1 = ok && (e & 0x40000000) != 0, x1 = ok && e < 0;
+                const unsigned voff = ((unsigned)e & 0x3fffffffu) * (unsigned)so_x + chan_off;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool valid = k == 0 ? ok : (k == 1 ? x1 : (k == 2 ? y1 : (y1 && x1)));
+                    if (HAS_STATS) { const float m = valid ? o[k] : 0.f; s1 += m; s2 += m * m; }
+                    const float uu = o[k] * psc + psh;
+                    v[k] = uu > 0.f ? uu : uu * a.slope;
+                    if (HAS_Y) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k]), ry, (int)(valid ? voff : OOB), ((k & 1) ? so_x : 0) + ((k >> 1) ? so_y : 0), 0);
+                }
+                if (HAS_POOL) {
+                    const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mx), ryp, (int)(ok ? (unsigned)tt * (unsigned)(a.ldp * 4) + pool_off : OOB), 0, 0);
+                }
+            }
+            if (HAS_STATS) {
+                s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                if (kq == 0 && nok) {
+                    double* st = a.stats + (size_t)((em0 >> 6) % Y2_STATS_REPL) * 2 * a.Cout;
+                    atomicAdd(st + pn, (double)s1);
+                    atomicAdd(st + a.Cout + pn, (double)s2);
+                }
+            }
+        }
+        if (!more) break;
+    }
+#undef Y2_G
+}
+
 // ---- weight gradient:  dU[p][co][ci] = sum_t dM[p][t][co] * V[p][t][ci],   dM = A dz A^T (4x4 from the 2x2 gradient tile),
 //      dg = G^T dU G.  16 reductions over T tiles instead of 9 shifted reductions over 4T pixels (2.25x fewer MACs).
 struct WinoDzArgs {
@@ -1051,8 +1377,13 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
         ia.tile_pix = fused ? reinterpret_cast<int32_t*>(M) : nullptr;      // the fused path has no product tensor: the table sits behind V
         // persistent fused kernel: one workgroup per CU; the kernel launched in front of it also sets the per-XCD tile counters to
         // "every workgroup has taken its first tile"
-        const long long fused_tiles = (long long)y2_cdiv(Tc, 64) * y2_cdiv(p->Cout, 64);
-        const long long fused_grid = fused_tiles < Y2_NUM_CU ? ((fused_tiles + Y2_NUM_XCD - 1) / Y2_NUM_XCD) * Y2_NUM_XCD : Y2_NUM_CU;
+        const char* ve = getenv("Y2_WF_VARIANT");           // read per call (experiments / tests switch it at run time)
+        const int variant = ve != nullptr ? atoi(ve) : WF2_DEFAULT_VARIANT;
+        const bool small_out = (unsigned long long)p->B * p->H * p->W * (unsigned long long)(p->ldy > p->ldp ? p->ldy : p->ldp) * 4ull < 0x80000000ull;      // bytes: 2^31 is the dropped-store offset
+        const bool gen3 = fused && (variant >= 32 || p->tile == 3) && p->Cin >= 64 && small_out;      // wino_fused3_kernel (y2_conv_params.tile = 3): 32 x 64 units, two workgroups per CU
+        const int unit_m = gen3 ? F3_TM : 64, slots = gen3 ? 2 * Y2_NUM_CU : Y2_NUM_CU;
+        const long long fused_tiles = (long long)y2_cdiv(Tc, unit_m) * y2_cdiv(p->Cout, 64);
+        const long long fused_grid = fused_tiles < slots ? ((fused_tiles + Y2_NUM_XCD - 1) / Y2_NUM_XCD) * Y2_NUM_XCD : slots;
         ia.sched = fused ? reinterpret_cast<int32_t*>(M + (mbytes - 256) / sizeof(float)) : nullptr;
         ia.sched_init = (int)(fused_grid / Y2_NUM_XCD);
         if (implicit) Y2_LAUNCH("wino_tile_table_kernel", 0.0, wino_tile_table_kernel, dim3((unsigned)y2_cdiv(Tc, 256)), dim3(256), 0, s, ia.tile_pix, ia.T, ia.H, ia.W, th, tw, d_tt, d_tw, ia.sched, ia.sched_init);
@@ -1067,7 +1398,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
             fa.y = p->y != nullptr ? p->y + in_off * p->ldy : nullptr;
             fa.y_pool = p->y_pool != nullptr ? p->y_pool + (size_t)b0 * th * tw * p->ldp : nullptr;
             fa.H = p->H; fa.W = p->W; fa.Cin = p->Cin; fa.Cout = p->Cout; fa.ldy = p->ldy; fa.coff = p->coff; fa.ldp = p->ldp; fa.poff = p->poff;
-            fa.th = th; fa.tw = tw; fa.T = (int)Tc; fa.tiles_m = y2_cdiv(Tc, 64); fa.tiles_n = y2_cdiv(p->Cout, 64);
+            fa.th = th; fa.tw = tw; fa.T = (int)Tc; fa.tiles_m = y2_cdiv(Tc, unit_m); fa.tiles_n = y2_cdiv(p->Cout, 64);
             fa.v_bytes = implicit ? 0u : (unsigned)((size_t)16 * Tc * p->Cin * 4); fa.u_bytes = (unsigned)((size_t)16 * p->Cout * p->Cin * 4);
             fa.slope = p->slope; fa.d_tt = d_tt; fa.d_tw = d_tw;
             { const char* se = getenv("Y2_WF_STATIC"); fa.sched_static = (se != nullptr && atoi(se) != 0) ? 1 : 0; }
@@ -1100,10 +1431,26 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
             } while (0)
             const int out_mask = (p->y != nullptr ? 1 : 0) | (p->y_pool != nullptr ? 2 : 0) | (p->stats != nullptr ? 4 : 0);
             // second-generation instruction stream (see wino_fused2_kernel); Y2_WF_VARIANT = -1 selects the first generation, 0 / 1 / 3 a
-            // feature mask (A/B runs).  Its buffer-descriptor stores need the output tensors below 2^31 bytes.
-            const char* ve = getenv("Y2_WF_VARIANT");           // read per call (experiments / tests switch it at run time)
-            const int variant = ve != nullptr ? atoi(ve) : WF2_DEFAULT_VARIANT;
-            const bool small_out = (unsigned long long)p->B * p->H * p->W * (unsigned long long)(p->ldy > p->ldp ? p->ldy : p->ldp) * 4ull < 0x80000000ull;      // bytes: 2^31 is the dropped-store offset
+            // feature mask (A/B runs), 32 the third generation.  Their buffer-descriptor stores need the output tensors below 2^31 bytes.
+#define Y2_WF3_LAUNCH_(VAR_, OUT_)                                                                                                 \
+            do {                                                                                                                   \
+                auto kern = wino_fused3_kernel<VAR_, OUT_>;                                                                        \
+                const size_t lds = (size_t)F3_NST * F3_STAGE_FLOATS * sizeof(float) + 64;                                          \
+                static Y2LdsAttr attr;                                                                                             \
+                if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(kern))) return rc_;                                  \
+                Y2_LAUNCH(((VAR_) & 4) ? "wino_fused3_kernel[implicit]" : "wino_fused3_kernel", 2.0 * 16.0 * (double)fa.T * fa.Cout * fa.Cin, kern, dim3((unsigned)grid), dim3(256), lds, s, fa); \
+            } while (0)
+#define Y2_WF3_LAUNCH(VAR_)                                                                                                        \
+            do {                                                                                                                   \
+                if (out_mask == 1) Y2_WF3_LAUNCH_(VAR_, 1);                                                                        \
+                else if (out_mask == 2) Y2_WF3_LAUNCH_(VAR_, 2);                                                                   \
+                else if (out_mask == 3) Y2_WF3_LAUNCH_(VAR_, 3);                                                                   \
+                else if (out_mask == 5) Y2_WF3_LAUNCH_(VAR_, 5);                                                                   \
+                else Y2_WF3_LAUNCH_(VAR_, 7);                                                                                      \
+            } while (0)
+            if (gen3) { if (implicit) Y2_WF3_LAUNCH(4); else Y2_WF3_LAUNCH(0); continue; }
+#undef Y2_WF3_LAUNCH
+#undef Y2_WF3_LAUNCH_
             if (implicit) {
                 if (!small_out) return Y2_ENOSUP;
                 if (p->Cin == 32) { Y2_WF2_LAUNCH(13); continue; }      // a tile is one K slab
