@@ -123,7 +123,7 @@ typedef struct y2_conv_params {
     int32_t out_mode;    /* 0: y[b,y,x,coff+n];  1: reorg(stride 2): y[b,y/2,x/2, coff + ((y&1)*2+(x&1))*Cout + n] */
     float slope;         /* LeakyReLU negative slope; 1.0f = no activation */
     int32_t tile;        /* 0 = auto; else force a tile config (see conv_fwd.hip; benchmarking only).  With the fused Winograd algorithms:
-                          * 3 = the third-generation kernel (32-tile x 64-channel units, two workgroups per CU; Cin >= 64) */
+                          * 3 = the third-generation kernel (32-tile x 64-channel units, two workgroups per CU) */
     float* workspace;    /* optional scratch (16-B aligned) for the split-K remainder scheme, or NULL */
     int64_t workspace_bytes; /* its size; y2_conv_fwd_workspace_bytes() tells how much a problem can use */
     const float* residual; /* optional [B,Ho,Wo,Cout] (pixel stride ldr) added before the activation (model/resnet.py:59,101) */

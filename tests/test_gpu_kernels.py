@@ -187,8 +187,6 @@ def test_conv_fwd_implicit_is_bit_identical_to_fused(B, cin, cout, H, W, pad_ch,
     gen = 3: the same pair as wino_fused3_kernel (y2_conv_params.tile = 3; 32-tile x 64-channel units, two workgroups per CU, 16x16x4
     MFMAs): bit-identical to each other, and equal to the second-generation kernels up to the order of the K sum."""
     import _hip
-    if gen == 3 and cin < 64:
-        pytest.skip('the third-generation kernel needs two K slabs (Cin >= 64); below that tile = 3 runs the second-generation kernel')
     L, d = _hip.lib(), dev()
     g = torch.Generator().manual_seed(B * 131 + cin + cout + H * W)
     ldx = cin + pad_ch

@@ -450,7 +450,7 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
         if split_ok and params.H * params.W <= 19 * 19:
             prefer.append((split_algo(), 0))       # opt-in split mode: the 13x13 (19x19 at 608) layers, 25-30 % ahead of the fp32 GEMMs there
         if wino_ok and implicit_ok and (params.H * params.W >= 52 * 52 or (params.H * params.W >= 26 * 26 and params.Cout <= params.Cin)):
-            if 64 <= params.Cin <= 128:
+            if params.Cin <= 128:
                 prefer.append((3, 3))   # ... its two-workgroups-per-CU form where the K loop is short (11-13 % ahead on the 104x104 / 52x52 layers)
             prefer.append((3, 0))       # fused Winograd with the input transform in its loader: the large maps and the data gradients
         if wino_ok and params.Cin % 32 == 0 and params.H * params.W >= 26 * 26:
@@ -473,7 +473,7 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
             cands.append((2, 0))        # fused GEMM + output transform (no product tensor): pays on the 52x52 layers
         if implicit_ok:
             cands.append((3, 0))        # ... with the input transform in its loader (no transformed input in memory either)
-        if params.Cin % 32 == 0 and params.Cin >= 64:
+        if params.Cin % 32 == 0:
             cands.append((2, 3))        # the same two as 32 x 64 units, two workgroups per CU (wino_fused3_kernel): short K loops, small grids
             if implicit_ok:
                 cands.append((3, 3))

@@ -896,6 +896,7 @@ template <int VAR, int OUT>     // VAR bit 2: implicit input transform; OUT as i
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_fused3_kernel(const WinoFusedArgs a) {
     constexpr bool HAS_Y = (OUT & 1) != 0, HAS_POOL = (OUT & 2) != 0, HAS_STATS = (OUT & 4) != 0;
     constexpr bool RAWIN = (VAR & 4) != 0;
+    constexpr bool ONE = (VAR & 8) != 0;         // Cin == 32: a tile is ONE K slab, at once its first, its next-to-last and its last
     constexpr unsigned OOB = 0x80000000u, OOB_COL = 0x40000000u;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1021,7 +1022,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         offA[h] = (wm * 16 + l15) * 32 + (((4 * h + kq) ^ sw) << 2);
         offB[h] = (32 + wn * 32 + l15) * 32 + (((4 * h + kq) ^ sw) << 2);
     }
-    const int nks = a.Cin / 32;                   // host: >= 2
+    const int nks = ONE ? 1 : a.Cin / 32;         // host: >= 2 unless ONE
     int slot = 0;                                 // ring slot of the stage being consumed
     int claimed = 0;
     bool more = false;
@@ -1089,7 +1090,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // handed over through LDS across stage barriers); the last slab's fetch stream moves on to that tile: its patch rows from fetch
     // stage 6 on, its operand rows in the last two stages.
     auto slab = [&](auto ZC_, int ks) {
-        const bool pen = ks == nks - 2, last = ks == nks - 1;
+        const bool pen = ONE || ks == nks - 2, last = ONE || ks == nks - 1;      // ONE: the slab reads the claim made during the previous tile and makes the next one
         if (last) {
             tile = xcd * per_xcd + __builtin_amdgcn_readfirstlane(*sched_lds);
             more = tile < xcd_end;
@@ -1133,13 +1134,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     fetch(0, 0, 0);
     fetch(0, 1, 1);
+    if (ONE && t == 0) *sched_lds = a.sched_static ? (wg_in_xcd + wgs_per_xcd) : atomicAdd(a.sched + xcd, 1);      // the first tile's successor
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     reads(smem, 0, a0, b0);
     for (;;) {
         const int em0 = fm0, en0 = fn0;            // this tile's origin (the fetch cursor moves on during its last K slab)
-        slab(std::true_type{}, 0);                 // (never the last slab: nks >= 2) the accumulators start from the MFMA's zero operand
-        for (int ks = 1; ks < nks; ++ks) slab(std::false_type{}, ks);
+        slab(std::true_type{}, 0);                 // the accumulators start from the MFMA's zero operand
+        if (!ONE)
+            for (int ks = 1; ks < nks; ++ks) slab(std::false_type{}, ks);
         // ---- epilogue: A^T M A in registers, affine + LeakyReLU, pooling, statistics, stores - branch-free (see wino_fused2_kernel).
         //      Accumulator register `reg` of block `blk` of the 16 positions belongs to tile row 4 * kq + reg, channel 16 * blk + l15.
         typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -1380,7 +1383,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
         const char* ve = getenv("Y2_WF_VARIANT");           // read per call (experiments / tests switch it at run time)
         const int variant = ve != nullptr ? atoi(ve) : WF2_DEFAULT_VARIANT;
         const bool small_out = (unsigned long long)p->B * p->H * p->W * (unsigned long long)(p->ldy > p->ldp ? p->ldy : p->ldp) * 4ull < 0x80000000ull;      // bytes: 2^31 is the dropped-store offset
-        const bool gen3 = fused && (variant >= 32 || p->tile == 3) && p->Cin >= 64 && small_out;      // wino_fused3_kernel (y2_conv_params.tile = 3): 32 x 64 units, two workgroups per CU
+        const bool gen3 = fused && (variant >= 32 || p->tile == 3) && small_out;      // wino_fused3_kernel (y2_conv_params.tile = 3): 32 x 64 units, two workgroups per CU
         const int unit_m = gen3 ? F3_TM : 64, slots = gen3 ? 2 * Y2_NUM_CU : Y2_NUM_CU;
         const long long fused_tiles = (long long)y2_cdiv(Tc, unit_m) * y2_cdiv(p->Cout, 64);
         const long long fused_grid = fused_tiles < slots ? ((fused_tiles + Y2_NUM_XCD - 1) / Y2_NUM_XCD) * Y2_NUM_XCD : slots;
@@ -1448,7 +1451,12 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
                 else if (out_mask == 5) Y2_WF3_LAUNCH_(VAR_, 5);                                                                   \
                 else Y2_WF3_LAUNCH_(VAR_, 7);                                                                                      \
             } while (0)
-            if (gen3) { if (implicit) Y2_WF3_LAUNCH(4); else Y2_WF3_LAUNCH(0); continue; }
+            if (gen3) {
+                if (p->Cin == 32) { if (implicit) Y2_WF3_LAUNCH(12); else Y2_WF3_LAUNCH(8); }      // a tile is one K slab
+                else if (implicit) Y2_WF3_LAUNCH(4);
+                else Y2_WF3_LAUNCH(0);
+                continue;
+            }
 #undef Y2_WF3_LAUNCH
 #undef Y2_WF3_LAUNCH_
             if (implicit) {

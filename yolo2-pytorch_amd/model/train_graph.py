@@ -309,6 +309,15 @@ def _darknet_fwd(ctx, dnn, x, params, frozen):
     blocks = []
     written = []          # running statistics / step counters updated through raw pointers by y2_bn_finalize
 
+    def keep_v(h, w, cin, ldx, cout, k):
+        """Should the forward convolution leave its transformed input behind?  Only the Winograd weight gradient reads it: once that
+        layer's weight gradient is known to run the direct kernel (measured in the first backward with V at hand; the 208x208 layer),
+        the forward is free to take the algorithm that never materialises V."""
+        if k != 3:
+            return False
+        with_v, without_v = (_hip.wgrad_choice(B, h, w, cin, ldx, cout, cout, k, hv, dev) for hv in (True, False))
+        return not (with_v == 0 or (with_v is None and without_v == 0))      # (never had V and the direct kernel won anyway: stays direct)
+
     def run_block(name, mod, xin, ldx, h, w, pool, out_full=None, out_ld=0, out_off=0, out_mode=0, want_full=True, first=False):
         """raw conv + stats -> finalize -> act.  Returns (_Block, full activation or None, pooled activation or None)."""
         blk = _Block()
@@ -326,12 +335,12 @@ def _darknet_fwd(ctx, dnn, x, params, frozen):
             _hip.check(L.y2_conv0_fwd(_hip.ptr(xin), _hip.ptr(e.w), None, None, _hip.ptr(z), None, _hip.ptr(estats),
                                       B, h, w, cin, cout, cout, 0, 1.0, st), 'y2_conv0_fwd')
         elif mod in prepared:
-            blk.wino_v = _conv(L, st, xin, prepared[mod]['wp'], z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=True, u=prepared[mod]['uf'],
+            blk.wino_v = _conv(L, st, xin, prepared[mod]['wp'], z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=keep_v(h, w, cin, ldx, cout, k), u=prepared[mod]['uf'],
                                us=prepared[mod]['ufs'], us_plane=prepared[mod]['plane'])
         else:
             wp = _new(dev, e.w.numel())
             _hip.check(L.y2_pack_weight(_hip.ptr(e.w), _hip.ptr(wp), cout, cin, k, 0, st), 'y2_pack_weight')
-            blk.wino_v = _conv(L, st, xin, wp, z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=True)
+            blk.wino_v = _conv(L, st, xin, wp, z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=keep_v(h, w, cin, ldx, cout, k))
         if det and stats is not None:
             _hip.colstats_det(z, B * h * w, cout, cout, stats)
         blk.z = z
