@@ -39,13 +39,22 @@ struct WgradArgs {
     // grouped mode (Winograd wgrad: 16 independent reductions of one shape): group g uses x + g*gx, dz + g*gz, dw + g*gw
     int groups;
     long long gx, gz, gw;
+    // DZRAW (the Winograd weight gradient without a dM tensor): dz is the layer's raw output gradient [B,zH,zW,Cout] (pixel stride ldz, gz = 0)
+    // and group g = position (xi, nu) builds its operand rows dM_g[t] = (A dz_t A^T)[xi][nu] in the loader; tile_pix[t] = pixel index of tile t's
+    // first pixel | bit 30: its second row exists | bit 31: its second column exists (wino_tile_table_kernel)
+    const int32_t* tile_pix;
+    int zW;
 };
 
 // LIN: 1x1 / stride 1 / no padding (every grouped Winograd reduction and the 1x1 layers): input pixel = output pixel, so the operand
 // offsets of the next slab are the current ones + 32 rows (one v_add per DMA instruction) and the buffer's num_records supplies the
 // zeros past the last pixel.  The general form recomputes (image, y, x) -> address per piece: ~100 VALU instructions per slab next to
 // 64 MFMAs per wave (PMC: twice the VALU activity of the forward GEMM kernel at 0.69 instead of 0.81 MFMA-busy).
-template <int TI, int WAVES_I, int TJ = 128, bool LIN = false>
+// DZRAW (with LIN, 16 groups): the A operand is not DMA'd from a transformed gradient tensor; a thread owns the same (tile row, 4-channel chunk)
+// items the DMA lane owned, loads the 1, 2 or 4 gradient pixels its position needs (buffer loads, a missing pixel = out-of-range offset = 0),
+// combines them with the operations of wino_dz_kernel in the same order and ds_writes the chunk where the DMA would have put it.  wino_dz_kernel
+// and the 4x-gradient tensor dM (write + read) disappear; the gradient pixels are read 2.25x on average (36 pixel reads for 16 positions), from L2.
+template <int TI, int WAVES_I, int TJ = 128, bool LIN = false, bool DZRAW = false>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr unsigned OOB = 0x80000000u;
     constexpr int WAVES_J = 4 / WAVES_I;
@@ -144,6 +153,53 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         }
     };
 
+    // ---- DZRAW loader state
+    const int xi = grp >> 2, nu = grp & 3;                  // position of this group
+    const bool two_i = xi == 1 || xi == 2, two_j = nu == 1 || nu == 2;       // rows / columns of the 2x2 gradient tile the position reads
+    const int i_first = xi == 3 ? 1 : 0, j_first = nu == 3 ? 1 : 0;
+    const unsigned pixb = (unsigned)a.ldz * 4u;
+    int e_next[PA];                                          // decode-table entries of the thread's rows of the slab after the one being fetched
+    f32x4 dpx[PA][2][2];
+    auto dz_table = [&](int slab) {                          // (plain loads: 4 B per row per slab from an L2-resident table)
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int m = slab * KS + prow_a + RA * p;
+            e_next[p] = m < a.M ? a.tile_pix[m] : 0x3fffffff;      // no such tile: a pixel index past every image
+        }
+    };
+    auto dz_loads = [&]() {                                  // the pixels of the rows described by e_next (consumed: dz_table may run again afterwards)
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int e = e_next[p];
+            const unsigned pix = (unsigned)e & 0x3fffffffu;
+            const bool rowok = a_ok && pix != 0x3fffffffu;
+            const bool y1 = (e & 0x40000000) != 0, x1 = e < 0;
+            const unsigned base = pix * pixb + (unsigned)ca * 4u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if ((i == 1 && !two_i) || (j == 1 && !two_j)) continue;      // (uniform)
+                    const int ii = i_first + i, jj = j_first + j;                // pixel (ii, jj) of the tile
+                    const bool ok = rowok && (ii == 0 || y1) && (jj == 0 || x1);
+                    dpx[p][i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, (int)(ok ? base : OOB), (ii * a.zW + jj) * (int)pixb, 0));
+                }
+        }
+    };
+    auto dz_store = [&](int buf) {                           // dM chunk = column combination nu of the row combinations xi (wino_dz_kernel's order)
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            f32x4 sj[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j == 1 && !two_j) continue;
+                sj[j] = xi == 0 ? dpx[p][0][j] : (xi == 1 ? dpx[p][0][j] + dpx[p][1][j] : (xi == 2 ? dpx[p][0][j] - dpx[p][1][j] : -dpx[p][0][j]));
+            }
+            const f32x4 r = nu == 0 ? sj[0] : (nu == 1 ? sj[0] + sj[1] : (nu == 2 ? sj[0] - sj[1] : -sj[0]));
+            *reinterpret_cast<f32x4*>(smem + buf * STAGE + p * RA * TI + t * 4) = r;
+        }
+    };
+
     f32x16 acc[IB][JB];
 #pragma unroll
     for (int i = 0; i < IB; ++i)
@@ -192,10 +248,10 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         }
     };
     auto issue_piece = [&](int buf, int j) {
-        if (j < PA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (lds_ptr_t)(smem + buf * STAGE + wave * 256 + j * RA * TI), 16, (int)nva[j], 0, 0, 0);
+        if (j < PA) { if (!DZRAW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (lds_ptr_t)(smem + buf * STAGE + wave * 256 + j * RA * TI), 16, (int)nva[j], 0, 0, 0); }
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + buf * STAGE + KS * TI + wave * 256 + (j - PA) * RB * TJ), 16, (int)nvb[j - PA], 0, 0, 0);
     };
-    auto compute_slab_spread = [&](int buf, int nbuf) {
+    auto compute_slab_spread = [&](int buf, int nbuf, int next_slab = 0) {
         const float* sbuf = smem + buf * STAGE;
         constexpr int TOTAL = (KS / 2) * IB * JB, NPIECES = PA + PB;
         constexpr int EVERY = (TOTAL / 2) / NPIECES > 0 ? (TOTAL / 2) / NPIECES : 1;
@@ -215,6 +271,13 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
                     if (cnt % EVERY == 0 && cnt / EVERY < NPIECES) {
                         issue_piece(nbuf, cnt / EVERY);
                         __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (DZRAW) {
+                        // the loader's share of the next slab: its pixels behind the first MFMA (their table entries came in during the
+                        // previous slab), the entries of the slab after it behind the third, combination + store in the last quarter
+                        if (cnt == 0) { dz_loads(); __builtin_amdgcn_sched_barrier(0); }
+                        if (cnt == 2) { dz_table(next_slab + 1); __builtin_amdgcn_sched_barrier(0); }
+                        if (cnt == (TOTAL * 3) / 4) { dz_store(nbuf); __builtin_amdgcn_sched_barrier(0); }
                     }
                     ++cnt;
                 }
@@ -271,6 +334,24 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     // One loop per case (the case is fixed for the workgroup): with the branch INSIDE the loop the accumulators of the two paths
     // met in phi nodes and the compiler paid 64 v_accvgpr_mov per slab - one per MFMA - to bring them back to one register set
     // (PMC: VALU activity 6.3 against the forward GEMM's 3.8 even with linear offsets).
+    if (DZRAW) {
+        // first slab: table -> pixels -> operand chunk, in line; then the steady state above.  (Blocks outside the output multiply zeros.)
+        dz_table(slab_lo);
+        dz_loads();
+        dz_table(slab_lo + 1);
+        dz_store(0);
+#pragma unroll
+        for (int j = PA; j < PA + PB; ++j) issue_piece(0, j);
+        for (int ks = 0; ks < nk - 1; ++ks) {
+            plan_slab(slab_lo + ks + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute_slab_spread(ks & 1, (ks + 1) & 1, slab_lo + ks + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        compute_slab((nk - 1) & 1);
+    } else {
     issue_slab(slab_lo, 0);
     if (!all_ok) {                           // ragged tile: plain fetch, MFMAs of the outside blocks skipped
         for (int ks = 0; ks < nk - 1; ++ks) {
@@ -297,6 +378,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         compute_slab((nk - 1) & 1);
+    }
     }
 
     // ---- epilogue: lane -> column j (l31), register r -> row co = (r&3) + 8*(r>>2) + 4*half
@@ -361,8 +443,10 @@ int y2_internal_wgrad_needs_zero(long long M, int Cin, int Cout, int groups) {
     return (wgrad_splits(M, Cin, Cout, groups, nullptr) > 1 && !y2_det.on) ? 1 : 0;      // 1x1 shape of the grouped Winograd reductions
 }
 
+struct WgradRawDz { const int32_t* tile_pix; int zW, ldz; unsigned long long bytes; };      // DZRAW: the raw gradient behind `dz` (see WgradArgs)
+
 static int wgrad_impl(const float* x, const float* dz, float* dw, int B, int Hi, int Wi, int Cin, int ldx, int Cout, int ldz,
-                      int ksize, int stride, int pad, y2_stream_t stream, int groups, long long gx, long long gz, long long gw) {
+                      int ksize, int stride, int pad, y2_stream_t stream, int groups, long long gx, long long gz, long long gw, const WgradRawDz* raw = nullptr) {
     if (!x || !dz || !dw || B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0) return Y2_EINVAL;
     if (ksize < 1 || ksize > 7 || stride < 1 || pad < 0) return Y2_ENOSUP;
     if (ldx < Cin || ldz < Cout) return Y2_EINVAL;
@@ -386,6 +470,11 @@ static int wgrad_impl(const float* x, const float* dz, float* dw, int B, int Hi,
     const int slabs = y2_cdiv(M, KS);
     a.splits = wgrad_splits(M, a.taps * Cin, Cout, groups, &a.slabs_per_split);
     a.x_bytes = (unsigned)xb; a.dz_bytes = (unsigned)zb;
+    a.tile_pix = nullptr; a.zW = 0;
+    if (raw != nullptr) {
+        if (groups != 16 || raw->bytes >= 0x7fffffffull || (raw->ldz & 3) || raw->ldz < Cout) return Y2_ENOSUP;
+        a.tile_pix = raw->tile_pix; a.zW = raw->zW; a.ldz = raw->ldz; a.dz_bytes = (unsigned)raw->bytes; a.gz = 0;
+    }
     a.partial = nullptr;
     const long long wsize = (long long)Cout * a.taps * Cin;            // floats per group
     if (y2_det.on && a.splits > 1) {
@@ -403,9 +492,16 @@ static int wgrad_impl(const float* x, const float* dz, float* dw, int B, int Hi,
         if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<TI_, WI_, TJ_, LIN_>))) return rc_;     \
         Y2_LAUNCH(a.groups > 1 ? "conv_wgrad_kernel[grouped]" : "conv_wgrad_kernel", 2.0 * (double)a.M * a.Cout * a.taps * a.Cin * (a.groups > 1 ? a.groups : 1), (conv_wgrad_kernel<TI_, WI_, TJ_, LIN_>), dim3((unsigned)grid), dim3(NT), lds, s, a);                 \
     } while (0)
+#define Y2_WGRAD_LAUNCH_RAW(TI_, WI_, TJ_)                                                                                \
+    do {                                                                                                                  \
+        static Y2LdsAttr attr;                                                                                            \
+        if (const int rc_ = attr.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<TI_, WI_, TJ_, true, true>))) return rc_;     \
+        Y2_LAUNCH("conv_wgrad_kernel[grouped,dz]", 2.0 * (double)a.M * a.Cout * a.taps * a.Cin * a.groups, (conv_wgrad_kernel<TI_, WI_, TJ_, true, true>), dim3((unsigned)grid), dim3(NT), lds, s, a);                 \
+    } while (0)
 #define Y2_WGRAD_LAUNCH(TI_, WI_, TJ_)                                                                                    \
     do {                                                                                                                  \
-        if (lin) Y2_WGRAD_LAUNCH_(TI_, WI_, TJ_, true); else Y2_WGRAD_LAUNCH_(TI_, WI_, TJ_, false);                      \
+        if (raw != nullptr) Y2_WGRAD_LAUNCH_RAW(TI_, WI_, TJ_);                                                           \
+        else if (lin) Y2_WGRAD_LAUNCH_(TI_, WI_, TJ_, true); else Y2_WGRAD_LAUNCH_(TI_, WI_, TJ_, false);                 \
     } while (0)
     if (TI == 32) Y2_WGRAD_LAUNCH(32, 1, 128);
     else if (TI == 64 && TJ == 64) Y2_WGRAD_LAUNCH(64, 2, 64);
@@ -413,6 +509,7 @@ static int wgrad_impl(const float* x, const float* dz, float* dw, int B, int Hi,
     else if (TJ == 64) Y2_WGRAD_LAUNCH(128, 2, 64);
     else Y2_WGRAD_LAUNCH(128, 2, 128);
 #undef Y2_WGRAD_LAUNCH
+#undef Y2_WGRAD_LAUNCH_RAW
 #undef Y2_WGRAD_LAUNCH_
     Y2_LAUNCH_CHECK();
     if (a.partial != nullptr) {       // fixed-order sum of the K-split partials; group g's result goes to dw + g*gw
@@ -685,6 +782,15 @@ int y2_internal_wgrad_grouped(const float* x, const float* dz, float* dw, long l
                               long long gw, y2_stream_t stream) {
     if (M <= 0 || M > 0x7fffffffLL || groups < 1) return Y2_EINVAL;
     return wgrad_impl(x, dz, dw, 1, 1, (int)M, Cin, Cin, Cout, Cout, 1, 1, 0, stream, groups, gx, gz, gw);
+}
+
+// The same with the gradient operand built in the loader (DZRAW): dz_raw = the layer's output gradient [*, zW, ldz] of `dz_bytes` bytes,
+// tile_pix = wino_tile_table_kernel's table of the M tiles.  Y2_ENOSUP: the caller falls back to wino_dz_kernel + y2_internal_wgrad_grouped.
+int y2_internal_wgrad_grouped_dz(const float* v, const float* dz_raw, const int32_t* tile_pix, float* dw, long long M, int Cin, int Cout, int ldz, int zW,
+                                 unsigned long long dz_bytes, long long gx, long long gw, y2_stream_t stream) {
+    if (M <= 0 || M > 0x7fffffffLL || tile_pix == nullptr) return Y2_EINVAL;
+    const WgradRawDz raw = {tile_pix, zW, ldz, dz_bytes};
+    return wgrad_impl(v, dz_raw, dw, 1, 1, (int)M, Cin, Cin, Cout, Cout, 1, 1, 0, stream, 16, gx, 0, gw, &raw);
 }
 
 extern "C" int y2_conv_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int ldx, int Cout, int ldz,

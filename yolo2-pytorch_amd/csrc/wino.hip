@@ -1554,12 +1554,22 @@ extern "C" int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, 
     if (v_transformed == nullptr) Y2_LAUNCH("wino_input_kernel", 0.0, wino_input_kernel, dim3((unsigned)y2_cdiv(T * ia.c4n, 256)), dim3(256), 0, s, ia);
     const float* Vsrc = v_transformed != nullptr ? v_transformed : V;
 
-    WinoDzArgs za;
-    za.dz = dz; za.dm = DM; za.B = B; za.H = H; za.W = W; za.Cout = Cout; za.ldz = ldz; za.th = th; za.tw = tw; za.T = (int)T; za.c4n = Cout / 4;
-    za.d_c4 = y2_make_fastdiv((uint32_t)za.c4n); za.d_tt = ia.d_tt; za.d_tw = ia.d_tw;
-    Y2_LAUNCH("wino_dz_kernel", 0.0, wino_dz_kernel, dim3((unsigned)y2_cdiv(T * za.c4n, 256)), dim3(256), 0, s, za);
-
-    const int rc = y2_internal_wgrad_grouped(Vsrc, DM, DU, T, Cin, Cout, 16, T * Cin, T * Cout, (long long)Cout * Cin, stream);
+    // the gradient operand dM = A dz A^T: formed in the loader of the grouped reduction from the raw gradient (no wino_dz_kernel, no 4x tensor) -
+    // Y2_WGRAD_DZRAW=0: the three-step form (A/B runs, and the fallback when the raw gradient does not fit one buffer descriptor)
+    static const bool dzraw_env = getenv("Y2_WGRAD_DZRAW") == nullptr || atoi(getenv("Y2_WGRAD_DZRAW")) != 0;
+    int rc = Y2_ENOSUP;
+    if (dzraw_env && !y2_det.on && Cout <= 256) {      // measured (B=64): 104x104 64->128 0.99 -> 0.80 ms, 52x52 128->256 0.63 -> 0.56; 26x26 256->512 0.49 -> 0.52, 13x13 layers +15-20 %
+        int32_t* table = reinterpret_cast<int32_t*>(DM);                 // (the tensor's place in the workspace)
+        Y2_LAUNCH("wino_tile_table_kernel", 0.0, wino_tile_table_kernel, dim3((unsigned)y2_cdiv(T, 256)), dim3(256), 0, s, table, (int)T, H, W, th, tw, ia.d_tt, ia.d_tw, (int32_t*)nullptr, 0);
+        rc = y2_internal_wgrad_grouped_dz(Vsrc, dz, table, DU, T, Cin, Cout, ldz, W, (unsigned long long)B * H * W * ldz * 4ull, T * Cin, (long long)Cout * Cin, stream);
+    }
+    if (rc == Y2_ENOSUP) {
+        WinoDzArgs za;
+        za.dz = dz; za.dm = DM; za.B = B; za.H = H; za.W = W; za.Cout = Cout; za.ldz = ldz; za.th = th; za.tw = tw; za.T = (int)T; za.c4n = Cout / 4;
+        za.d_c4 = y2_make_fastdiv((uint32_t)za.c4n); za.d_tt = ia.d_tt; za.d_tw = ia.d_tw;
+        Y2_LAUNCH("wino_dz_kernel", 0.0, wino_dz_kernel, dim3((unsigned)y2_cdiv(T * za.c4n, 256)), dim3(256), 0, s, za);
+        rc = y2_internal_wgrad_grouped(Vsrc, DM, DU, T, Cin, Cout, 16, T * Cin, T * Cout, (long long)Cout * Cin, stream);
+    }
     if (rc != Y2_OK) return rc;
     const long long n = (long long)Cout * Cin;
     Y2_LAUNCH("wino_dw_kernel", 0.0, wino_dw_kernel, dim3((unsigned)y2_cdiv(n, 256)), dim3(256), 0, s, DU, dw_packed, Cout, Cin);
