@@ -188,6 +188,11 @@ int y2_wino_weight(const float* w_packed, float* u, int32_t Cout, int32_t Cin, y
 long long y2_wino_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t ldx,
                   int32_t Cout, int32_t ldz, const float* v_transformed, float* workspace, long long workspace_bytes, y2_stream_t stream);
+/* ... native_layout != 0: the result is written as dw[Cout][Cin][3][3] - nn.Conv2d.weight.grad's own layout (model/yolo2.py:57), no
+ * y2_unpack_weight_grad pass behind it. */
+int y2_wino_wgrad_ex(const float* x, const float* dz, float* dw, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t ldx,
+                     int32_t Cout, int32_t ldz, const float* v_transformed, float* workspace, long long workspace_bytes, int32_t native_layout,
+                     y2_stream_t stream);
 /* v_transformed (optional): the transformed input V[16][B*ceil(H/2)*ceil(W/2)][Cin] of the SAME x, as y2_conv_fwd with
  * algo = Y2_ALGO_WINOGRAD leaves it at the start of its workspace when the batch fits one chunk (V + M <= Y2_WINO_CHUNK_MB,
  * default 4096 MB): the training graph keeps that workspace alive and the weight gradient skips the input transform. */

@@ -81,6 +81,7 @@ SIGNATURES = {
     'y2_opt_clip_grads': [ctypes.POINTER(OptTensor), c_int, c_void_p, c_float, c_void_p],
     'y2_wino_wgrad_workspace_bytes': [c_int, c_int, c_int, c_int, c_int],
     'y2_wino_wgrad': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_longlong, c_void_p],
+    'y2_wino_wgrad_ex': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_void_p],
     'y2_conv_fwd_batch': [ctypes.POINTER(ConvParams), c_int, c_void_p],
     'y2_conv0_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
@@ -537,18 +538,33 @@ def wgrad_choice(B, H, W, cin, ldx, cout, ldz, k, has_v, dev):
     return _TUNE.get(('wgrad', B, H, W, cin, ldx, cout, ldz, bool(has_v), str(dev)))
 
 
-def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=False):
+def eligible_wino(cout, cin, k, ldx, ldz):
+    return wino_eligible(cout, cin, k) and not (ldx % 4) and not (ldz % 4)
+
+
+def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=False, native=None):
     """Packed weight gradient dw[cout][k*k][cin] of a stride-1 "same" convolution: y2_conv_wgrad (9 shifted reductions
     over pixels) or, for 3x3 layers where it measures faster, y2_wino_wgrad (16 reductions over 2x2 tiles).  The choice
     is timed once per problem shape and cached.  `v`: the layer's transformed input kept from a Winograd forward (see
     include/yolo2_hip.h, y2_wino_wgrad) - the weight gradient then skips its input transform.  `out`: destination (cout*k*k*cin
-    floats) instead of a fresh tensor; `zeroed`: the caller has zero-filled it (one y2_multi launch for all layers of a step)."""
+    floats) instead of a fresh tensor; `zeroed`: the caller has zero-filled it (one y2_multi launch for all layers of a step).
+    `native`: a [cout][cin][3][3] destination; when the (already measured) choice is the Winograd reduction it is written directly in
+    that layout and returned INSTEAD of the packed buffer (the caller checks `result is native`)."""
     L, st, dev = lib(), stream(), x.device
     nw = cout * cin * k * k
     choice = wgrad_choice(B, H, W, cin, ldx, cout, ldz, k, v is not None, dev)
     eligible = wino_eligible(cout, cin, k) and not (ldx % 4) and not (ldz % 4)
     key = ('wgrad', B, H, W, cin, ldx, cout, ldz, v is not None, str(dev))
     # the direct kernel accumulates split partial sums into a zeroed buffer; the Winograd path overwrites (no fill needed)
+    if native is not None and choice == 1 and eligible_wino(cout, cin, k, ldx, ldz):
+        assert native.numel() == nw and native.is_contiguous()
+        need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
+        ws = _WGRAD_WS.get(str(dev))
+        if ws is None or ws.numel() * 4 < need:
+            ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=dev)
+            _WGRAD_WS[str(dev)] = ws
+        check(L.y2_wino_wgrad_ex(ptr(x), ptr(dz), ptr(native), B, H, W, cin, ldx, cout, ldz, ptr(v), ptr(ws), ws.numel() * 4, 1, st), 'y2_wino_wgrad_ex')
+        return native
     dwp = out if out is not None else torch.empty(nw, dtype=torch.float32, device=dev)
     assert dwp.numel() >= nw and dwp.is_contiguous()
     if choice != 1 and not zeroed:

@@ -1250,7 +1250,9 @@ __global__ __launch_bounds__(256) void wino_dz_kernel(const WinoDzArgs a) {
     }
 }
 
-// dw_packed[co][tap][ci] = (G^T dU G)[tap]
+// dw_packed[co][tap][ci] = (G^T dU G)[tap];  NATIVE: dw[co][ci][tap], the nn.Conv2d.weight layout (a thread's 9 taps are 36 contiguous bytes,
+// neighbouring threads continue them: no unpack pass behind the weight gradient)
+template <bool NATIVE>
 __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ du, float* __restrict__ dw, int Cout, int Cin) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)Cout * Cin) return;
@@ -1270,10 +1272,11 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        float* dst = dw + ((size_t)co * 9 + 3 * i) * Cin + ci;
+        float* dst = NATIVE ? dw + ((size_t)co * Cin + ci) * 9 + 3 * i : dw + ((size_t)co * 9 + 3 * i) * Cin + ci;
+        const size_t step = NATIVE ? 1 : (size_t)Cin;
         dst[0] = s[i][0] + 0.5f * (s[i][1] + s[i][2]);
-        dst[Cin] = 0.5f * (s[i][1] - s[i][2]);
-        dst[2 * (size_t)Cin] = 0.5f * (s[i][1] + s[i][2]) + s[i][3];
+        dst[step] = 0.5f * (s[i][1] - s[i][2]);
+        dst[2 * step] = 0.5f * (s[i][1] + s[i][2]) + s[i][3];
     }
 }
 
@@ -1528,6 +1531,12 @@ extern "C" long long y2_wino_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t
 
 extern "C" int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t ldx,
                              int32_t Cout, int32_t ldz, const float* v_transformed, float* workspace, long long workspace_bytes, y2_stream_t stream) {
+    return y2_wino_wgrad_ex(x, dz, dw_packed, B, H, W, Cin, ldx, Cout, ldz, v_transformed, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int y2_wino_wgrad_ex(const float* x, const float* dz, float* dw_packed, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t ldx,
+                                int32_t Cout, int32_t ldz, const float* v_transformed, float* workspace, long long workspace_bytes, int32_t native_layout,
+                                y2_stream_t stream) {
     if ((x == nullptr && v_transformed == nullptr) || dz == nullptr || dw_packed == nullptr || workspace == nullptr) return Y2_EINVAL;
     if (v_transformed != nullptr && !y2_aligned16(v_transformed)) return Y2_EALIGN;
     if (x == nullptr) x = v_transformed;      // only the alignment checks below look at it
@@ -1572,7 +1581,8 @@ extern "C" int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, 
     }
     if (rc != Y2_OK) return rc;
     const long long n = (long long)Cout * Cin;
-    Y2_LAUNCH("wino_dw_kernel", 0.0, wino_dw_kernel, dim3((unsigned)y2_cdiv(n, 256)), dim3(256), 0, s, DU, dw_packed, Cout, Cin);
+    if (native_layout != 0) Y2_LAUNCH("wino_dw_kernel", 0.0, wino_dw_kernel<true>, dim3((unsigned)y2_cdiv(n, 256)), dim3(256), 0, s, DU, dw_packed, Cout, Cin);
+    else Y2_LAUNCH("wino_dw_kernel", 0.0, wino_dw_kernel<false>, dim3((unsigned)y2_cdiv(n, 256)), dim3(256), 0, s, DU, dw_packed, Cout, Cin);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

@@ -574,13 +574,16 @@ def _darknet_bwd(ctx, dout):
                 _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw4), cop, 4, k, st_w), 'y2_unpack_weight_grad')
                 return dw4[:e.cout_r, :cin].contiguous()
             tgt, final, zeroed = wg[i]
-            _hip.conv_wgrad(blk.x, dz, B, h, w, cin, blk.ldx, cop, cop, k, v=blk.wino_v, out=tgt, zeroed=zeroed)     # direct or Winograd, by measurement
+            dw = None
+            if k == 3:
+                dw = dest(weight) if (cop == cout and not e.padded) else _new(dev, cop, cin, k, k)
+            got = _hip.conv_wgrad(blk.x, dz, B, h, w, cin, blk.ldx, cop, cop, k, v=blk.wino_v, out=tgt, zeroed=zeroed, native=dw)     # direct or Winograd, by measurement
             if final:
                 return tgt.view(cout, cin, 1, 1)
             if k == 1:
                 return real(tgt.view(cop, cin, 1, 1))
-            dw = dest(weight) if (cop == cout and not e.padded) else _new(dev, cop, cin, k, k)
-            _hip.check(L.y2_unpack_weight_grad(_hip.ptr(tgt), _hip.ptr(dw), cop, cin, k, st_w), 'y2_unpack_weight_grad')
+            if got is not dw:       # packed [cout][tap][cin] (the direct kernel's GEMM output): one more pass into the gradient's layout
+                _hip.check(L.y2_unpack_weight_grad(_hip.ptr(tgt), _hip.ptr(dw), cop, cin, k, st_w), 'y2_unpack_weight_grad')
             return real(dw)
 
         if side is not None:
