@@ -178,6 +178,8 @@ def test_conv_fwd_winograd_matches_fp64_reference(B, cin, cout, H, W, tile, pool
     (3, 32, 64, 30, 26, 0, True),         # Cin = 32: a tile is a single K slab (the 208x208 layer of Darknet-19), pooled output
     (2, 32, 40, 13, 9, 32, False),        # ... ragged map, channel window, Cout not a multiple of 64
     (33, 128, 200, 30, 26, 0, True),      # 6435 tiles x 4 channel tiles on 512 workgroup slots (gen 3), last channel tile ragged
+    (3, 64, 32, 18, 22, 0, False),        # Cout = 32 (the data gradient of the 208x208 layer): gen 3 idles the waves without channels
+    (2, 128, 20, 9, 7, 4, False),         # ... Cout < 32, odd map, channel window
 ])
 @pytest.mark.parametrize('gen', [0, 3])
 def test_conv_fwd_implicit_is_bit_identical_to_fused(B, cin, cout, H, W, pad_ch, pool, gen):

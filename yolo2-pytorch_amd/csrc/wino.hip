@@ -897,6 +897,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr bool HAS_Y = (OUT & 1) != 0, HAS_POOL = (OUT & 2) != 0, HAS_STATS = (OUT & 4) != 0;
     constexpr bool RAWIN = (VAR & 4) != 0;
     constexpr bool ONE = (VAR & 8) != 0;         // Cin == 32: a tile is ONE K slab, at once its first, its next-to-last and its last
+    constexpr bool HALF = (VAR & 16) != 0;       // Cout <= 32 (the data gradient of the 208x208 layer): channels 32..63 of every unit do not exist - their B rows
+                                                 // are not fetched and the waves that would multiply zeros (wn = 1) only load, transform and keep the barriers:
+                                                 // their SIMDs' matrix pipes belong to the other workgroup's working waves
     constexpr unsigned OOB = 0x80000000u, OOB_COL = 0x40000000u;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -963,7 +966,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("" : "+s"(p));
         float* sa = smem + slot * F3_STAGE_FLOATS + pp * F3_POS_FLOATS + wave * (8 * 32);
         if (w == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)sa, 16, (int)a_off, (int)((unsigned)p * v_plane + (unsigned)kslab * 128u), 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(sa + w * 32 * 32), 16, (int)b_off[w - 1], (int)((unsigned)p * u_plane + (unsigned)kslab * 128u), 0, 0);
+        else if (w == 1 || !HALF) __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(sa + w * 32 * 32), 16, (int)b_off[w - 1], (int)((unsigned)p * u_plane + (unsigned)kslab * 128u), 0, 0);
     };
     auto fetch = [&](int kslab, int g, int slot) {
 #pragma unroll
@@ -1047,19 +1050,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // fk: K slab of fetch stage i+2; fkn: the K slab behind it (RAWIN re-loads); DRAIN: the workgroup's last two stages fetch nothing
     // (no LDS-DMA may be in flight when it ends).  The order inside a half is the compiler's: pinning it with scheduling barriers
     // (pieces and loader steps behind individual MFMAs, as in wino_fused2_kernel) measured 3-5 % slower and spilled accumulators.
-    auto stage = [&](auto G_, auto ZC_, auto DRAIN_, int fk, int fkn) {
+    auto stage = [&](auto G_, auto ZC_, auto DRAIN_, auto IDLE_, int fk, int fkn) {
         constexpr int G = decltype(G_)::value;
         constexpr bool zc = decltype(ZC_)::value;
         constexpr bool drain = decltype(DRAIN_)::value;
+        constexpr bool idle = decltype(IDLE_)::value;      // a wave without channels (HALF): no fragments, no MFMAs
         constexpr int FG = (G + 2) & 7;
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         f32x4 a1[2], b1[2][2];
-        if (RAWIN) reads(smem + slot * F3_STAGE_FLOATS, 0, a0, b0);      // (the loader's registers: no fragments carried across its work)
-        reads(smem + slot * F3_STAGE_FLOATS, 1, a1, b1);
+        if (!idle) {
+            if (RAWIN) reads(smem + slot * F3_STAGE_FLOATS, 0, a0, b0);      // (the loader's registers: no fragments carried across its work)
+            reads(smem + slot * F3_STAGE_FLOATS, 1, a1, b1);
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) {
-            const int s = idx >> 2, pp = (idx >> 1) & 1, blk = idx & 1;
-            acc[2 * G + pp][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[pp][s], b0[pp][blk][s], (zc && s == 0) ? zero4 : acc[2 * G + pp][blk], 0, 0, 0);
+            for (int idx = 0; idx < 16; ++idx) {
+                const int s = idx >> 2, pp = (idx >> 1) & 1, blk = idx & 1;
+                acc[2 * G + pp][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[pp][s], b0[pp][blk][s], (zc && s == 0) ? zero4 : acc[2 * G + pp][blk], 0, 0, 0);
+            }
         }
         if (!RAWIN) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1078,18 +1084,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
         if (!drain) fetch(fk, FG, fslot);
         if (RAWIN) raw_fetch(std::integral_constant<int, FG>{}, DRAIN_, fk, fkn, fslot);
-        else reads(smem + slot * F3_STAGE_FLOATS, 0, a0, b0);
+        else if (!idle) reads(smem + slot * F3_STAGE_FLOATS, 0, a0, b0);
+        if (!idle) {
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) {
-            const int s = idx >> 2, pp = (idx >> 1) & 1, blk = idx & 1;
-            acc[2 * G + pp][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[pp][s], b1[pp][blk][s], acc[2 * G + pp][blk], 0, 0, 0);
+            for (int idx = 0; idx < 16; ++idx) {
+                const int s = idx >> 2, pp = (idx >> 1) & 1, blk = idx & 1;
+                acc[2 * G + pp][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[pp][s], b1[pp][blk][s], acc[2 * G + pp][blk], 0, 0, 0);
+            }
         }
     };
 #define Y2_G(n) std::integral_constant<int, n>{}
     // the 8 stages of K slab ks.  The slab before the last one claims the workgroup's next tile from the XCD's counter (thread 0;
     // handed over through LDS across stage barriers); the last slab's fetch stream moves on to that tile: its patch rows from fetch
     // stage 6 on, its operand rows in the last two stages.
-    auto slab = [&](auto ZC_, int ks) {
+    auto slab = [&](auto ZC_, auto IDLE_, int ks) {
         const bool pen = ONE || ks == nks - 2, last = ONE || ks == nks - 1;      // ONE: the slab reads the claim made during the previous tile and makes the next one
         if (last) {
             tile = xcd * per_xcd + __builtin_amdgcn_readfirstlane(*sched_lds);
@@ -1097,22 +1105,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         const int fk2 = last ? 0 : ks + 1;
         using NO = std::false_type;
-        stage(Y2_G(0), ZC_, NO{}, ks, fk2);
-        stage(Y2_G(1), ZC_, NO{}, ks, fk2);
-        stage(Y2_G(2), ZC_, NO{}, ks, fk2);
+        stage(Y2_G(0), ZC_, NO{}, IDLE_, ks, fk2);
+        stage(Y2_G(1), ZC_, NO{}, IDLE_, ks, fk2);
+        stage(Y2_G(2), ZC_, NO{}, IDLE_, ks, fk2);
         if (RAWIN && last) place_a(tile, more);      // (row 3 of this tile's last K slab has just been requested: the patch offsets move on)
-        stage(Y2_G(3), ZC_, NO{}, ks, fk2);
-        stage(Y2_G(4), ZC_, NO{}, ks, fk2);
+        stage(Y2_G(3), ZC_, NO{}, IDLE_, ks, fk2);
+        stage(Y2_G(4), ZC_, NO{}, IDLE_, ks, fk2);
         if (pen && t == 0) claimed = a.sched_static ? (tile - xcd * per_xcd + wgs_per_xcd) : atomicAdd(a.sched + xcd, 1);
-        stage(Y2_G(5), ZC_, NO{}, ks, fk2);
+        stage(Y2_G(5), ZC_, NO{}, IDLE_, ks, fk2);
         if (pen && t == 0) *sched_lds = claimed;
         if (last && !more) {
-            stage(Y2_G(6), ZC_, std::true_type{}, fk2, fk2);
-            stage(Y2_G(7), ZC_, std::true_type{}, fk2, fk2);
+            stage(Y2_G(6), ZC_, std::true_type{}, IDLE_, fk2, fk2);
+            stage(Y2_G(7), ZC_, std::true_type{}, IDLE_, fk2, fk2);
         } else {
             if (last) { if (!RAWIN) place_a(tile, true); place_b(tile); }
-            stage(Y2_G(6), ZC_, NO{}, fk2, fk2);
-            stage(Y2_G(7), ZC_, NO{}, fk2, fk2);
+            stage(Y2_G(6), ZC_, NO{}, IDLE_, fk2, fk2);
+            stage(Y2_G(7), ZC_, NO{}, IDLE_, fk2, fk2);
         }
     };
 
@@ -1138,11 +1146,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     reads(smem, 0, a0, b0);
+    auto run = [&](auto IDLE_) {
     for (;;) {
         const int em0 = fm0, en0 = fn0;            // this tile's origin (the fetch cursor moves on during its last K slab)
-        slab(std::true_type{}, 0);                 // the accumulators start from the MFMA's zero operand
+        slab(std::true_type{}, IDLE_, 0);                 // the accumulators start from the MFMA's zero operand
         if (!ONE)
-            for (int ks = 1; ks < nks; ++ks) slab(std::false_type{}, ks);
+            for (int ks = 1; ks < nks; ++ks) slab(std::false_type{}, IDLE_, ks);
+        if (!decltype(IDLE_)::value) {
         // ---- epilogue: A^T M A in registers, affine + LeakyReLU, pooling, statistics, stores - branch-free (see wino_fused2_kernel).
         //      Accumulator register `reg` of block `blk` of the 16 positions belongs to tile row 4 * kq + reg, channel 16 * blk + l15.
         typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -1199,8 +1209,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
+        }
         if (!more) break;
     }
+    };
+    if (HALF && wn == 1) run(std::true_type{});
+    else run(std::false_type{});
 #undef Y2_G
 }
 
@@ -1456,6 +1470,7 @@ int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* w
             } while (0)
             if (gen3) {
                 if (p->Cin == 32) { if (implicit) Y2_WF3_LAUNCH(12); else Y2_WF3_LAUNCH(8); }      // a tile is one K slab
+                else if (implicit && p->Cout <= 32) Y2_WF3_LAUNCH(20);                              // half-empty units: the waves without channels idle
                 else if (implicit) Y2_WF3_LAUNCH(4);
                 else Y2_WF3_LAUNCH(0);
                 continue;
