@@ -388,3 +388,32 @@ def test_gradient_with_respect_to_the_image(arch, training):
     for k, v in sd64.items():
         if v.requires_grad:
             assert rel(ours[k].grad, v.grad) <= max(2e-3, 3 * rel(sd32[k].grad, v.grad)), k
+
+
+@pytest.mark.parametrize('cout,cin', [(40, 12), (100, 36), (64, 32), (256, 128), (33 * 4, 9 * 4)])
+def test_multi_tensor_weight_preparation_equals_the_single_tensor_kernels(cout, cin):
+    """y2_prep_weights (one launch for every layer's GEMM operands: packed, rotated / transposed for the data gradient, and the
+    Winograd filter transforms of both) against y2_pack_weight + y2_wino_weight: bit-identical, for channel counts that do not fill
+    its 32 x 8 staging tiles."""
+    import _hip
+    L, d = _hip.lib(), dev()
+    g = torch.Generator().manual_seed(cout * 7 + cin)
+    w3 = torch.randn(cout, cin, 3, 3, generator=g).to(d)
+    w1 = torch.randn(cout, cin, 1, 1, generator=g).to(d)
+    want = {}
+    for name, w, k in (('3', w3, 3), ('1', w1, 1)):
+        for mode in (0, 1):
+            t = torch.empty(w.numel(), device=d)
+            _hip.check(L.y2_pack_weight(_hip.ptr(w), _hip.ptr(t), cout, cin, k, mode, _hip.stream()), 'pack')
+            want[(name, mode)] = t
+    want[('3', 2)] = _hip.wino_weight(want[('3', 0)], cout, cin)
+    want[('3', 3)] = _hip.wino_weight(want[('3', 1)], cin, cout)
+    specs = [('3', 0, w3, 3, 1), ('3', 1, w3, 3, 1), ('1', 0, w1, 1, 1), ('1', 1, w1, 1, 1), ('3', 2, w3, 3, 16.0 / 9), ('3', 3, w3, 3, 16.0 / 9)]
+    outs = [torch.full((int(round(w.numel() * f)),), float('nan'), device=d) for _, _, w, _, f in specs]
+    table = (_hip.PrepItem * len(specs))()
+    for i, (name, mode, w, k, f) in enumerate(specs):
+        table[i].src, table[i].dst, table[i].Cout, table[i].Cin, table[i].ksize, table[i].mode = w.data_ptr(), outs[i].data_ptr(), cout, cin, k, mode
+    _hip.check(L.y2_prep_weights(table, len(specs), _hip.stream()), 'y2_prep_weights')
+    torch.cuda.synchronize()
+    for (name, mode, w, k, f), got in zip(specs, outs):
+        assert torch.equal(got, want[(name, mode)]), (name, mode)

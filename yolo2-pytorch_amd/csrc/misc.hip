@@ -80,6 +80,47 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepTable tb) {
     const bool dg = q.mode == Y2_PREP_WINO_DGRAD;
     const int N = dg ? Cin : Cout, K = dg ? Cout : Cin;
     const long long total = (long long)N * K;
+    if (dg) {
+        // the data-gradient operand is the transpose (n = ci, k = co): with one thread per (ci, co) pair and co fastest the stores are
+        // coalesced, but every lane's 36-byte load sits Cin * 36 bytes from its neighbour's (28 % of every line used; this item type was
+        // half of the kernel's time).  So a workgroup stages a 32 co x 8 ci tile through LDS: rows of 288 contiguous bytes in, pairs out.
+        __shared__ float tile[32][73];                  // (73: the 32 rows of a column read fall into 32 different banks)
+        const int t = threadIdx.x;
+        const int tiles_k = (Cout + 31) / 32, tiles_n = (Cin + 7) / 8;
+        for (int tl = blk; tl < tiles_k * tiles_n; tl += nblk) {
+            const int c0 = (tl % tiles_k) * 32, n0 = (tl / tiles_k) * 8;
+            const int nn = min(8, Cin - n0);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int e = t + 256 * j, row = e / 72, col = e % 72;
+                if (c0 + row < Cout && col < nn * 9) tile[row][col] = w[((long long)(c0 + row) * Cin + n0) * 9 + col];
+            }
+            __syncthreads();
+            const int k = c0 + (t & 31), n = n0 + (t >> 5);
+            if (k >= Cout || n >= Cin) continue;
+            float g[3][3];
+#pragma unroll
+            for (int x = 0; x < 9; ++x) g[x / 3][x % 3] = tile[t & 31][(t >> 5) * 9 + 8 - x];
+            float s[4][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                s[0][j] = g[0][j];
+                s[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+                s[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+                s[3][j] = g[2][j];
+            }
+            float* d = dst + (long long)n * K + k;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                d[(4 * r + 0) * total] = s[r][0];
+                d[(4 * r + 1) * total] = 0.5f * (s[r][0] + s[r][1] + s[r][2]);
+                d[(4 * r + 2) * total] = 0.5f * (s[r][0] - s[r][1] + s[r][2]);
+                d[(4 * r + 3) * total] = s[r][2];
+            }
+        }
+        return;
+    }
     for (long long i = (long long)blk * 256 + threadIdx.x; i < total; i += (long long)nblk * 256) {
         const int k = (int)(i % K);
         const int n = (int)(i / K);
