@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""A/B of the fused Winograd kernels (Y2_WF_VARIANT: -1 = first generation, 0..3 = feature mask of wino_fused2_kernel, 100 =
-Y2_ALGO_WINOGRAD_IMPLICIT: the same kernel with the input transform in its loader, no wino_input_kernel) on the
+"""A/B of the fused Winograd kernels (Y2_WF_VARIANT: -1 = first generation, 0..3 = feature mask of wino_fused2_kernel, 32 = the
+third generation (wino_fused3_kernel: two workgroups per CU); 100 / 136 = Y2_ALGO_WINOGRAD_IMPLICIT on the second / third generation:
+the same kernels with the input transform in their loader, no wino_input_kernel; 200 = three-kernel Winograd, 300 = direct) on the
 Darknet-19 layer shapes that run it: time per launch (HIP events, best of 3 x reps) and bit-exactness against variant -1.
 
     python tools/wf_bench.py [--batch 32] [--variants -1,0,1,...] [--reps 10] [--pool] [--stats]
