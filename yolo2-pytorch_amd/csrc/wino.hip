@@ -1036,6 +1036,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // stage ago), the barrier publishes everybody's - and says that nobody reads ring slot i-1 any more - , the pieces of stage
     // i+2 go out into that slot, the first-half fragments of stage i+1 are read, and the second half's MFMAs cover their latency.
     f32x4 a0[2], b0[2][2];                      // first-half fragments of the stage about to run [position][block]
+    // (-DY2_F3EXP=1|2|3 via Y2_EXTRA_FLAGS of build.sh compiles the LDS-DMA pieces / the fragment reads out - wrong results, timing only: what
+    //  DESIGN.md 3.5 prices them with)
     auto reads = [&](const float* sb, int h, f32x4* av, f32x4 (*bv)[2]) {
 #if defined(Y2_F3EXP) && (Y2_F3EXP & 2)
         if (a.T < 0)
