@@ -188,8 +188,10 @@ int y2_wino_weight(const float* w_packed, float* u, int32_t Cout, int32_t Cin, y
 long long y2_wino_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t ldx,
                   int32_t Cout, int32_t ldz, const float* v_transformed, float* workspace, long long workspace_bytes, y2_stream_t stream);
-/* ... native_layout != 0: the result is written as dw[Cout][Cin][3][3] - nn.Conv2d.weight.grad's own layout (model/yolo2.py:57), no
- * y2_unpack_weight_grad pass behind it. */
+/* ... native_layout bit 0: the result is written as dw[Cout][Cin][3][3] - nn.Conv2d.weight.grad's own layout (model/yolo2.py:57), no
+ * y2_unpack_weight_grad pass behind it.  Bit 1: Winograd F(3x3, 4x4) - 36 reductions over 4x4 gradient tiles (1.78x fewer multiply-adds than
+ * the 2x2 form on even maps); needs x (not v_transformed); its larger transform constants cost accuracy (1.2-1.4e-5 x rms of the gradient in
+ * fp32 against 2.7e-6): for weight gradients only. */
 int y2_wino_wgrad_ex(const float* x, const float* dz, float* dw, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t ldx,
                      int32_t Cout, int32_t ldz, const float* v_transformed, float* workspace, long long workspace_bytes, int32_t native_layout,
                      y2_stream_t stream);

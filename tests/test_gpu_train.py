@@ -95,6 +95,16 @@ def test_winograd_wgrad_and_dgrad(B, cin, cout, H, W):
     dwp2 = torch.full((w.numel(),), -3.0, device=d)
     _hip.check(L.y2_wino_wgrad(None, _hip.ptr(dzd), _hip.ptr(dwp2), B, H, W, cin, cin, cout, cout, _hip.ptr(wsf), _hip.ptr(ws), ws.numel() * 4, _hip.stream()), 'wino_wgrad(v)')
     assert torch.equal(dwp2, dwp) or rel(dwp2, dwp.cpu()) <= 1e-5      # same arithmetic; split partial sums are added atomically
+    # the 4x4-tile form (Winograd F(3x3, 4x4): larger transform constants - 1.2-1.4e-5 x rms in fp32), packed and native layouts
+    for flags in (2, 3):
+        dw6 = torch.full((w.numel(),), 5.0, device=d)
+        _hip.check(L.y2_wino_wgrad_ex(_hip.ptr(xd), _hip.ptr(dzd), _hip.ptr(dw6), B, H, W, cin, cin, cout, cout, None, _hip.ptr(ws), ws.numel() * 4, flags, _hip.stream()), 'wino6')
+        if flags == 2:
+            t6 = torch.empty(cout, cin, 3, 3, device=d)
+            _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dw6), _hip.ptr(t6), cout, cin, 3, _hip.stream()), 'unpack')
+        else:
+            t6 = dw6.view(cout, cin, 3, 3)
+        assert rel(t6, w.grad) <= 4 * TOL, (flags, rel(t6, w.grad))
     wd = torch.empty(w.numel(), device=d)
     _hip.check(L.y2_pack_weight(_hip.ptr(wdev), _hip.ptr(wd), cout, cin, 3, 1, _hip.stream()), 'pack1')
     u = _hip.wino_weight(wd, cin, cout)

@@ -54,9 +54,11 @@ def main():
 
         def wino():
             _hip.check(L.y2_wino_wgrad(_hip.ptr(x), _hip.ptr(dz), _hip.ptr(dw), B, H, W, cin, cin, cout, cout, None, _hip.ptr(ws), ws.numel() * 4, st), 'wino_wgrad')
-        td, tw = timeit(direct, args.reps), timeit(wino, args.reps)
-        print('%-6s B=%d %3dx%-3d %4d->%-4d direct %7.3f ms %6.1f TF/s | winograd %7.3f ms %6.1f TF/s (equiv)  x%.2f' %
-              (name, B, H, W, cin, cout, td, flops / td / 1e9, tw, flops / tw / 1e9, td / tw), flush=True)
+        def wino6():
+            _hip.check(L.y2_wino_wgrad_ex(_hip.ptr(x), _hip.ptr(dz), _hip.ptr(dw), B, H, W, cin, cin, cout, cout, None, _hip.ptr(ws), ws.numel() * 4, 2, st), 'wino6_wgrad')
+        td, tw, t6 = timeit(direct, args.reps), timeit(wino, args.reps), timeit(wino6, args.reps)
+        print('%-6s B=%d %3dx%-3d %4d->%-4d direct %7.3f ms | F(3,2) %7.3f ms (x + dz transformed here) | F(3,4) %7.3f ms' %
+              (name, B, H, W, cin, cout, td, tw, t6), flush=True)
 
 
 if __name__ == '__main__':

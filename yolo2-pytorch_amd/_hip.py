@@ -335,6 +335,7 @@ if TUNE_CACHE and os.path.exists(TUNE_CACHE):
 
 
 WINOGRAD = os.environ.get('Y2_WINOGRAD', '1') != '0'     # 0: never pick the Winograd F(2x2,3x3) algorithm
+WGRAD_F34 = os.environ.get('Y2_WGRAD_F34', '1') != '0'     # offer the 4x4-tile Winograd weight gradient (F(3x3, 4x4)) to the per-layer measurement
 FORCE_ALGO = os.environ.get('Y2_FORCE_ALGO') or None     # 'direct' | 'winograd' | 'fused' | 'implicit' | 'fused3' | 'implicit3' | 'split': no autotune, that algorithm wherever the library accepts it
 if FORCE_ALGO not in (None, 'direct', 'winograd', 'fused', 'implicit', 'fused3', 'implicit3', 'split'):
     raise ValueError('Y2_FORCE_ALGO must be direct, winograd, fused, implicit, fused3, implicit3 or split (got %r)' % FORCE_ALGO)      # ('split': the algorithm of the current split mode; '...3': the two-workgroups-per-CU kernel)
@@ -530,7 +531,8 @@ _WGRAD_WS = {}
 
 def wgrad_choice(B, H, W, cin, ldx, cout, ldz, k, has_v, dev):
     """Which kernel conv_wgrad will run for this problem: 0 = y2_conv_wgrad (accumulates into a ZEROED buffer), 1 = y2_wino_wgrad
-    (overwrites), None = eligible for both and not measured yet (conv_wgrad will time them and zero the buffer itself)."""
+    (2x2 gradient tiles; overwrites), 2 = its 4x4-tile form (Winograd F(3x3, 4x4): fewer multiply-adds, never reads the forward's
+    transformed input; overwrites), None = eligible for all and not measured yet (conv_wgrad will time them and zero the buffer itself)."""
     if not (wino_eligible(cout, cin, k) and not (ldx % 4) and not (ldz % 4)):
         return 0
     if DETERMINISTIC or not AUTOTUNE:
@@ -556,18 +558,19 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
     eligible = wino_eligible(cout, cin, k) and not (ldx % 4) and not (ldz % 4)
     key = ('wgrad', B, H, W, cin, ldx, cout, ldz, v is not None, str(dev))
     # the direct kernel accumulates split partial sums into a zeroed buffer; the Winograd path overwrites (no fill needed)
-    if native is not None and choice == 1 and eligible_wino(cout, cin, k, ldx, ldz):
+    if native is not None and choice in (1, 2) and eligible_wino(cout, cin, k, ldx, ldz):
         assert native.numel() == nw and native.is_contiguous()
         need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
         ws = _WGRAD_WS.get(str(dev))
         if ws is None or ws.numel() * 4 < need:
             ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=dev)
             _WGRAD_WS[str(dev)] = ws
-        check(L.y2_wino_wgrad_ex(ptr(x), ptr(dz), ptr(native), B, H, W, cin, ldx, cout, ldz, ptr(v), ptr(ws), ws.numel() * 4, 1, st), 'y2_wino_wgrad_ex')
+        check(L.y2_wino_wgrad_ex(ptr(x), ptr(dz), ptr(native), B, H, W, cin, ldx, cout, ldz, ptr(v) if choice == 1 else None, ptr(ws), ws.numel() * 4,
+                                 1 if choice == 1 else 3, st), 'y2_wino_wgrad_ex')
         return native
     dwp = out if out is not None else torch.empty(nw, dtype=torch.float32, device=dev)
     assert dwp.numel() >= nw and dwp.is_contiguous()
-    if choice != 1 and not zeroed:
+    if choice not in (1, 2) and not zeroed:
         dwp.zero_()
 
     def direct():
@@ -583,12 +586,14 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
 
     def wino():
         check(L.y2_wino_wgrad(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, ptr(v), ptr(ws), ws.numel() * 4, st), 'y2_wino_wgrad')
+    def wino6():
+        check(L.y2_wino_wgrad_ex(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, None, ptr(ws), ws.numel() * 4, 2, st), 'y2_wino_wgrad_ex')
     if choice is None:
         if torch.cuda.is_current_stream_capturing():
             choice = 1 if cin >= 128 else 0
         else:
             times = []
-            for fn in (direct, wino):
+            for fn in (direct, wino) + ((wino6,) if WGRAD_F34 else ()):
                 fn()
                 t = float('inf')
                 for _ in range(2):
@@ -600,11 +605,11 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
                     e1.synchronize()
                     t = min(t, e0.elapsed_time(e1))
                 times.append(t)
-            choice = 1 if times[1] < times[0] else 0
+            choice = times.index(min(times))
             _TUNE[key] = choice
             _tune_save()
             dwp.zero_()          # the timing launches of the direct kernel accumulated into dwp
-    (wino if choice == 1 else direct)()
+    (direct, wino, wino6)[choice]()
     return dwp
 
 

@@ -316,7 +316,8 @@ def _darknet_fwd(ctx, dnn, x, params, frozen):
         if k != 3:
             return False
         with_v, without_v = (_hip.wgrad_choice(B, h, w, cin, ldx, cout, cout, k, hv, dev) for hv in (True, False))
-        return not (with_v == 0 or (with_v is None and without_v == 0))      # (never had V and the direct kernel won anyway: stays direct)
+        # (0 = direct kernel, 2 = the 4x4-tile Winograd form: neither reads V; never had V and one of them won anyway: stays that way)
+        return not (with_v in (0, 2) or (with_v is None and without_v in (0, 2)))
 
     def run_block(name, mod, xin, ldx, h, w, pool, out_full=None, out_ld=0, out_off=0, out_mode=0, want_full=True, first=False):
         """raw conv + stats -> finalize -> act.  Returns (_Block, full activation or None, pooled activation or None)."""
