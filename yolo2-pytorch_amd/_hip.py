@@ -536,6 +536,8 @@ def wgrad_choice(B, H, W, cin, ldx, cout, ldz, k, has_v, dev):
     if not (wino_eligible(cout, cin, k) and not (ldx % 4) and not (ldz % 4)):
         return 0
     if DETERMINISTIC or not AUTOTUNE:
+        if not DETERMINISTIC and WGRAD_F34 and cin >= 128 and H * W <= 19 * 19:
+            return 2                    # what the measurements converge to on the 13x13 (19x19) layers
         return 1 if cin >= 128 else 0
     return _TUNE.get(('wgrad', B, H, W, cin, ldx, cout, ldz, bool(has_v), str(dev)))
 
