@@ -151,6 +151,10 @@ typedef struct y2_conv_params {
                                       accuracy at 2.67x the fp32-MFMA rate.  w = y2_split_bf16x3 of the y2_wino_weight output; Cin % 32 == 0.
                                       Opt-in precision mode of the Python layer (Y2_SPLIT_BF16=1); never chosen by the library itself. */
 
+#define Y2_ALGO_WINOGRAD_F43 6     /* three kernels like WINOGRAD, on 4x4 output tiles: Winograd F(4x4,3x3), 36 GEMMs, 2.25x fewer multiply-adds than
+                                      F(2x2,3x3) on even maps; w = y2_wino6_weight output [36][Cout][Cin]; y only (no pool / statistics).  Error 8-9e-6 x rms
+                                      per layer in an fp32 model (F(2x2,3x3): 1.3e-6): meant for GRADIENTS (the training step's data gradients), not
+                                      for the inference path, whose tolerance it would use up */
 #define Y2_ALGO_WINOGRAD_SPLIT_F16 5 /* as SPLIT with fp16 plane PAIRS (hi = fp16(s x), lo = fp16(s x - hi): 2 x 11 bits + the residual's sign) and three
                                       products (hi x hi, hi x lo, lo x hi): half the matrix instructions and 4 instead of 6 operand bytes of SPLIT.
                                       fp16 has 5 exponent bits: the operands carry fixed power-of-two scales (V x 2^-4, w x 2^8 - pass 256 to
@@ -181,6 +185,8 @@ int y2_gemm_split(const void* A, const void* B, float* C, long long M, int32_t N
  * WINOGRAD algorithm the reference's nn.Conv2d (model/yolo2.py:57) may pick for fp32 3x3 convolutions: 2.25x fewer
  * multiplications, results within fp32 rounding of the direct sum (tests state the tolerance). */
 int y2_wino_weight(const float* w_packed, float* u, int32_t Cout, int32_t Cin, y2_stream_t stream);
+/* ... and for Y2_ALGO_WINOGRAD_F43: u6[36][Cout][Cin] = G g G^T (G 6x3, interpolation points 0, 1, -1, 2, -1/2, inf). */
+int y2_wino6_weight(const float* w_packed, float* u6, int32_t Cout, int32_t Cin, y2_stream_t stream);
 
 /* Winograd form of y2_conv_wgrad for a 3x3 / stride-1 / same-padding convolution: dw_packed[Cout][9][Cin] = (not +=) the
  * weight gradient; 16 reductions over ceil(H/2)*ceil(W/2) tiles per image instead of 9 over H*W pixels.  Cin, Cout, ldx,

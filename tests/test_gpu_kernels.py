@@ -721,3 +721,35 @@ def test_eval_matching_like_reference():
     np.testing.assert_array_equal(tp, want)
     assert tp.sum() >= 5
     assert ev.matching(torch.zeros(0, 2, device=d), torch.zeros(0, 2, device=d), torch.from_numpy(p_min).to(d), torch.from_numpy(p_max).to(d), 0.5).sum() == 0
+
+
+@pytest.mark.parametrize('B,cin,cout,H,W', [(2, 64, 32, 13, 13), (1, 128, 64, 26, 26), (3, 32, 48, 7, 10), (2, 512, 256, 13, 13), (1, 16, 20, 4, 4), (2, 8, 12, 1, 3)])
+def test_conv_fwd_winograd_f43_for_gradients(B, cin, cout, H, W):
+    """Y2_ALGO_WINOGRAD_F43 (Winograd F(4x4,3x3), three kernels, 36 GEMMs; offered to the training step's data gradients): against the fp64
+    reference at the single-Winograd-layer tolerance (its larger transform constants: ~1e-5 x rms instead of ~2e-6), ragged 4x4 tiles,
+    channel window and affine + LeakyReLU epilogue."""
+    import _hip
+    L, d = _hip.lib(), dev()
+    g = torch.Generator().manual_seed(B + cin + cout + H * W)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    scale, shift = torch.randn(cout, generator=g), torch.randn(cout, generator=g) * 0.1
+    _, ref = ref_conv(x, w, scale, shift, 0.1, 3)
+    xd = to_nhwc(x).to(d)
+    wp = torch.empty(w.numel(), device=d)
+    _hip.check(L.y2_pack_weight(_hip.ptr(w.to(d).contiguous()), _hip.ptr(wp), cout, cin, 3, 0, _hip.stream()), 'pack')
+    u6 = _hip.wino6_weight(wp, cout, cin)
+    sc, sh = scale.to(d), shift.to(d)
+    y = torch.full((B, H, W, cout + 8), -7.0, device=d)
+    p = _hip.ConvParams()
+    p.x, p.w, p.scale, p.shift, p.y = xd.data_ptr(), u6.data_ptr(), sc.data_ptr(), sh.data_ptr(), y.data_ptr()
+    p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize, p.ldy, p.coff, p.slope, p.algo, p.tile = B, H, W, cin, cin, cout, 3, cout + 8, 4, 0.1, 6, 0
+    assert _hip.conv_workspace(p, d) >= 0
+    _hip.check(L.y2_conv_fwd(ctypes.byref(p), _hip.stream()), 'conv algo 6')
+    torch.cuda.synchronize()
+    yc = y.cpu()
+    assert torch.all(yc[..., :4] == -7.0) and torch.all(yc[..., 4 + cout:] == -7.0), 'wrote outside its channel window'
+    err = rel_err(yc[..., 4:4 + cout].permute(0, 3, 1, 2), ref)
+    assert err <= 4 * CONV_TOL, err
+    p.y_pool = y.data_ptr()                      # no pooled output / statistics in this algorithm: refused, not ignored
+    assert L.y2_conv_fwd(ctypes.byref(p), _hip.stream()) != 0

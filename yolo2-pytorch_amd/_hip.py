@@ -75,6 +75,7 @@ SIGNATURES = {
     'y2_conv_fwd': [ctypes.POINTER(ConvParams), c_void_p],
     'y2_conv_fwd_workspace_bytes': [ctypes.POINTER(ConvParams)],
     'y2_wino_weight': [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    'y2_wino6_weight': [c_void_p, c_void_p, c_int, c_int, c_void_p],
     'y2_opt_sgd': [ctypes.POINTER(OptTensor), c_int, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p],
     'y2_opt_adam': [ctypes.POINTER(OptTensor), c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p],
     'y2_opt_grad_sumsq': [ctypes.POINTER(OptTensor), c_int, c_void_p, c_void_p],
@@ -387,6 +388,13 @@ def wino_eligible(cout, cin, k, stride=1):
     return WINOGRAD and k == 3 and stride in (0, 1) and cin % 4 == 0 and cout % 4 == 0 and cin >= WINO_MIN_CIN
 
 
+def wino6_weight(wp, cout, cin):
+    """U6 [36][Cout][Cin] from a packed 3x3 weight: the filter operand of Y2_ALGO_WINOGRAD_F43 (4x4 output tiles; gradients only)."""
+    u = torch.empty(36 * cout * cin, dtype=torch.float32, device=wp.device)
+    check(lib().y2_wino6_weight(ptr(wp), ptr(u), cout, cin, stream()), 'y2_wino6_weight')
+    return u
+
+
 def wino_weight(wp, cout, cin):
     """U [16][Cout][Cin] from a packed 3x3 weight (y2_pack_weight mode 0 or 1)."""
     u = torch.empty(16 * cout * cin, dtype=torch.float32, device=wp.device)
@@ -407,27 +415,36 @@ def _time_conv(L, params, st):
     return t
 
 
-def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, split_plane=0):
+def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, split_plane=0, f43=None):
     """Measure-don't-guess algorithm + tile selection for one y2_conv_fwd problem: the first time a problem shape is seen,
     every tile configuration of the direct kernel - and, when `wino_w` (y2_wino_weight output) is given, of the Winograd
     path - is timed (HIP events, best of 2 x 3 launches) and the fastest is cached for the process; later calls only
     look the answer up.  Sets params.algo / params.tile / params.w.  The outputs written while timing are real outputs.
     Never measures while a hipGraph is being captured (plans are built during warm-up).
     implicit_ok=False: the caller wants the transformed input left in the workspace (training keeps it for the weight gradient),
-    so the algorithm that never materialises it (3) is not offered."""
+    so the algorithm that never materialises it (3) is not offered.
+    f43: the result is a GRADIENT and may take Winograd F(4x4,3x3) (Y2_ALGO_WINOGRAD_F43, 8-9e-6 x rms per layer): the y2_wino6_weight operand
+    or a callable producing it (called only when that algorithm is timed or chosen)."""
     wino_ok = (wino_w is not None and WINOGRAD and params.ksize == 3 and params.stride in (0, 1) and params.pad_plus1 in (0, 2)
                and not params.transposed and not params.residual and params.out_mode == 0)
     split_ok = bool(wino_ok and SPLIT and wino_split is not None and params.Cin % 32 == 0)
     key = (params.B, params.H, params.W, params.Cin, params.ldx, params.Cout, params.ksize, bool(params.y), bool(params.y_pool),
            bool(params.stats), params.out_mode, params.stride, params.pad_plus1, bool(params.residual), params.transposed, params.out_h, params.out_w, str(dev),
-           bool(wino_ok), bool(implicit_ok and IMPLICIT)) + (('split', split_mode()) if split_ok else ())
+           bool(wino_ok), bool(implicit_ok and IMPLICIT)) + (('split', split_mode()) if split_ok else ()) + (('f43',) if (f43 is not None and wino_ok) else ())
+    f43_ok = f43 is not None and wino_ok and not DETERMINISTIC and params.y and not params.y_pool and not params.stats
+    f43_t = []
+
+    def f43_w():
+        if not f43_t:
+            f43_t.append(f43() if callable(f43) else f43)
+        return f43_t[0]
     implicit_ok = bool(implicit_ok and IMPLICIT) and params.Cin % 32 == 0
     w_direct = params.w
 
     def apply(choice):
         algo, tile = choice
         params.algo, params.tile = algo, tile
-        params.w = wino_split.data_ptr() if algo in (4, 5) else wino_w.data_ptr() if algo in (1, 2, 3) else w_direct
+        params.w = wino_split.data_ptr() if algo in (4, 5) else wino_w.data_ptr() if algo in (1, 2, 3) else f43_w().data_ptr() if algo == 6 else w_direct
         params.w_plane = split_plane if algo in (4, 5) else 0
         return choice
     if FORCE_ALGO is not None:
@@ -449,6 +466,8 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
     if not AUTOTUNE or DETERMINISTIC or torch.cuda.is_current_stream_capturing():
         # no measurement possible (or, deterministic mode: a timed choice may differ from run to run and with it the rounding): the choices the measurements converge to on MI355X (profiles/r01_detect_b32_layer_table.txt)
         prefer = []
+        if f43_ok and params.Cin >= 128 and params.H * params.W <= 19 * 19:
+            prefer.append((6, 5))                  # gradients of the 13x13 (19x19) layers: 4x4 tiles, 64x128 GEMM tiles
         if split_ok and params.H * params.W <= 19 * 19:
             prefer.append((split_algo(), 0))       # opt-in split mode: the 13x13 (19x19 at 608) layers, 25-30 % ahead of the fp32 GEMMs there
         if wino_ok and implicit_ok and (params.H * params.W >= 52 * 52 or (params.H * params.W >= 26 * 26 and params.Cout <= params.Cin)):
@@ -481,6 +500,8 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
                 cands.append((3, 3))
         if split_ok:
             cands.append((split_algo(), 0))        # three-kernel Winograd with the GEMMs on the bf16 / fp16 pipe (opt-in precision modes)
+        if f43_ok:
+            cands += [(6, t) for t in (5, 3, 2, 1)]      # gradients: Winograd F(4x4,3x3), three kernels, 36 GEMMs
     best, best_t = (0, 0), float('inf')
     stats_save = params.stats
     params.stats = None          # timing launches must not accumulate statistics twice

@@ -26,6 +26,7 @@ __attribute__((visibility("hidden"))) int y2_internal_wgrad_needs_zero(long long
 __attribute__((visibility("hidden"))) int y2_internal_wgrad_grouped_dz(const float* v, const float* dz_raw, const int32_t* tile_pix, float* dw, long long M, int Cin, int Cout,
                                                                          int ldz, int zW, unsigned long long dz_bytes, long long gx, long long gw, y2_stream_t stream);
 __attribute__((visibility("hidden"))) int y2_internal_wino_conv(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need);
+__attribute__((visibility("hidden"))) int y2_internal_wino6_conv(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need);
 // gemm_split.hip: fp32-accurate GEMMs on the bf16 matrix pipe (three bf16 planes per operand, six plane products)
 __attribute__((visibility("hidden"))) int y2_internal_gemm_split(const void* A, long long planeA, const void* B, long long planeB, float* C, long long M, int N, int K, int ldc, int groups, int planes,
                                                                   float out_scale, y2_stream_t stream);

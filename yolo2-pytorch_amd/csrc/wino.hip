@@ -1409,6 +1409,103 @@ __global__ __launch_bounds__(256) void wino6_dw_kernel(const float* __restrict__
         }
 }
 
+// ---- convolution on 4x4 output tiles: Winograd F(4x4, 3x3) with the same interpolation points (Y2_ALGO_WINOGRAD_F43): 36 multiplications
+// per 16 outputs instead of 64 (2x2 tiles) or 144 (direct).  Its error is 8-9e-6 x rms per layer in an fp32 model (1.3e-6 for F(2x2,3x3)):
+// offered where the caller says the result is a GRADIENT (the training step's data gradients of the 13x13 layers, whose 2x2 form runs
+// as three kernels anyway); inference and the training forward stay on F(2x2,3x3).  Input transform: wino6_in_kernel<false> (the B^T of
+// F(3x3,4x4) and of F(4x4,3x3) are the same matrix: it depends on the points only).
+//   A^T = | 1  1  1  1   1    0 |     G = |   1      0      0   |
+//         | 0  1 -1  2 -1/2   0 |         | -1/3   -1/3   -1/3  |
+//         | 0  1  1  4  1/4   0 |         |  1/3   -1/3    1/3  |
+//         | 0  1 -1  8 -1/8   1 |         |  1/15   2/15   4/15 |
+//                                         | -16/15  8/15  -4/15 |
+//                                         |   0      0      1   |
+__global__ __launch_bounds__(256) void wino6_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin) {
+    constexpr float GM[6][3] = {{1.f, 0.f, 0.f}, {-1.f / 3, -1.f / 3, -1.f / 3}, {1.f / 3, -1.f / 3, 1.f / 3},
+                                {1.f / 15, 2.f / 15, 4.f / 15}, {-16.f / 15, 8.f / 15, -4.f / 15}, {0.f, 0.f, 1.f}};
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)Cout * Cin;
+    if (idx >= total) return;
+    const int k = (int)(idx % Cin);
+    const int n = (int)(idx / Cin);
+    float g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = w[((size_t)n * 9 + t) * Cin + k];      // packed [n][tap][k]
+    float sm[6][3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (GM[a][i] != 0.f) v += GM[a][i] * g[i][j];
+            sm[a][j] = v;
+        }
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (GM[b][j] != 0.f) v += GM[b][j] * sm[a][j];
+            u[(size_t)(6 * a + b) * total + idx] = v;
+        }
+}
+
+struct Wino6OutArgs {
+    const float* m;       // [36][T][C]
+    const float* scale; const float* shift;
+    float* y;
+    int B, H, W, C, ldy, coff, th, tw, T;
+    float slope;
+    y2_fastdiv d_c, d_tt, d_tw;
+};
+
+__global__ __launch_bounds__(256) void wino6_out_kernel(const Wino6OutArgs a) {
+    constexpr float AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -0.5f, 0.f}, {0.f, 1.f, 1.f, 4.f, 0.25f, 0.f}, {0.f, 1.f, -1.f, 8.f, -0.125f, 1.f}};
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t t = y2_div(idx, a.d_c);
+    if (t >= (uint32_t)a.T) return;
+    const int c = (int)(idx - t * (uint32_t)a.C);
+    const int b = (int)y2_div(t, a.d_tt);
+    const int r = (int)t - b * a.th * a.tw;
+    const int ty = (int)y2_div((uint32_t)r, a.d_tw);
+    const int tx = r - ty * a.tw;
+    const float* src = a.m + (size_t)t * a.C + c;
+    const size_t plane = (size_t)a.T * a.C;
+    float s[4][6];                 // A^T M
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 6; ++v) s[i][v] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+            const float x = src[(size_t)(6 * u + v) * plane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (AT[i][u] != 0.f) s[i][v] += AT[i][u] * x;
+        }
+    const float sc = a.scale != nullptr ? a.scale[c] : 1.f, sh = a.shift != nullptr ? a.shift[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                if (AT[j][q] != 0.f) v += AT[j][q] * s[i][q];
+            const int yy = 4 * ty + i, xx = 4 * tx + j;
+            if (yy < a.H && xx < a.W) {
+                const float uu = v * sc + sh;
+                a.y[((size_t)(b * a.H + yy) * a.W + xx) * a.ldy + a.coff + c] = uu > 0.f ? uu : uu * a.slope;
+            }
+        }
+}
+
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // V + M bytes per batch chunk (Y2_WINO_CHUNK_MB).  Chunks small enough to keep V and M in the 256 MB Infinity Cache were
@@ -1421,6 +1518,63 @@ inline size_t wino_chunk_bytes() {
 }
 
 }  // namespace
+
+extern "C" int y2_wino6_weight(const float* w_packed, float* u6, int32_t Cout, int32_t Cin, y2_stream_t stream) {
+    if (w_packed == nullptr || u6 == nullptr || Cout <= 0 || Cin <= 0) return Y2_EINVAL;
+    const long long n = (long long)Cout * Cin;
+    Y2_LAUNCH("wino6_weight_kernel", 0.0, wino6_weight_kernel, dim3((unsigned)y2_cdiv(n, 256)), dim3(256), 0, y2_s(stream), w_packed, u6, Cout, Cin);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+// y2_conv_fwd with algo == Y2_ALGO_WINOGRAD_F43: input transform, 36 grouped GEMMs, output transform (+ affine, LeakyReLU).  y only.
+int y2_internal_wino6_conv(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need) {
+    if (ws_need != nullptr) *ws_need = 0;
+    if (p == nullptr || p->x == nullptr || p->w == nullptr) return Y2_EINVAL;
+    if (p->y == nullptr || p->y_pool != nullptr || p->stats != nullptr || p->residual != nullptr || p->out_mode != 0) return Y2_ENOSUP;
+    if (p->B <= 0 || p->H <= 0 || p->W <= 0 || p->Cin <= 0 || p->Cout <= 0 || p->ldx < p->Cin || p->ldy < p->coff + p->Cout) return Y2_EINVAL;
+    const int stride = p->stride > 0 ? p->stride : 1;
+    const int pad = p->pad_plus1 > 0 ? p->pad_plus1 - 1 : 1;
+    if (p->ksize != 3 || stride != 1 || pad != 1 || p->transposed != 0) return Y2_ENOSUP;
+    if ((p->Cin % 4) != 0 || (p->Cout % 4) != 0 || !y2_aligned16(p->w)) return Y2_ENOSUP;
+    const int th = (p->H + 3) / 4, tw = (p->W + 3) / 4;
+    const long long T = (long long)p->B * th * tw;
+    if (T * p->Cin >= 0xffffffffLL || T * p->Cout >= 0xffffffffLL || T > 0x7fffffff) return Y2_ENOSUP;
+    const size_t vbytes = align256((size_t)36 * T * p->Cin * 4), mbytes = align256((size_t)36 * T * p->Cout * 4);
+    y2_conv_params q = {};
+    q.B = 1; q.H = 1; q.W = (int)T; q.Cin = p->Cin; q.ldx = p->Cin; q.Cout = p->Cout; q.ksize = 1;
+    q.ldy = p->Cout; q.slope = 1.f; q.tile = p->tile; q.algo = Y2_ALGO_DIRECT;
+    if (ws_need != nullptr) {
+        float* const dummy = reinterpret_cast<float*>(256);
+        q.x = dummy; q.w = dummy; q.y = dummy;
+        size_t inner = 0;
+        const int rc = y2_internal_conv_grouped(&q, 36, T * p->Cin, (long long)p->Cout * p->Cin, T * p->Cout, stream, &inner);
+        if (rc != Y2_OK) return rc;
+        *ws_need = vbytes + mbytes + inner;
+        return Y2_OK;
+    }
+    if (p->workspace == nullptr || !y2_aligned16(p->workspace) || (size_t)p->workspace_bytes < vbytes + mbytes) return Y2_EINVAL;
+    float* V = p->workspace;
+    float* M = V + vbytes / sizeof(float);
+    hipStream_t s = y2_s(stream);
+    Wino6Args ia;
+    ia.B = p->B; ia.H = p->H; ia.W = p->W; ia.th = th; ia.tw = tw; ia.T = (int)T;
+    ia.d_tt = y2_make_fastdiv((uint32_t)(th * tw)); ia.d_tw = y2_make_fastdiv((uint32_t)tw);
+    ia.src = p->x; ia.dst = V; ia.C = p->Cin; ia.ld = p->ldx; ia.d_c = y2_make_fastdiv((uint32_t)p->Cin);
+    Y2_LAUNCH("wino6_in_kernel", 0.0, wino6_in_kernel<false>, dim3((unsigned)y2_cdiv(T * p->Cin, 256)), dim3(256), 0, s, ia);
+    q.x = V; q.w = p->w; q.y = M;
+    q.workspace = M + mbytes / sizeof(float);
+    q.workspace_bytes = (long long)((size_t)p->workspace_bytes - vbytes - mbytes);
+    const int rc = y2_internal_conv_grouped(&q, 36, T * p->Cin, (long long)p->Cout * p->Cin, T * p->Cout, stream, nullptr);
+    if (rc != Y2_OK) return rc;
+    Wino6OutArgs oa;
+    oa.m = M; oa.scale = p->scale; oa.shift = p->shift; oa.y = p->y;
+    oa.B = p->B; oa.H = p->H; oa.W = p->W; oa.C = p->Cout; oa.ldy = p->ldy; oa.coff = p->coff; oa.th = th; oa.tw = tw; oa.T = (int)T; oa.slope = p->slope;
+    oa.d_c = y2_make_fastdiv((uint32_t)p->Cout); oa.d_tt = ia.d_tt; oa.d_tw = ia.d_tw;
+    Y2_LAUNCH("wino6_out_kernel", 0.0, wino6_out_kernel, dim3((unsigned)y2_cdiv(T * p->Cout, 256)), dim3(256), 0, s, oa);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
 
 extern "C" int y2_wino_weight(const float* w_packed, float* u, int32_t Cout, int32_t Cin, y2_stream_t stream) {
     if (w_packed == nullptr || u == nullptr || Cout <= 0 || Cin <= 0) return Y2_EINVAL;

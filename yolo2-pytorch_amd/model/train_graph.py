@@ -36,6 +36,7 @@ def _side_stream(dev):
     return s
 
 
+GRAD_F43 = os.environ.get('Y2_GRAD_F43', '1') != '0'        # offer Winograd F(4x4,3x3) to the data gradients of the deep layers (A/B)
 FUSE_CONV0 = os.environ.get('Y2_FUSE_CONV0', '1') != '0'      # 0: materialise the first layer's dz and run the two-kernel form (A/B runs)
 DEBUG_TAP = None        # tools/debug: callable(block name, dz, dx) invoked per block of the Darknet backward
 
@@ -74,7 +75,7 @@ def _new(dev, *shape, dtype=torch.float32):
 
 
 def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=None, slope=1.0, stats=None, y_pool=None, ldp=0, coff=0, out_mode=0, keep_v=False, u=False,
-          us=None, us_plane=0):
+          us=None, us_plane=0, grad=False):
     """One y2_conv_fwd.  keep_v: when the Winograd algorithm is chosen, run it in a workspace of its own and return that tensor -
     its head is the transformed input V, which the weight gradient of the same layer reuses (y2_wino_wgrad v_transformed).
     u: the layer's Winograd filter transform when the caller prepared it (y2_prep_weights), None = not eligible, False = derive it here."""
@@ -94,7 +95,9 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
     elif out_mode != 0:
         u = None
     # us: bf16 plane triple of u (opt-in split-bf16 mode; planes us_plane elements apart), offered as Y2_ALGO_WINOGRAD_SPLIT
-    _hip.autotune_conv(p, x.device, wino_w=u, implicit_ok=not keep_v, wino_split=us if u is not None else None, split_plane=us_plane)
+    # grad: the output is a data gradient - the deep layers may take the 4x4-tile Winograd form (its filter operand is built on demand)
+    f43 = (lambda: _hip.wino6_weight(wp, cout, cin)) if (grad and GRAD_F43 and u is not None and cin >= 128 and H * W <= 26 * 26) else None
+    _hip.autotune_conv(p, x.device, wino_w=u, implicit_ok=not keep_v, wino_split=us if u is not None else None, split_plane=us_plane, f43=f43)
     kept = None
     if keep_v and p.algo in (1, 2):
         T = B * ((H + 1) // 2) * ((W + 1) // 2)
@@ -624,7 +627,7 @@ def _darknet_bwd(ctx, dout):
                 # (the fp16 split mode is for activations: its fixed operand scales assume O(1) values, and gradients are 1e-5 and smaller -
                 # their fp16 planes would be subnormal; data gradients stay on the fp32 / bf16-split algorithms)
                 dg_split = ready_ops['uds'] if _hip.split_mode() == 'bf16' else None
-                _conv(L, st, dz, ready_ops['wd'], dx, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'], us=dg_split, us_plane=ready_ops['plane'])
+                _conv(L, st, dz, ready_ops['wd'], dx, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'], us=dg_split, us_plane=ready_ops['plane'], grad=True)
             else:
                 wsrc = e.w
                 if cop != cout:
