@@ -1,0 +1,59 @@
+"""Host logic of the binding that needs no GPU: the per-shape plan LRU (multi-scale training, utils/data.py:135-141), the measured-choice
+table's export / import (what data-parallel ranks exchange, train.py:427-433) and the static algorithm preferences (Y2_AUTOTUNE=0)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'yolo2-pytorch_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def test_plan_cache_is_an_lru_bounded_by_entries_and_bytes():
+    import _hip
+    c = _hip.PlanCache(entries=3, gbytes=1.0)
+    for i in range(3):
+        c.put(('shape', i), {'id': i}, 100 << 20)
+    assert c.get(('shape', 0))['id'] == 0                      # touch 0: 1 is now the oldest
+    c.put(('shape', 3), {'id': 3}, 100 << 20)
+    assert c.get(('shape', 1)) is None and c.get(('shape', 0)) is not None and c.get(('shape', 3)) is not None
+    c.put(('shape', 4), {'id': 4}, 900 << 20)                  # the byte bound evicts until the newest fits with what is left
+    assert c.get(('shape', 4)) is not None and sum(p['nbytes'] for p in c.d.values()) <= (1 << 30)
+    c.put(('huge',), {'id': 9}, 5 << 30)                       # a plan larger than the bound still stays (the cache never drops its only entry)
+    assert c.latest()['id'] == 9 and len(c.d) == 1
+    assert c.hits == 4 and c.misses == 1
+
+
+def test_tune_table_round_trip_keeps_choices_and_device_placeholders(monkeypatch):
+    import _hip
+    monkeypatch.setattr(_hip, '_TUNE', {})
+    monkeypatch.setattr(_hip, 'TUNE_CACHE', None)
+    key_conv = (64, 13, 13, 512, 512, 1024, 3, True, False, False, 0, 0, 0, False, 0, 0, 0, 'cuda:0', True, True)
+    key_wgrad = ('wgrad', 64, 13, 13, 512, 512, 1024, 1024, True, 'cuda:0')
+    _hip._TUNE[key_conv] = [2, 3]
+    _hip._TUNE[key_wgrad] = 2
+    blob = _hip.export_tune()
+    monkeypatch.setattr(_hip, '_TUNE', {})
+    epoch = _hip.tune_epoch()
+    _hip.import_tune(blob, 'cuda:3')                           # another rank's device name
+    assert len(_hip._TUNE) == 2 and _hip.tune_epoch() != epoch     # plans built on the old choices are invalidated
+    got = {k: v for k, v in _hip._TUNE.items()}
+    assert any(k[0] == 'wgrad' and k[-1] == 'cuda:3' and v == 2 for k, v in got.items())
+    assert any(k[0] == 64 and 'cuda:3' in k and list(v) == [2, 3] for k, v in got.items())
+
+
+@pytest.mark.parametrize('cin,hw,want', [(32, 208, 0), (64, 104, 0), (128, 52, 1), (256, 26, 1), (512, 13, 2), (1024, 19, 2), (1280, 13, 2)])
+def test_static_weight_gradient_preferences(monkeypatch, cin, hw, want):
+    """Y2_AUTOTUNE=0: the choices the measurements converge to - direct kernel below 128 input channels, the 2x2-tile Winograd reduction above,
+    its 4x4-tile form on the 13x13 / 19x19 layers; the deterministic mode never takes the 4x4 form (the library refuses it there)."""
+    import _hip
+    monkeypatch.setattr(_hip, 'AUTOTUNE', False)
+    monkeypatch.setattr(_hip, 'DETERMINISTIC', False)
+    monkeypatch.setattr(_hip, 'WINOGRAD', True)
+    monkeypatch.setattr(_hip, 'WGRAD_F34', True)
+    assert _hip.wgrad_choice(64, hw, hw, cin, cin, 2 * cin, 2 * cin, 3, True, 'cuda:0') == want
+    assert _hip.wgrad_choice(64, hw, hw, cin, cin, 2 * cin, 2 * cin, 1, True, 'cuda:0') == 0          # 1x1 layers: the direct kernel
+    monkeypatch.setattr(_hip, 'DETERMINISTIC', True)
+    assert _hip.wgrad_choice(64, hw, hw, cin, cin, 2 * cin, 2 * cin, 3, True, 'cuda:0') == (1 if cin >= 128 else 0)
