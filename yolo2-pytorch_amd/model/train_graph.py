@@ -96,7 +96,7 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
         u = None
     # us: bf16 plane triple of u (opt-in split-bf16 mode; planes us_plane elements apart), offered as Y2_ALGO_WINOGRAD_SPLIT
     # grad: the output is a data gradient - the deep layers may take the 4x4-tile Winograd form (its filter operand is built on demand)
-    f43 = (lambda: _hip.wino6_weight(wp, cout, cin)) if (grad and GRAD_F43 and u is not None and cin >= 128 and H * W <= 26 * 26) else None
+    f43 = (lambda: _hip.wino6_weight(wp, cout, cin)) if (grad and GRAD_F43 and u is not None and cin >= 128 and H * W <= 52 * 52) else None      # (offered; the measurement decides: 13x13 ... 26x26 at 416, 19x19 ... 38x38 at 608)
     _hip.autotune_conv(p, x.device, wino_w=u, implicit_ok=not keep_v, wino_split=us if u is not None else None, split_plane=us_plane, f43=f43)
     kept = None
     if keep_v and p.algo in (1, 2):
