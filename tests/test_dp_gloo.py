@@ -105,6 +105,21 @@ def worker(rank, world, port, tmp):
     for (n, a), b in zip(m.named_parameters(), ref.parameters()):
         assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6), ('accumulate', n)
     assert m[2].in_place >= 2, m[2].in_place            # the zero_grad'ed steps wrote the early layer's weight gradient in place
+    # Train.iterate's ordering (train.py:344-351): forward FIRST, then optimizer.zero_grad(), then backward - last step's gradients are
+    # still set while forward() runs; who accumulates must be decided at backward time or the in-place bucket path never runs
+    before = m[2].in_place
+    for step in range(2):
+        out = dp(x[shard])
+        for p in dp.parameters():
+            p.grad = None
+        ((out - y[shard]) ** 2).mean().backward()
+        for p in ref.parameters():
+            p.grad = None
+        ((ref(x) - y) ** 2).mean().backward()
+        for (n, a), b in zip(m.named_parameters(), ref.parameters()):
+            assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6), ('iterate order', n, step)
+        assert m[2].weight.grad.data_ptr() == dp._flat[dp._where[id(m[2].weight)][0]][dp._where[id(m[2].weight)][1]:].data_ptr()      # the gradient IS the bucket slice
+    assert m[2].in_place == before + 2, (m[2].in_place, before)
     # two backward passes WITHOUT a forward in between (two outputs of one step): the first pass's averaged gradients are bucket
     # slices; the second pass must not overwrite them in place: grad = avg(pass 1) + avg(pass 2)
     for p in dp.parameters():
@@ -134,6 +149,17 @@ def worker(rank, world, port, tmp):
     assert train.sync_tune(torch.device('cpu')) == 1
     assert _hip._TUNE[(32, 13, 13, 1024, 'cpu')] == [1, 5]
     assert (_hip.tune_epoch() != epoch) == (rank != 0)          # plans built on the old choices are invalidated where the table changed
+    # the wrapper's own exchange is triggered by its call count alone (identical on every rank whatever shapes the ranks' loaders drew) and
+    # MERGES: rank 0's entries win, an entry only this rank has stays
+    _hip._TUNE.clear()
+    _hip._TUNE[(64, 10, 10, 512, 'cpu')] = [1, rank]
+    _hip._TUNE[('mine', rank, 'cpu')] = [2, 0]
+    dp2 = train.DataParallelRCCL(nn.Linear(3, 3))
+    for call in range(1, 5):
+        dp2(torch.randn(2 + rank * call, 3))                    # a different input shape per rank and call
+        assert (dp2.tune_synced is not None) == (call >= 4)
+    assert _hip._TUNE[(64, 10, 10, 512, 'cpu')] == [1, 0] and _hip._TUNE[('mine', rank, 'cpu')] == [2, 0]
+    assert (('mine', 0, 'cpu') in _hip._TUNE) and len(_hip._TUNE) == (2 if rank == 0 else 3)
     if rank == 0:
         open(os.path.join(tmp, 'ok'), 'w').write('ok')
     dist.barrier()

@@ -44,6 +44,17 @@ def test_tune_table_round_trip_keeps_choices_and_device_placeholders(monkeypatch
     assert any(k[0] == 64 and 'cuda:3' in k and list(v) == [2, 3] for k, v in got.items())
 
 
+def test_tune_table_merge_keeps_local_entries_and_moves_the_epoch_only_on_change(monkeypatch):
+    import _hip
+    monkeypatch.setattr(_hip, '_TUNE', {('a', 'cuda:1'): [1, 5], ('mine', 'cuda:1'): 2})
+    epoch = _hip.tune_epoch()
+    _hip.import_tune([(('a', '@dev'), (1, 5))], 'cuda:1', merge=True)          # nothing new: plans stay valid
+    assert _hip.tune_epoch() == epoch and len(_hip._TUNE) == 2
+    _hip.import_tune([(('a', '@dev'), [2, 0]), (('b', '@dev'), 1)], 'cuda:1', merge=True)
+    assert _hip.tune_epoch() == epoch + 1
+    assert _hip._TUNE == {('a', 'cuda:1'): [2, 0], ('mine', 'cuda:1'): 2, ('b', 'cuda:1'): 1}
+
+
 @pytest.mark.parametrize('cin,hw,want', [(32, 208, 0), (64, 104, 0), (128, 52, 1), (256, 26, 1), (512, 13, 2), (1024, 19, 2), (1280, 13, 2)])
 def test_static_weight_gradient_preferences(monkeypatch, cin, hw, want):
     """Y2_AUTOTUNE=0: the choices the measurements converge to - direct kernel below 128 input channels, the 2x2-tile Winograd reduction above,

@@ -213,7 +213,11 @@ def require_gpu(*tensors):
 # model's caches or captured graphs.
 def wrote(tensors):
     """Advance torch's version counter of every tensor in `tensors` (Parameters / buffers written by a HIP kernel)."""
-    torch.autograd.graph.increment_version(tensors)
+    try:
+        torch.autograd.graph.increment_version(tensors)
+    except TypeError:          # torch releases whose increment_version takes ONE tensor (README: developed on torch 2.10)
+        for t in tensors:
+            torch.autograd.graph.increment_version(t)
 
 
 # Execution plans additionally depend on the measured algorithm table: adopting another process's table (import_tune) moves this.
@@ -529,13 +533,29 @@ def export_tune():
     return out
 
 
-def import_tune(items, dev):
+def import_tune(items, dev, merge=False):
     """Adopt another process's choices (export_tune) for device `dev`: every rank of a data-parallel job then runs the same
-    algorithms (same rounding, no straggler that measured a worse plan).  Plans built on the old choices are invalidated."""
-    _TUNE.clear()
-    for k, v in items:
-        _TUNE[tuple(str(dev) if e == '@dev' else e for e in k)] = v
-    _TUNE_EPOCH[0] += 1
+    algorithms (same rounding, no straggler that measured a worse plan).  merge: entries only this process has (a problem shape
+    the other has not met) stay.  Plans built on the old choices are invalidated - only when an entry actually changed."""
+    new = {tuple(str(dev) if e == '@dev' else e for e in k): v for k, v in items}
+    if not merge:
+        if new == _TUNE:
+            return
+        _TUNE.clear()
+        _TUNE.update(new)
+        _TUNE_EPOCH[0] += 1
+        return
+    changed = False
+    for k, v in new.items():
+        if k not in _TUNE or _same_choice(_TUNE[k], v) is False:
+            _TUNE[k] = v
+            changed = True
+    if changed:
+        _TUNE_EPOCH[0] += 1
+
+
+def _same_choice(a, b):
+    return (list(a) if isinstance(a, (list, tuple)) else a) == (list(b) if isinstance(b, (list, tuple)) else b)
 
 
 def _tune_save():

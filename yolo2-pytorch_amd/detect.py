@@ -162,6 +162,10 @@ class GraphedDetector(object):
         # what the captured pointers were derived from: the tensors themselves (kept alive here) with their version counters - the check in
         # run() is one attribute read per tensor, no module-tree walk (it sits in the replay path)
         self._watched = [(t, t.data_ptr(), t._version) for t in list(dnn.parameters()) + list(dnn.buffers())]
+        # the graph bakes in the addresses of the plan's intermediate buffers and scratch: hold the plan, so that an eviction from the
+        # plugin's plan LRU (a 13th input shape) cannot hand that memory to somebody else while this graph can still be replayed
+        plans = getattr(dnn, '_plans', None)
+        self._plan = plans.latest() if plans is not None else None
 
     def run(self, x=None):
         for t, ptr, ver in self._watched:

@@ -164,7 +164,8 @@ class ResNet(nn.Module):
         return prep
 
     def _plan(self, prep, dev, B, cin0, H, W):
-        key = (str(dev), B, cin0, H, W, _hip.tune_epoch(), _hip.WINOGRAD, _hip.FORCE_ALGO)
+        widths = tuple(tuple(m.weight.shape) for m in self.modules() if isinstance(m, nn.Conv2d))      # (pruned / replaced layers re-plan)
+        key = (str(dev), B, cin0, H, W, _hip.tune_epoch(), _hip.WINOGRAD, _hip.FORCE_ALGO, widths)
         plan = self._plans.get(key)
         if plan is not None:
             if plan['prep'] is not prep:      # same shape, new parameter version: only the weight operand pointers move

@@ -223,7 +223,10 @@ class Darknet(nn.Module):
         y2_conv_params array of the 22 generic convolutions (model/yolo2.py:76-113 in execution order)."""
         # slot: plans of the same shape with PRIVATE intermediate buffers and scratch, so that two batches can be in flight on two streams
         # (detect.GraphedDetector(slot=...): the tail of one batch's kernels overlaps the head of the next batch's)
-        key = (str(dev), B, cin0, H, W, _hip.tune_epoch(), _hip.WINOGRAD, _hip.FORCE_ALGO, _hip.split_mode(), slot)
+        # (the widths are part of the key: a plan's buffers, leading dimensions and algorithm choices are sized for the conv weights it was
+        # built for - channel surgery, a replaced head - while a new parameter VERSION of the same shapes only moves operand pointers)
+        widths = tuple(tuple(m.conv.weight.shape) for m in self.modules() if isinstance(m, Conv2d))
+        key = (str(dev), B, cin0, H, W, _hip.tune_epoch(), _hip.WINOGRAD, _hip.FORCE_ALGO, _hip.split_mode(), slot, widths)
         plan = self._plans.get(key)
         if plan is not None:
             if plan['prep'] is not prep:

@@ -87,19 +87,21 @@ class DataParallelRCCL(nn.Module):
             if hasattr(m, 'grad_ready_hook'):
                 m.grad_ready_hook = self._early_hook
                 m.grad_buffer_hook = self._grad_buffer
-        self._shape_calls = {}
 
     tune_synced = None
-    SYNC_TUNE_AT = 4        # forward call WITH A GIVEN INPUT SHAPE at which every rank adopts rank 0's measured algorithm choices (after 3 whole steps at that shape)
+    # forward calls (counted per wrapper, identical on every rank) at which the ranks adopt rank 0's measured algorithm choices: after 3 whole
+    # steps, then at a thinning schedule that picks up the shapes a multi-scale run visits later, then every 4096 calls.  Rank 0's entries
+    # win, entries only this rank has (a shape rank 0 has not met) stay; plans are rebuilt only where something changed.
+    SYNC_TUNE_CALLS = (4, 16, 64, 256, 1024, 4096)
     _calls = 0
 
     def _sync_tune(self):
         """Each rank times its kernels itself during the first steps at a new input shape; near-ties resolve differently from rank
         to rank, and the step time of the job is the slowest rank's.  One broadcast of rank 0's table makes the plans identical.
-        Every rank reaches the collective (the input shapes of a step are the same on all ranks: utils/data.py:135-141 resizes the
-        whole batch); whatever can fail locally happens outside it and degrades to "keep my own choices"."""
+        Every rank reaches the collective (forward() triggers it on its own call count); whatever can fail locally happens outside
+        it and degrades to "keep my own choices"."""
         import _hip
-        dev = next((p.device for p in self._params if p.is_cuda), None)
+        dev = next((p.device for p in self._params if p.is_cuda), None) or next((p.device for p in self._params), None)
         first = dist.get_rank(self.pg) == 0
         src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0      # (None = the default group: rank 0 is rank 0)
         table = None
@@ -109,7 +111,7 @@ class DataParallelRCCL(nn.Module):
             except Exception as e:
                 logging.warning('autotune choices not exported: %s' % e)
         box = [table]
-        if self._staged or dev is None:
+        if self._staged or dev is None or dev.type != 'cuda':
             dist.broadcast_object_list(box, src=src, group=self.pg)
         else:
             dist.broadcast_object_list(box, src=src, group=self.pg, device=dev)
@@ -117,7 +119,7 @@ class DataParallelRCCL(nn.Module):
             return
         if not first:
             try:
-                _hip.import_tune(box[0], dev)
+                _hip.import_tune(box[0], dev, merge=True)
             except Exception as e:      # never fatal: this rank keeps its own choices
                 logging.warning('autotune choices not adopted: %s' % e)
                 return
@@ -171,18 +173,21 @@ class DataParallelRCCL(nn.Module):
         self._next = 0          # buckets are launched strictly in index order: every rank issues the SAME collective sequence
 
     def _start(self):
+        """First gradient event of a backward pass.  Who accumulates is decided HERE, at backward time (Train.iterate runs the forward
+        before optimizer.zero_grad(), train.py:344-351: a snapshot taken in forward() would see last step's gradients on every parameter
+        and switch the in-place bucket path off for good): a parameter whose .grad is set now keeps it, and a kept gradient that is a
+        bucket slice of the previous pass (see _finalize; also a second backward without a forward in between: two outputs,
+        retain_graph) becomes a private copy before this pass's _fill rewrites the bucket."""
         if not self._pending:
             self._pending = True
-            # a second backward without a forward() in between (two outputs, retain_graph): gradients of the first are still the
-            # bucket slices this backward is about to rewrite - give the caller private copies and treat them as accumulated
-            had = None
+            had = set()
             for q in self._params:
-                if q.grad is not None and q.grad is self._views.get(id(q)):
-                    q.grad = q.grad.clone()
-                    had = self._had if isinstance(self._had, set) else set(self._had)
+                if q.grad is not None:
+                    if q.grad is self._views.get(id(q)):
+                        q.grad = q.grad.clone()
                     had.add(id(q))
-                    self._had = had
-                    del self._views[id(q)]
+            self._had = had
+            self._views = {}
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
 
     def _grad_buffer(self, p):
@@ -190,10 +195,10 @@ class DataParallelRCCL(nn.Module):
         (model.train_graph) saves the copy into the bucket; None = not this time (an accumulating caller, a moved module, a
         parameter this wrapper does not reduce)."""
         w = self._where.get(id(p))
-        if w is None or id(p) in self._done or id(p) in self._had:
+        if w is None or id(p) in self._done:
             return None
         self._start()
-        if p.grad is not None:
+        if id(p) in self._had or p.grad is not None:
             return None
         bi, off = w
         flat = self._flat[bi]
@@ -283,20 +288,12 @@ class DataParallelRCCL(nn.Module):
         self._pending = False
         self._reset()
         self._calls += 1
-        if self.world > 1:
-            shape = tuple(tuple(a.shape) for a in args if isinstance(a, torch.Tensor))
-            seen = self._shape_calls[shape] = self._shape_calls.get(shape, 0) + 1
-            if seen == self.SYNC_TUNE_AT:       # a new input size (multi-scale training) was tuned by every rank for 3 steps: adopt rank 0's table
-                self._sync_tune()
-        # gradients the caller kept from earlier steps (accumulation: no zero_grad): a kept gradient that is a bucket slice (see
-        # _finalize) becomes a private copy before this step's _fill rewrites the bucket, and _had remembers who accumulates
-        self._had = set()
-        for q in self._params:
-            if q.grad is not None:
-                if q.grad is self._views.get(id(q)):
-                    q.grad = q.grad.clone()
-                self._had.add(id(q))
-        self._views = {}
+        if self.world > 1 and (self._calls in self.SYNC_TUNE_CALLS or self._calls % self.SYNC_TUNE_CALLS[-1] == 0):
+            # the trigger is the wrapper's call count and nothing else: every rank calls forward() once per step, so every rank reaches the
+            # broadcast at the same point of its collective sequence - whatever input shapes the ranks' own loaders drew (with one process
+            # per GPU each rank's collate picks its multi-scale size itself, utils/data.py:135-141; a per-shape trigger would put one rank
+            # into the broadcast while the others start a gradient all-reduce)
+            self._sync_tune()
         out = self.module(*args, **kwargs)
         # the region loss sums its positive count over THIS wrapper's group (model/__init__.py:162: mean over the positives of the
         # global batch): the reducer travels with the predictions (model.train_graph.DP_TAG)
