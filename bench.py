@@ -78,6 +78,9 @@ def parse_args():
     ap.add_argument('--ms-sizes', default='320,352,384,416,448,480,512,544,576,608', help='input sizes of the multi-scale schedule (config.ini:39-40: 320..608 step 32)')
     ap.add_argument('--ms-maintain', type=int, default=10, help='batches per size before the next resize (config.ini [data] maintain, utils/data.py:135-141)')
     ap.add_argument('--ms-cycles', type=int, default=1, help='timed passes over the whole size schedule')
+    ap.add_argument('--no-latency', action='store_true', help='skip the batch-1 / batch-8 detect latency leg (BASELINE configs[0] twin on the GPU)')
+    ap.add_argument('--no-resnet', action='store_true', help='skip the ResNet-50 608x608 COCO-80 leg (BASELINE configs[4] per GPU)')
+    ap.add_argument('--resnet-batch', type=int, default=32, help='per-GPU batch of the ResNet-50 leg')
     ap.add_argument('--dry-run', action='store_true', help='no GPU: exercise launch / rendezvous / DP wrapper / timing protocol with a stand-in CPU workload (gloo); the numbers mean nothing')
     return ap.parse_args()
 
@@ -101,6 +104,25 @@ def self_launch(args):
 
 
 # ---------------------------------------------------------------------------------------------------- measurement helpers
+def pin_rank(local, world):
+    """One process per GPU on ONE host: give every rank its own contiguous share of the cores this job may use (issue thread, RCCL proxy
+    and torch's intra-op threads of a rank stay on one set of caches instead of migrating over the whole socket pair).  Y2_PIN=0: leave the
+    affinity alone.  Returns the number of cores the rank ends up with."""
+    try:
+        have = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+    if world <= 1 or os.environ.get('Y2_PIN', '1') == '0' or len(have) < 2 * world:
+        return len(have)
+    per = len(have) // world
+    mine = have[local * per:(local + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return len(have)
+    return len(mine)
+
+
 class Ctx(object):
     """Process-wide run context: ranks, device, barrier, max-over-ranks."""
 
@@ -112,6 +134,7 @@ class Ctx(object):
         self.rank = int(os.environ.get('RANK', '0'))
         self.local = int(os.environ.get('LOCAL_RANK', '0'))
         self.gpu = torch.cuda.is_available() and not args.dry_run
+        self.cores = pin_rank(self.local, self.world)
         if self.gpu:
             if os.environ.get('Y2_BENCH_DEVICE'):      # test rig only: several ranks on ONE GPU (with Y2_DIST_BACKEND=gloo) to exercise the N > 1 code path
                 self.local = int(os.environ['Y2_BENCH_DEVICE'])
@@ -188,6 +211,19 @@ def kernel_table(fn, steps):
         e['ms'] /= steps
         e['flops'] /= steps
     return table
+
+
+def issue_time(ctx, step, n=6):
+    """Host time to ISSUE one step with the GPU idle (median of n, synchronised before each): `host_ms_per_step` of a timed region also
+    contains the time the host spends blocked on a full launch queue, which says nothing about the cost of issuing."""
+    t = []
+    for i in range(n):
+        ctx.sync()
+        t0 = time.perf_counter()
+        step(i)
+        t.append((time.perf_counter() - t0) * 1e3)
+    ctx.sync()
+    return round(sorted(t)[len(t) // 2], 3)
 
 
 def top_kernels(table, min_share=0.01):
@@ -456,6 +492,8 @@ def train_leg(args, ctx):
         inf, anchors = bench_data.build_model(args.classes, ctx.dev, args.model)
         inf.train()
         m = y2train.ensure_model(inf) if wrap else inf
+        if m is not inf:
+            m.overlap_stats = []          # event pair per step around the wait for the outstanding all-reduces (dp_exposed_comm_ms_per_step)
         opt = utils.optim.SGD(m.parameters(), 1e-3, momentum=0.9)      # fused multi-tensor step (y2_opt_sgd), torch.optim.SGD semantics
         last = {}
 
@@ -485,8 +523,18 @@ def train_leg(args, ctx):
     dt, host = ctx.timed(step, steps)
     if ctx.world > 1:
         out['autotune_choices_synced'] = getattr(keep[1], 'tune_synced', None)
+        st = getattr(keep[1], 'overlap_stats', None)
+        if st:
+            ctx.sync()
+            ex = sorted(a.elapsed_time(b) for a, b in st[-steps:])
+            out['dp_exposed_comm_ms_per_step'] = round(ex[len(ex) // 2], 3)
+            out['dp_exposed_comm_note'] = 'median time the compute stream waits for the outstanding all-reduces after backward has finished (event pair around the waits)'
     out.update({'images_per_sec': round(B * steps * ctx.world / dt, 2), 'ms_per_step': round(dt / steps * 1e3, 3), 'host_ms_per_step': round(host / steps * 1e3, 3),
                 'loss_total': float(last['r']['loss_total'].detach())})
+    out['host_issue_ms_per_step'] = issue_time(ctx, step)
+    runner = keep[0].__dict__.get('_y2_step_runner')
+    out['launch'] = ('hipGraph replay of the captured step (%d graph segment(s)) + eager optimizer' % sum(1 for p in runner.plans.values() for op in (p.ops or []) if op[0] == 'graph')
+                     if (runner is not None and runner.captures) else 'eager launches')
     if single:
         out['dp_speedup_vs_single_gpu'] = round(out['images_per_sec'] / single, 3)
     if per_img is not None:
@@ -496,11 +544,13 @@ def train_leg(args, ctx):
         # the BatchNorm / transform passes of the next layers and the kernels inflate each other's durations (sum 60 ms in a 40 ms step)
         from model import train_graph
         streams, train_graph.BWD_STREAMS = train_graph.BWD_STREAMS, 1
+        graph, y2train.GRAPH = y2train.GRAPH, False          # the event hooks bracket LAUNCHES: this table comes from the same launch sequence issued eagerly
         try:
             step(0)
             table = kernel_table(step, 2)
         finally:
             train_graph.BWD_STREAMS = streams
+            y2train.GRAPH = graph
         out['roofline'] = roofline_from(table, 'training step, batch %d: fprop / dgrad / wgrad kernels with their executed FLOPs; per-kernel durations measured single-stream '
                                                '(the timed step runs the weight gradients on a side stream, Y2_BWD_STREAMS=%d)' % (B, streams))
         out['roofline']['kernel_ms_sum_single_stream'] = round(sum(e['ms'] for e in table.values()), 3)
@@ -556,6 +606,7 @@ def multiscale_leg(args, ctx):
         first_visit[S] = max(0.0, (t1 - t0) - max(5, maintain // 2) * steady)
     schedule = [S for _ in range(max(1, args.ms_cycles)) for S in sizes for _ in range(maintain)]
     dt, host = ctx.timed(lambda i: step(schedule[i]), len(schedule))
+    issue = {S: issue_time(ctx, lambda i, S=S: step(S), 4) for S in (sizes[0], sizes[-1])}
     images = B * len(schedule) * ctx.world
     # per-step table (synchronised after every step: NOT the throughput number)
     per = {S: [] for S in sizes}
@@ -577,6 +628,7 @@ def multiscale_leg(args, ctx):
     out = {'workload': '%s YOLOv2 %d-class multi-scale train, batch-%d/GPU, sizes %s, resize every %d batches: fwd + region loss + bwd + SGD (BASELINE configs[3] per GPU)'
                        % (args.model, C, B, '..'.join(str(v) for v in (sizes[0], sizes[-1])) + ' step %d' % (sizes[1] - sizes[0] if len(sizes) > 1 else 0), maintain),
            'images_per_sec': round(images / dt, 2), 'steps': len(schedule), 'ms_per_step_mean': round(dt / len(schedule) * 1e3, 3), 'host_ms_per_step_mean': round(host / len(schedule) * 1e3, 3),
+           'host_issue_ms_per_step': {str(S): v for S, v in issue.items()},
            'switch_cost_ms_mean': round(sum(switch) / len(switch), 3), 'switch_cost_ms_max': round(max(switch), 3),
            'first_visit_ms_mean': round(sum(first_visit.values()) / len(first_visit) * 1e3, 1), 'first_visit_ms_total': round(sum(first_visit.values()) * 1e3, 1),
            'per_gpu_batch': B, 'global_batch': B * ctx.world, 'loss_total': float(last['r']['loss_total'].detach()),
@@ -589,6 +641,131 @@ def multiscale_leg(args, ctx):
     torch.cuda.empty_cache()
     return out
 
+
+
+# ---------------------------------------------------------------------------------------------------- single-image / small-batch latency leg
+MIN_BYTES_B1 = 303e6       # every conv reads input + weights and writes its output once, fp32, 416x416, batch 1 (202.6 MB of it weights)
+WEIGHT_BYTES = 202.6e6
+PEAK_HBM_TBS = 8.0
+
+
+def latency_leg(args, ctx):
+    """BASELINE configs[0] is the reference's own usage: detect.py feeds ONE image per call (detect.py:141-153).  Its GPU twin: the
+    same conv + decode + filter + NMS step at batch 1 and batch 8, one captured hipGraph, strictly serial replays (latency, not
+    throughput).  Floors beside it: algorithmic conv FLOPs / fp32-MFMA peak and one-pass HBM bytes / 8 TB/s - at batch 1 both are
+    far below the measured time: the step is a chain of ~30 dependent launches on maps as small as 13x13."""
+    import torch
+
+    import bench_data
+    import detect
+    inf, anchors = bench_data.build_model(args.classes, ctx.dev, 'darknet')
+    dnn = inf.dnn
+    kw = dict(fix=True, threshold_cls=0.005, overlap=0.45, limit=200)
+    out = {'workload': 'Darknet-19 YOLOv2 %dx%d single-image / batch-8 inference: conv stack + decode + filter + NMS, hipGraph, serial (detect.py:141-153 on the GPU)' % (args.size, args.size)}
+    for B in (1, 8):
+        x = bench_data.images(B, args.size, seed=40 + B).to(ctx.dev)
+
+        def eager(i):
+            with torch.no_grad():
+                return detect.detect_batch(dnn.forward_nhwc(x), anchors, **kw)
+        for i in range(3):
+            eager(i)
+        ctx.sync()
+        table = kernel_table(eager, 4)
+        plan = dnn._plan_cache[1]
+        names = ['layers1.0'] + [n for n, _, _ in sum(dnn._blocks(), [])][1:]
+        algo_names = {0: 'direct', 1: 'winograd', 2: 'wino-fused', 3: 'wino-implicit', 4: 'split-bf16', 5: 'split-f16', 6: 'wino-f43'}
+        blk_name = {m: n for n, m, _ in sum(dnn._blocks(), [])}
+        blk_name[dnn.passthrough] = 'passthrough'
+        layers = [{'layer': blk_name.get(b, '?'), 'algo': algo_names.get(int(p.algo), str(p.algo)), 'tile': int(p.tile), 'HxW': '%dx%d' % (p.H, p.W), 'Cin': int(p.Cin), 'Cout': int(p.Cout), 'k': int(p.ksize)}
+                  for p, b in zip(plan['arr'], plan['blks'])]
+        g = detect.GraphedDetector(dnn, anchors, x, static_input=True, **kw)
+        for _ in range(20):
+            g.run()
+        steps = 200
+        dt, host = ctx.timed(lambda i: g.run(), steps)
+        ms = dt / steps * 1e3
+        flops = FLOPS_FWD_PER_IMG * B * (args.size / 416.0) ** 2
+        hbm = (WEIGHT_BYTES + (MIN_BYTES_B1 - WEIGHT_BYTES) * B) * (1.0 if args.size == 416 else (args.size / 416.0) ** 2)
+        mfma_floor = flops / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
+        hbm_floor = hbm / (PEAK_HBM_TBS * 1e12) * 1e3
+        kms = sum(e['ms'] for e in table.values())
+        out['b%d' % B] = {'batch': B, 'ms_per_step': round(ms, 4), 'ms_per_image': round(ms / B, 4), 'images_per_sec': round(B / ms * 1e3, 1), 'host_ms_per_step': round(host / steps * 1e3, 4),
+                          'launches_per_step': round(sum(e['launches'] for e in table.values()), 1), 'kernel_ms_sum_eager': round(kms, 4),
+                          'algorithmic_gflop': round(flops / 1e9, 2), 'min_hbm_mbytes': round(hbm / 1e6, 1),
+                          'mfma_floor_ms': round(mfma_floor, 4), 'hbm_floor_ms': round(hbm_floor, 4), 'bound': 'mfma' if mfma_floor >= hbm_floor else 'hbm',
+                          'frac_of_bound': round(max(mfma_floor, hbm_floor) / ms, 4), 'achieved_tflops_direct_equiv': round(flops / ms / 1e9, 2), 'achieved_hbm_tbs_min_bytes': round(hbm / ms / 1e9, 3),
+                          'winograd_layers': int(sum(1 for l in layers if l['algo'] != 'direct')), 'plan': layers,
+                          'top_kernels': top_kernels(table, 0.03)[0]}
+        del g
+    del inf, dnn
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- ResNet-50 608x608 COCO-80 leg (configs[4])
+RESNET50_608_FWD_GFLOP = 60.85          # SURVEY.md 8d [probe]: model/resnet.py resnet50 plugin, 608x608, 80 classes, per image
+RESNET50_608_STEM_DGRAD_GFLOP = 2 * 3 * 64 * 49 * 304 * 304 / 1e9       # the data gradient of the 7x7 stem is never computed
+
+
+def resnet_leg(args, ctx):
+    """BASELINE configs[4] per GPU: the plugin swap (`[model] dnn = model.resnet.resnet50`, config.ini:25) at 608x608 with the COCO-80 head:
+    batch-32 inference (conv stack + decode + filter + NMS, hipGraph) and batch-32 training (fwd + region loss + bwd + SGD, StepPlan),
+    with the per-kernel table of the training step (launch sequence issued eagerly under the event hooks)."""
+    import torch
+
+    import bench_data
+    import detect
+    import train as y2train
+    import utils
+    S, C, B = 608, 80, args.resnet_batch
+    kw = dict(fix=True, threshold_cls=0.005, overlap=0.45, limit=200)
+    out = {'workload': 'model.resnet.resnet50 YOLOv2 608x608 COCO-80, batch-%d/GPU (BASELINE configs[4] per GPU)' % B, 'per_gpu_batch': B}
+    inf, anchors = bench_data.build_model(C, ctx.dev, 'resnet50')
+    dnn = inf.dnn
+    x = bench_data.images(B, S, seed=71 + ctx.rank).to(ctx.dev)
+    with torch.no_grad():
+        for _ in range(3):
+            detect.detect_batch(dnn.forward_nhwc(x), anchors, **kw)
+    ctx.sync()
+    g = detect.GraphedDetector(dnn, anchors, x, static_input=True, **kw)
+    for _ in range(3):
+        g.run()
+    steps = 10
+    dt, _ = ctx.timed(lambda i: g.run(), steps)
+    out['detect'] = {'images_per_sec': round(B * steps * ctx.world / dt, 1), 'ms_per_step': round(dt / steps * 1e3, 3),
+                     'direct_equiv_tflops_per_gpu': round(RESNET50_608_FWD_GFLOP * B * steps / dt / 1e3, 2)}
+    out['detect']['direct_equiv_frac'] = round(out['detect']['direct_equiv_tflops_per_gpu'] / PEAK_FP32_MFMA_TFLOPS, 4)
+    del g
+    inf.train()
+    m = y2train.ensure_model(inf) if ctx.world > 1 else inf
+    opt = utils.optim.SGD(m.parameters(), 1e-3, momentum=0.9)
+    d = {k: v.to(ctx.dev) for k, v in bench_data.labels(B, S, C, seed=72 + ctx.rank).items()}
+    d['tensor'] = x
+    last = {}
+
+    def step(i):
+        last['r'] = y2train.iterate(m, opt, d, bench_data.HPARAM, bench_data.THRESHOLD, anchors)
+    for i in range(5):
+        step(i)
+    steps = 6
+    dt, host = ctx.timed(step, steps)
+    per_img = (3 * RESNET50_608_FWD_GFLOP - RESNET50_608_STEM_DGRAD_GFLOP) * 1e9
+    out['train'] = {'images_per_sec': round(B * steps * ctx.world / dt, 1), 'ms_per_step': round(dt / steps * 1e3, 3), 'host_ms_per_step': round(host / steps * 1e3, 3),
+                    'direct_equiv_tflops_per_gpu': round(per_img * B * steps / dt / 1e12, 2), 'loss_total': float(last['r']['loss_total'].detach())}
+    out['train']['direct_equiv_frac'] = round(out['train']['direct_equiv_tflops_per_gpu'] / PEAK_FP32_MFMA_TFLOPS, 4)
+    if ctx.world == 1:
+        graph, y2train.GRAPH = y2train.GRAPH, False
+        try:
+            step(0)
+            table = kernel_table(step, 2)
+        finally:
+            y2train.GRAPH = graph
+        roof = roofline_from(table, 'ResNet-50 608x608 COCO-80 training step, batch %d (same launch sequence issued eagerly under the event hooks)' % B)
+        out['train']['roofline'] = roof
+    del m, inf, dnn, opt
+    torch.cuda.empty_cache()
+    return out
 
 # ---------------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(sd, anchors, size, sample):
@@ -621,9 +798,54 @@ def cpu_baseline(sd, anchors, size, sample):
             for b in range(B):
                 odet.postprocess(iou[b], mn[b], mx[b], prob[b], fix=True)
         dt = time.perf_counter() - t0
+
+        def one_image(img):
+            feat = odark.forward(img, sd)
+            pred = ohead.decode(feat, anchors)
+            prob = torch.softmax(pred['logits'], -1).view(1, -1, pred['logits'].shape[-1]).numpy()
+            return odet.postprocess(pred['iou'].reshape(-1).numpy(), pred['yx_min'].reshape(-1, 2).numpy(), pred['yx_max'].reshape(-1, 2).numpy(), prob[0], fix=True)
+        # ---- BASELINE configs[0]: the reference's own usage, ONE image per call (detect.py:141-153)
+        one_image(x[:1])
+        n1 = 8
+        t0 = time.perf_counter()
+        for i in range(n1):
+            one_image(x[i:i + 1])
+        b1_ms = (time.perf_counter() - t0) / n1 * 1e3
+    # ---- one batch-8 training step (train.py:338-362 semantics: fwd with batch statistics + region loss + backward + SGD), SURVEY.md 8d
+    from oracle import loss as oloss
+    Bt = 8
+    sdt = {k: v.clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    opt = torch.optim.SGD([v for v in sdt.values() if v.requires_grad], 1e-3, momentum=0.9)
+    xt = bench_data.images(Bt, size, seed=11)
+    lab = bench_data.labels(Bt, size, 20, seed=2)
+    rows = size // 32
+    scale = torch.tensor([rows / size, rows / size]).view(1, 1, 2)
+    data = dict(yx_min=lab['yx_min'] * scale, yx_max=lab['yx_max'] * scale, cls=lab['cls'])
+    tt = []
+    for i in range(3):
+        t0 = time.perf_counter()
+        lo, _ = oloss.loss(anchors, data, ohead.decode(odark.forward(xt, sdt, training=True), anchors), bench_data.THRESHOLD)
+        opt.zero_grad()
+        oloss.total(lo, bench_data.HPARAM).backward()
+        opt.step()
+        tt.append(time.perf_counter() - t0)
+    train_s = min(tt[1:])
+    # ---- greedy NMS at n = 200 candidates (utils/postprocess.py:23-49), the reference's per-image post-processing cost
+    from oracle import nms as onms
+    from oracle import synth
+    sc, mn, mx = synth.nms_boxes(200)
+    onms.nms(sc, mn, mx, 0.45, 200)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        onms.nms(sc, mn, mx, 0.45, 200)
+    nms_ms = (time.perf_counter() - t0) / 20 * 1e3
     return {'value': round(sample / dt, 3), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': '%d synthetic %dx%d images in batches of 16, oracle conv stack (torch-CPU fp32, best of %d/%d/%d/%d threads) + decode + filter(fix=1) + NMS, %.1f s'
-                      % (sample, size, size, cores, cores // 2, cores // 4, cores // 8, dt)}
+                      % (sample, size, size, cores, cores // 2, cores // 4, cores // 8, dt),
+            'b1_ms_per_image': round(b1_ms, 2), 'b1_images_per_sec': round(1e3 / b1_ms, 2), 'b1_sample': '%d calls of ONE %dx%d image: conv stack + decode + filter + NMS (BASELINE configs[0], detect.py:141-153)' % (n1, size, size),
+            'train_b8_images_per_sec': round(Bt / train_s, 3), 'train_b8_s_per_step': round(train_s, 3),
+            'train_b8_sample': 'best of 2 batch-8 %dx%d VOC-20 steps after one warm-up: oracle fwd (batch-stat BN) + region loss + torch-CPU autograd + SGD' % (size, size),
+            'nms_n200_ms': round(nms_ms, 3), 'nms_sample': 'oracle.nms (numpy restatement of utils/postprocess.py:23-49), 200 candidates, overlap 0.45, mean of 20 calls'}
 
 
 # ---------------------------------------------------------------------------------------------------- dry run (no GPU)
@@ -689,7 +911,7 @@ def main():
 
     det = roof = state = anchors = None
     if args.multiscale:
-        args.no_detect = args.no_train = args.no_conv3 = True
+        args.no_detect = args.no_train = args.no_conv3 = args.no_latency = args.no_resnet = True
         args.cpu_sample = 0
     if not args.no_detect:
         det, roof, state, anchors = detect_leg(args, ctx)
@@ -713,6 +935,22 @@ def main():
             import traceback
             traceback.print_exc()
             tr = {'error': '%s: %s' % (type(e).__name__, e)}
+    lat = rn = None
+    if ctx.world == 1 and args.model == 'darknet' and not args.no_latency and not args.no_detect:
+        try:
+            lat = latency_leg(args, ctx)
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            lat = {'error': '%s: %s' % (type(e).__name__, e)}
+    if args.model == 'darknet' and not args.no_resnet and not args.no_train:
+        ctx.sync()
+        try:
+            rn = resnet_leg(args, ctx)
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            rn = {'error': '%s: %s' % (type(e).__name__, e)}
     ms = None
     if args.multiscale or (not args.no_multiscale and not args.no_train and args.model == 'darknet'):
         ctx.sync()
@@ -743,7 +981,10 @@ def main():
         # ---- scalars the driver's record keeps (it preserves the scalar members of `roofline`, `config`, `cpu_baseline`)
         extra = {}
         if ok(tr):
-            extra.update(train_images_per_sec=tr['images_per_sec'], train_ms_per_step=tr['ms_per_step'], train_host_ms_per_step=tr['host_ms_per_step'])
+            extra.update(train_images_per_sec=tr['images_per_sec'], train_ms_per_step=tr['ms_per_step'], train_host_ms_per_step=tr['host_ms_per_step'],
+                         train_host_issue_ms_per_step=tr.get('host_issue_ms_per_step'))
+            if 'dp_exposed_comm_ms_per_step' in tr:
+                extra['train_dp_exposed_comm_ms_per_step'] = tr['dp_exposed_comm_ms_per_step']
             r = tr.get('roofline')
             if r:
                 extra.update(train_traffic_bytes_per_step=r.get('traffic'), train_mfma_frac=r['all_mfma_kernels']['frac'], train_mfma_ms_per_step=r['all_mfma_kernels']['ms_per_step'],
@@ -754,7 +995,25 @@ def main():
             extra['conv3x3_b64_ms'] = conv3['autotuned']['ms']
             if 'direct_only' in conv3:
                 extra['conv3x3_b64_direct_only_util'] = conv3['direct_only']['mfma_utilisation']
+        if ok(lat):
+            for B in (1, 8):
+                e = lat['b%d' % B]
+                extra.update({'latency_b%d_ms' % B: e['ms_per_step'], 'latency_b%d_launches' % B: e['launches_per_step'], 'latency_b%d_frac_of_%s_floor' % (B, e['bound']): e['frac_of_bound'],
+                              'latency_b%d_winograd_layers' % B: e['winograd_layers']})
+        if ok(rn):
+            extra.update(resnet50_608_detect_images_per_sec=rn['detect']['images_per_sec'], resnet50_608_detect_direct_equiv_frac=rn['detect']['direct_equiv_frac'],
+                         resnet50_608_train_images_per_sec=rn['train']['images_per_sec'], resnet50_608_train_ms_per_step=rn['train']['ms_per_step'],
+                         resnet50_608_train_direct_equiv_frac=rn['train']['direct_equiv_frac'], resnet50_608_train_host_ms_per_step=rn['train']['host_ms_per_step'])
+            r = rn['train'].get('roofline')
+            if r:
+                extra.update(resnet50_608_train_mfma_frac=r['all_mfma_kernels']['frac'], resnet50_608_train_mfma_ms_per_step=r['all_mfma_kernels']['ms_per_step'],
+                             resnet50_608_train_kernel_ms_sum=r['kernel_ms_per_step'])
+                for row in r.get('top_kernels', [])[:8]:
+                    if row['frac'] is not None:
+                        extra['resnet50_frac_' + row['kernel'].replace('[', '_').replace(']', '').replace('<', '_').replace('>', '').replace(',', '_').replace(' ', '')] = row['frac']
         if ok(ms):
+            for S, v in ms.get('host_issue_ms_per_step', {}).items():
+                extra['multiscale_host_issue_ms_s%s' % S] = v
             extra.update(multiscale_images_per_sec=ms['images_per_sec'], multiscale_ms_per_step_mean=ms['ms_per_step_mean'], multiscale_switch_cost_ms_mean=ms['switch_cost_ms_mean'],
                          multiscale_switch_cost_ms_max=ms['switch_cost_ms_max'], multiscale_first_visit_ms_mean=ms['first_visit_ms_mean'])
         if ok(det):
@@ -791,6 +1050,10 @@ def main():
             out['train'] = dict(tr, workload=tr_workload)
         if ms is not None:
             out['multiscale'] = ms
+        if lat is not None:
+            out['latency'] = lat
+        if rn is not None:
+            out['resnet50_608'] = rn
         if roof is not None:
             tables = {k: roof.pop(k) for k in ('top_kernels', 'definition', 'split_bf16x6', 'split_f16x3', 'direct_only', 'conv_chain', 'all_mfma_kernels') if k in roof}
             out['detect_kernel_table'] = tables
@@ -801,6 +1064,11 @@ def main():
                 out['cpu_baseline'] = cpu_baseline(state, anchors, args.size, args.cpu_sample)
             except Exception as e:
                 out['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        cb = out.get('cpu_baseline') or {}
+        if 'b1_ms_per_image' in cb:
+            extra.update(cpu_b1_ms=cb['b1_ms_per_image'], cpu_train_b8_img_s=cb['train_b8_images_per_sec'], cpu_nms_n200_ms=cb['nms_n200_ms'])
+            if out.get('roofline') is not None:
+                out['roofline'].update(cpu_b1_ms=cb['b1_ms_per_image'], cpu_train_b8_img_s=cb['train_b8_images_per_sec'], cpu_nms_n200_ms=cb['nms_n200_ms'])
         out['summary'] = dict(extra, headline=headline, value=value, unit='images/sec', n_gpus=ctx.world,
                               roofline_kernel=(roof or {}).get('kernel'), roofline_frac=(roof or {}).get('frac'),
                               cpu_baseline_images_per_sec=(out.get('cpu_baseline') or {}).get('value'))

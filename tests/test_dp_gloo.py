@@ -289,3 +289,39 @@ def test_bench_self_launches_ranks_dry_run():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '1'],
                          capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'))
     assert bad.returncode != 0 and 'WORLD_SIZE=1' in (bad.stderr + bad.stdout)
+
+
+def test_buckets_follow_the_plugins_backward_order_and_keep_one_dimensional_parameters_apart():
+    """The all-reduce of a bucket can start when its LAST gradient exists.  Darknet's backward finishes weights in the order layers3,
+    layers2, passthrough, layers1 and hands the BatchNorm / bias gradients of all layers out together at the very end: buckets must
+    hold weights in that order and keep every one-dimensional parameter in the last bucket, or no bucket completes before the end."""
+    import configparser
+    for p in (ROOT, APP):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import model
+    import model.yolo2
+    import train
+    from oracle import darknet as odark
+    from oracle import synth
+    from oracle.make_golden import NARROW
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), RANK='0', WORLD_SIZE='1')
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        cfg = configparser.ConfigParser()
+        cfg.read_dict({'batch_norm': {'enable': '1'}})
+        anchors = torch.from_numpy(synth.ANCHORS_VOC)
+        sd = odark.init_state_dict(5, 20, seed=0, channels=NARROW)
+        dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, 20)
+        dp = train.DataParallelRCCL(model.Inference(cfg, dnn, anchors), bucket_bytes=2048)
+        assert len(dp._buckets) > 4
+        assert all(p.dim() <= 1 for p in dp._buckets[-1]) and all(p.dim() > 1 for b in dp._buckets[:-1] for p in b)
+        flat = [p for b in dp._buckets[:-1] for p in b]
+        want = dnn.backward_param_order()
+        assert [id(p) for p in flat] == [id(p) for p in want]
+        names = {id(p): n for n, p in dnn.named_parameters()}
+        order = [names[id(p)] for p in flat]
+        assert order[0] == 'layers3.1.conv.weight' and order.index('passthrough.conv.weight') > order.index('layers2.1.conv.weight')
+        assert sorted(id(p) for b in dp._buckets for p in b) == sorted(id(p) for p in dnn.parameters())
+    finally:
+        dist.destroy_process_group()

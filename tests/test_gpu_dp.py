@@ -246,7 +246,7 @@ def test_bench_two_ranks_share_the_one_gpu():
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(Y2_DIST_BACKEND='gloo', Y2_BENCH_DEVICE='0')
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--train-steps', '3', '--cpu-sample', '0'],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--train-steps', '3', '--cpu-sample', '0', '--no-resnet'],
                          capture_output=True, text=True, timeout=850, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]

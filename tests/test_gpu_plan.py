@@ -1,0 +1,285 @@
+"""A training step as a StepPlan (model.train_graph.StepPlan / train.StepRunner): the launch sequence of train.py:344-351 issued
+without autograd and, after the warm-up steps, replayed from captured hipGraph segments.  It must be the SAME step as the autograd
+path: same losses, same gradients, same running statistics, same parameters after a few optimizer steps - with labels whose box
+count changes from step to step (the static label buffers are zero-padded), for every plugin, and under the data-parallel wrapper
+(two ranks, also with one rank on the graph path and the other on the autograd path: the collective sequences must match)."""
+import configparser
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from oracle import darknet as odark
+from oracle import loss as oloss
+from oracle import synth
+from oracle.make_golden import NARROW
+
+pytestmark = pytest.mark.gpu
+
+# What separates two runs of the same step on the GPU: completion-order fp32 / fp64 atomics (split-K weight gradients, BatchNorm sums).
+# The comparisons below therefore run with learning rate 0 - every step is the same function of (weights, batch), whichever path issues
+# it - and hold losses / predictions to fp32 rounding and gradients to that noise.  (Trajectories of a 27-samples-per-channel BatchNorm
+# network are chaotic: one IoU crossing the 0.6 background threshold moves a loss term by 1 %; comparing them says nothing about the path.)
+# That replayed graphs really train is checked separately against an autograd witness on the weights they produced.
+STEP_TOL = 2e-5
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def rel(got, ref):
+    rms = ref.double().pow(2).mean().sqrt().item()
+    return (got.double() - ref.double()).abs().max().item() / max(rms, 1e-30)
+
+
+def darknet_sd():
+    widths = dict(NARROW)
+    widths['layers1.5'] = 8
+    return odark.init_state_dict(5, 20, seed=0, channels=widths, head_scale=1 / 8.0)
+
+
+def build(kind, sd=None, C=20):
+    import model
+    import model.resnet
+    import model.yolo2
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1'}, 'model': {'pretrained': '0'}})
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    if kind == 'darknet':
+        sd = darknet_sd() if sd is None else sd
+        dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, C)
+    elif kind == 'tiny':
+        sd = odark.init_tiny_state_dict(5, C, seed=0, div=4, head_scale=0.25)
+        dnn = model.yolo2.Tiny(model.ConfigChannels(cfg, sd), anchors, C)
+    else:
+        from oracle import resnet as ores
+        sd = ores.init_state_dict(kind, 5, C, seed=0, width=8, head_scale=0.25)
+        dnn = getattr(model.resnet, kind)(model.ConfigChannels(cfg, sd), anchors, C)
+    dnn.load_state_dict(sd, strict=False)
+    return model.Inference(cfg, dnn, anchors).to(dev()).train(), anchors
+
+
+def batches(S, B, C=20, onehot=False):
+    """Three batches with different maximum box counts (5, 8, 3 rows): the plan pads all of them to one static label buffer."""
+    out = []
+    for i, nmax in enumerate((5, 8, 3)):
+        d = {k: v.to(dev()) for k, v in synth.labels(B, S, C, nmax=nmax, seed=20 + i, onehot=onehot).items()}
+        d['tensor'] = synth.images(B, S, seed=30 + i).to(dev())
+        out.append(d)
+    return out
+
+
+def run_steps(kind, data, steps, plan, graph, onehot=False, lr=0.0):
+    import train as y2train
+    import utils
+    y2train.PLAN, y2train.GRAPH = plan, graph
+    try:
+        inf, anchors = build(kind)
+        opt = utils.optim.SGD(inf.parameters(), lr, momentum=0.9)
+        losses, grads = [], None
+        for i in range(steps):
+            r = y2train.iterate(inf, opt, data[i % len(data)], oloss.HPARAM, 0.6, anchors)
+            losses.append([float(r['loss'][k].detach()) for k in r['loss']] + [float(r['loss_total'].detach())])
+            if i == steps - 1:
+                grads = {k: p.grad.detach().clone() for k, p in inf.dnn.named_parameters()}
+                pred = {k: v.detach().clone() for k, v in r['pred'].items()}
+                pos = r['debug']['positive'].clone()
+        torch.cuda.synchronize()
+        runner = inf.__dict__.get('_y2_step_runner')
+        return dict(losses=losses, grads=grads, pred=pred, pos=pos, params={k: v.detach().clone() for k, v in inf.dnn.state_dict().items()}, runner=runner)
+    finally:
+        y2train.PLAN, y2train.GRAPH = True, True
+
+
+def assert_same_run(a, b, what, tol=STEP_TOL):
+    np.testing.assert_allclose(np.array(a['losses']), np.array(b['losses']), rtol=2e-5, err_msg=what)
+    for k in a['params']:
+        if a['params'][k].dtype.is_floating_point:
+            e = rel(b['params'][k], a['params'][k])
+            assert e <= tol, (what, k, e)
+        else:
+            assert torch.equal(a['params'][k], b['params'][k]), (what, k)          # num_batches_tracked: incremented by every replay
+    for k in a['grads']:
+        assert rel(b['grads'][k], a['grads'][k]) <= 50 * tol, (what, 'grad', k, rel(b['grads'][k], a['grads'][k]))
+    for k in a['pred']:
+        assert a['pred'][k].shape == b['pred'][k].shape and rel(b['pred'][k], a['pred'][k]) <= 5 * tol, (what, 'pred', k, rel(b['pred'][k], a['pred'][k]))
+    assert torch.equal(a['pos'], b['pos']), what
+
+
+@pytest.mark.parametrize('onehot', [False, True])
+def test_darknet_step_plan_equals_autograd_eager_and_replayed(onehot):
+    S, B, steps = 96, 3, 7
+    data = batches(S, B, onehot=onehot)
+    run_steps('darknet', data, 4, plan=False, graph=False, onehot=onehot)          # the per-layer algorithm table is measured once: every compared run sees the same one
+    ref = run_steps('darknet', data, steps, plan=False, graph=False, onehot=onehot)
+    assert ref['runner'] is None
+    eager = run_steps('darknet', data, steps, plan=True, graph=False, onehot=onehot)
+    assert eager['runner'] is not None and eager['runner'].captures == 0 and not eager['runner'].broken
+    assert_same_run(ref, eager, 'plan, eager launches')
+    graphed = run_steps('darknet', data, steps, plan=True, graph=True, onehot=onehot)
+    r = graphed['runner']
+    assert r.captures == 1 and not r.broken and len(r.plans) == 1          # one shape, box counts 5 / 8 / 3 all padded to 8 rows
+    plan = next(iter(r.plans.values()))
+    assert [op[0] for op in plan.ops] == ['graph'] and plan.calls == steps         # single GPU: the whole step is ONE graph
+    assert_same_run(ref, graphed, 'plan, hipGraph replays')
+
+
+@pytest.mark.parametrize('kind', ['tiny', 'resnet18', 'resnet50'])
+def test_other_plugins_step_plan_equals_autograd(kind):
+    S, B, steps = 96, 3, 6
+    data = batches(S, B)
+    run_steps(kind, data, 4, plan=False, graph=False)
+    ref = run_steps(kind, data, steps, plan=False, graph=False)
+    graphed = run_steps(kind, data, steps, plan=True, graph=True)
+    assert graphed['runner'].captures == 1 and not graphed['runner'].broken
+    # ~50 batch-statistics BatchNorm layers on 27 samples per channel amplify the atomics' order noise in the ResNets' gradients
+    assert_same_run(ref, graphed, kind, tol=STEP_TOL if kind == 'tiny' else 1e-4)
+
+
+def test_step_plans_per_input_size_and_box_count_share_one_pool():
+    """Multi-scale schedule (utils/data.py:135-141) + a batch whose box count outgrows the padded label buffer: one plan per
+    (size, padded count), warm-up counted per size, every plan replaying correctly after the others ran (they share one memory pool)."""
+    import train as y2train
+    import utils
+    inf, anchors = build('darknet')
+    opt = utils.optim.SGD(inf.parameters(), 1e-3, momentum=0.9)
+    data = {}
+    for S in (96, 128):
+        for nmax in (6, 14):
+            d = {k: v.to(dev()) for k, v in synth.labels(2, S, 20, nmax=nmax, seed=S + nmax).items()}
+            d['tensor'] = synth.images(2, S, seed=S).to(dev())
+            data[S, nmax] = d
+    order = [(96, 6)] * 5 + [(128, 6)] * 5 + [(96, 14)] * 2 + [(128, 14)] * 2 + [(96, 6), (128, 6), (96, 14), (128, 14)] * 2
+    first = {}
+    for i, key in enumerate(order):
+        r = y2train.iterate(inf, opt, data[key], oloss.HPARAM, 0.6, anchors)
+        lt = float(r['loss_total'])
+        assert np.isfinite(lt), (i, key)
+        first.setdefault(key, lt)
+    runner = inf.__dict__['_y2_step_runner']
+    assert len(runner.plans) == 4 and runner.captures == 4 and not runner.broken
+    assert all(p.ops is not None for p in runner.plans.values())
+    # the (.., 14) plans were captured at their FIRST call: the size was already measured
+    assert sorted(p.static['npad'] for p in runner.plans.values()) == [8, 8, 16, 16]
+    # an autograd-path witness on the final weights agrees with the next replay of every plan
+    for key in data:
+        y2train.PLAN = False
+        try:
+            wit, _ = build('darknet', sd={k: v.clone() for k, v in inf.dnn.state_dict().items()})
+            wopt = utils.optim.SGD(wit.parameters(), 0.0)
+            w = y2train.iterate(wit, wopt, data[key], oloss.HPARAM, 0.6, anchors)
+        finally:
+            y2train.PLAN = True
+        zopt = utils.optim.SGD(inf.parameters(), 0.0)
+        r = y2train.iterate(inf, zopt, data[key], oloss.HPARAM, 0.6, anchors)
+        np.testing.assert_allclose(float(r['loss_total']), float(w['loss_total']), rtol=2e-5)
+        for (k, a), (_, b) in zip(inf.dnn.named_parameters(), wit.dnn.named_parameters()):
+            assert rel(a.grad, b.grad) <= 1e-3, (key, k, rel(a.grad, b.grad))
+
+
+def test_eval_and_detect_see_the_weights_a_replayed_step_wrote():
+    """The replayed graph updates parameters (through the eager optimizer) and BatchNorm buffers (inside the graph, raw pointers):
+    the eval-mode caches must follow (version counters advanced per replay)."""
+    import model
+    import train as y2train
+    import utils
+    inf, anchors = build('darknet')
+    opt = utils.optim.SGD(inf.parameters(), 1e-2, momentum=0.9)
+    data = batches(96, 3)
+    x = data[0]['tensor']
+    for i in range(6):
+        y2train.iterate(inf, opt, data[i % 3], oloss.HPARAM, 0.6, anchors)
+        inf.eval()
+        with torch.no_grad():
+            got = model._inference(inf, x)['feature'].clone()
+        wit, _ = build('darknet', sd={k: v.clone() for k, v in inf.dnn.state_dict().items()})
+        wit.eval()
+        with torch.no_grad():
+            want = model._inference(wit, x)['feature']
+        assert torch.equal(got, want), i
+        inf.train()
+
+
+# ------------------------------------------------------------------------------------------------ data parallel, two ranks
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _dp_rank(rank, world, port, tmp, modes):
+    import sys
+    from conftest import APP, ROOT
+    for p in (ROOT, APP):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    rccl = torch.cuda.device_count() >= world and os.environ.get('Y2_TEST_DP_BACKEND', 'auto') != 'gloo'
+    if rccl:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        os.environ.pop('Y2_DIST_BACKEND', None)
+    else:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', Y2_DIST_BACKEND='gloo')
+    import train as y2train
+    import utils
+    assert y2train.init_distributed() == world
+    y2train.PLAN, y2train.GRAPH = modes[rank]
+    inf, anchors = build('darknet')
+    m = y2train.ensure_model(inf)
+    assert isinstance(m, y2train.DataParallelRCCL)
+    m.bucket_bytes = 4096
+    m._build_buckets()                       # many small buckets: several segment cuts inside backward
+    opt = utils.optim.SGD(m.parameters(), 0.0, momentum=0.9)          # learning rate 0: every step is the same function of (weights, shard)
+    S, B = 96, 4
+    per = B // world
+    data = []
+    for i, nmax in enumerate((5, 8, 3)):
+        d = {k: v[rank * per:(rank + 1) * per].cuda() for k, v in synth.labels(B, S, 20, nmax=nmax, seed=20 + i).items()}
+        d['tensor'] = synth.images(B, S, seed=30 + i)[rank * per:(rank + 1) * per].cuda()
+        data.append(d)
+    losses = []
+    for i in range(7):
+        r = y2train.iterate(m, opt, data[i % 3], oloss.HPARAM, 0.6, anchors)
+        losses.append([float(r['loss'][k].detach()) for k in r['loss']])
+    torch.cuda.synchronize()
+    runner = inf.__dict__.get('_y2_step_runner')
+    ops = None
+    if runner is not None and runner.plans:
+        plan = next(iter(runner.plans.values()))
+        ops = None if plan.ops is None else [op[0] for op in plan.ops]
+    torch.save({'losses': losses, 'params': {k: v.cpu() for k, v in inf.dnn.state_dict().items()}, 'grads': {k: p.grad.cpu() for k, p in inf.dnn.named_parameters()},
+                'ops': ops, 'captures': None if runner is None else runner.captures}, os.path.join(tmp, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_dp_world2_graph_segments_interoperate_with_the_hook_path(tmp_path):
+    """Two ranks x 7 steps: (a) both on the autograd / hook path, (b) both replaying graph segments, (c) rank 0 on graphs and rank 1 on
+    hooks.  Same collectives in the same order in all three: the runs must agree (and not hang)."""
+    import torch.multiprocessing as mp
+    world = 2
+    out = {}
+    for name, modes in (('hooks', [(False, False)] * 2), ('graphs', [(True, True)] * 2), ('mixed', [(True, True), (False, False)])):
+        d = tmp_path / name
+        d.mkdir()
+        mp.spawn(_dp_rank, args=(world, _free_port(), str(d), modes), nprocs=world, join=True)
+        out[name] = [torch.load(str(d / ('rank%d.pt' % r)), weights_only=False) for r in range(world)]
+    g0 = out['graphs'][0]
+    assert g0['captures'] == 1 and g0['ops'].count('graph') >= 3 and 'npos' in g0['ops'] and 'buckets' in g0['ops'], g0['ops']
+    assert out['mixed'][0]['captures'] == 1 and out['mixed'][1]['captures'] is None
+    for name in ('graphs', 'mixed'):
+        for r in range(world):
+            np.testing.assert_allclose(np.array(out[name][r]['losses']), np.array(out['hooks'][r]['losses']), rtol=2e-5, err_msg='%s rank %d' % (name, r))
+            for k, v in out['hooks'][r]['params'].items():
+                if v.dtype.is_floating_point and 'running' not in k:
+                    assert rel(out[name][r]['params'][k], v) <= STEP_TOL, (name, r, k, rel(out[name][r]['params'][k], v))
+        # replicas stay identical: both ranks hold the same averaged gradients and parameters
+        for k, v in out[name][0]['grads'].items():
+            assert torch.equal(v, out[name][1]['grads'][k]), (name, k)
+            assert rel(v, out['hooks'][0]['grads'][k]) <= 50 * STEP_TOL, (name, 'grad', k)

@@ -166,7 +166,11 @@ def lib():
     return _lib
 
 
+LAUNCHES = [0]      # library entry points that returned through check(): what a capture segment counts to know it is not empty
+
+
 def check(rc, what):
+    LAUNCHES[0] += 1
     if rc != 0:
         if rc <= -1000:
             raise RuntimeError('%s: HIP error %d' % (what, -rc - 1000))
@@ -270,16 +274,28 @@ def colstats_det(z, M, C, ld, stats):
 
 
 _WS = {}
+# A hipGraph bakes in the addresses of every scratch buffer its kernels were launched with.  The process-wide scratch caches
+# (_WS, _WGRAD_WS) grow by REPLACING their tensor, which would leave a captured graph writing into memory the allocator has handed to
+# somebody else - so while a training step is being captured (model.train_graph.StepPlan) SCOPE points at a dict owned by that plan and
+# every cache lookup below goes there instead: the plan's scratch lives exactly as long as its graphs.
+SCOPE = None
+
+
+def _cache(d):
+    if SCOPE is None:
+        return d
+    return SCOPE.setdefault(('_hip', id(d)), {})
 
 
 def workspace(dev, nbytes):
     """Per-device scratch for the conv split-K remainder scheme (grows on demand; consecutive convolutions on one stream
     may share it: a layer's fix-up kernel has consumed it before the next layer's main kernel starts)."""
     key = str(dev)
-    t = _WS.get(key)
+    ws = _cache(_WS)
+    t = ws.get(key)
     if t is None or t.numel() * 4 < nbytes:
         t = torch.empty(max(int(nbytes) // 4 + 4, 1024), dtype=torch.float32, device=dev)
-        _WS[key] = t
+        ws[key] = t
     return t
 
 
@@ -604,10 +620,10 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
     if native is not None and choice in (1, 2) and eligible_wino(cout, cin, k, ldx, ldz):
         assert native.numel() == nw and native.is_contiguous()
         need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
-        ws = _WGRAD_WS.get(str(dev))
+        ws = _cache(_WGRAD_WS).get(str(dev))
         if ws is None or ws.numel() * 4 < need:
             ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=dev)
-            _WGRAD_WS[str(dev)] = ws
+            _cache(_WGRAD_WS)[str(dev)] = ws
         check(L.y2_wino_wgrad_ex(ptr(x), ptr(dz), ptr(native), B, H, W, cin, ldx, cout, ldz, ptr(v) if choice == 1 else None, ptr(ws), ws.numel() * 4,
                                  1 if choice == 1 else 3, st), 'y2_wino_wgrad_ex')
         return native
@@ -622,10 +638,10 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
         direct()
         return dwp
     need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
-    ws = _WGRAD_WS.get(str(dev))
+    ws = _cache(_WGRAD_WS).get(str(dev))
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=dev)
-        _WGRAD_WS[str(dev)] = ws
+        _cache(_WGRAD_WS)[str(dev)] = ws
 
     def wino():
         check(L.y2_wino_wgrad(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, ptr(v), ptr(ws), ws.numel() * 4, st), 'y2_wino_wgrad')

@@ -318,6 +318,56 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
     }
 }
 
+// The same for 4 channels per thread (all strides multiples of 4, 16-byte aligned): one row of the image per blockIdx.y, 16-byte loads, no
+// 64-bit divisions.  The stem pool of the ResNets at 608x608 (757 MB of input at batch 32) took 5.3 ms in the scalar form.
+__global__ void maxpool_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ dy2, float* __restrict__ dx,
+                                    int H, int W, int Ho, int Wo, int C4, int ldx, int ldy, int lddx, int k, int stride, int pad) {
+    const int row = blockIdx.y;                    // b * H + yy
+    const int b = row / H, yy = row - b * H;
+    const int oy_hi = min(Ho - 1, (yy + pad) / stride);
+    int oy_lo = (yy + pad - k + stride) / stride; if (yy + pad - k + 1 < 0 || oy_lo < 0) oy_lo = 0;
+    const float* xb = x + (size_t)b * H * W * ldx;
+    const float* dyb = dy + (size_t)b * Ho * Wo * ldy;
+    const float* dy2b = dy2 ? dy2 + (size_t)b * Ho * Wo * ldy : nullptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W * C4; i += gridDim.x * blockDim.x) {
+        const int xx = i / C4, c = (i - xx * C4) * 4;
+        const int ox_hi = min(Wo - 1, (xx + pad) / stride);
+        int ox_lo = (xx + pad - k + stride) / stride; if (xx + pad - k + 1 < 0 || ox_lo < 0) ox_lo = 0;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+                int4 at = make_int4(-1, -1, -1, -1);              // flat window position (ky * k + kx) of the first maximum per channel
+                int mine = -1;
+                for (int ky = 0; ky < k; ++ky) {
+                    const int y2 = oy * stride - pad + ky;
+                    if ((unsigned)y2 >= (unsigned)H) continue;
+                    for (int kx = 0; kx < k; ++kx) {
+                        const int x2 = ox * stride - pad + kx;
+                        if ((unsigned)x2 >= (unsigned)W) continue;
+                        const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)y2 * W + x2) * ldx + c);
+                        const int pos = ky * k + kx;
+                        if (y2 == yy && x2 == xx) mine = pos;
+                        if (at.x < 0 || v.x > best.x) { best.x = v.x; at.x = pos; }
+                        if (at.y < 0 || v.y > best.y) { best.y = v.y; at.y = pos; }
+                        if (at.z < 0 || v.z > best.z) { best.z = v.z; at.z = pos; }
+                        if (at.w < 0 || v.w > best.w) { best.w = v.w; at.w = pos; }
+                    }
+                }
+                if (at.x == mine || at.y == mine || at.z == mine || at.w == mine) {
+                    const size_t o = ((size_t)oy * Wo + ox) * ldy + c;
+                    float4 d = *reinterpret_cast<const float4*>(dyb + o);
+                    if (dy2b != nullptr) { const float4 e = *reinterpret_cast<const float4*>(dy2b + o); d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
+                    if (at.x == mine) g.x += d.x;
+                    if (at.y == mine) g.y += d.y;
+                    if (at.z == mine) g.z += d.z;
+                    if (at.w == mine) g.w += d.w;
+                }
+            }
+        *reinterpret_cast<float4*>(dx + ((size_t)row * W + xx) * lddx + c) = g;
+    }
+}
+
 // per-channel column sums of a [M, C] (stride ld) matrix -> fp64 atomics (conv-bias gradient of blocks without BN)
 __global__ void colsum_kernel(const float* __restrict__ x, long long M, int C, int ld, double* out) {
     extern __shared__ float red[];
@@ -761,6 +811,13 @@ extern "C" int y2_maxpool_bwd(const float* x, const float* dy, const float* dy2,
     const int Ho = (H + pad + pad_end - ksize) / stride + 1, Wo = (W + pad + pad_end - ksize) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return Y2_EINVAL;
     const long long total = (long long)B * H * W * C;
+    if (!(C & 3) && !(ldx & 3) && !(ldy & 3) && !(lddx & 3) && y2_aligned16(x) && y2_aligned16(dy) && y2_aligned16(dx) && (!dy2 || y2_aligned16(dy2)) && (long long)B * H < 65535
+        && (long long)H * W * ldx < 0x7fffffffLL) {
+        const int per_row = W * (C / 4);
+        Y2_LAUNCH("maxpool_bwd_kernel", 0.0, maxpool_bwd4_kernel, dim3((per_row + 255) / 256, B * H), dim3(256), 0, y2_s(stream), x, dy, dy2, dx, H, W, Ho, Wo, C / 4, ldx, ldy, lddx, ksize, stride, pad);
+        Y2_LAUNCH_CHECK();
+        return Y2_OK;
+    }
     Y2_LAUNCH("maxpool_bwd_kernel", 0.0, maxpool_bwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, y2_s(stream), x, dy, dy2, dx, H, W, Ho, Wo, C, ldx, ldy, lddx, ksize, stride, pad, total);
     Y2_LAUNCH_CHECK();
     return Y2_OK;

@@ -90,6 +90,18 @@ class ResNet(nn.Module):
         self.profile = None
         self.grad_ready_hook = None   # train.DataParallelRCCL: called as hook(param, grad) from inside backward
 
+    def backward_param_order(self):
+        """Convolution weights in the order the training backward finishes their gradients (the reverse of the forward's op list,
+        model.train_graph.ResNetTrainFn: stem, per block the projection shortcut then its convolutions, head)."""
+        fwd = [self.conv1]
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                if blk.downsample is not None:
+                    fwd.append(blk.downsample[0])
+                fwd += [conv for conv, _, _, _ in blk.convs()]
+        fwd.append(self.conv)
+        return [c.weight for c in reversed(fwd)]
+
     def scope(self, name):
         """Pruning helper (model/resnet.py:142-156): the block-level scope of a parameter name - 'layer1.0.conv2.weight' ->
         'layer1.0.2', 'layer2.0.downsample.0.weight' -> 'layer2.0', 'conv.weight' -> 'conv'."""

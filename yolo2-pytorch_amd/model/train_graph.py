@@ -36,6 +36,11 @@ def _side_stream(dev):
     return s
 
 
+# A captured StepPlan may fork the weight gradients onto the side stream like the eager backward does (joined before every segment end).
+# Measured at batch 64: the step gains 0.75 ms of GPU time (31.8 -> 31.05 ms at 416x416, 19.8 -> 18.9 at 320x320) and hipGraphLaunch of the
+# multi-branch graph costs 11.2 / 6.8 ms of HOST time per step against 0.27 ms for the linear graph - with eight ranks on one host the
+# linear graph is the safe choice; 1 = fork (A/B runs).
+GRAPH_FORK = os.environ.get('Y2_GRAPH_FORK', '0') == '1'
 GRAD_F43 = os.environ.get('Y2_GRAD_F43', '1') != '0'        # offer Winograd F(4x4,3x3) to the data gradients of the deep layers (A/B)
 FUSE_CONV0 = os.environ.get('Y2_FUSE_CONV0', '1') != '0'      # 0: materialise the first layer's dz and run the two-kernel form (A/B runs)
 DEBUG_TAP = None        # tools/debug: callable(block name, dz, dx) invoked per block of the Darknet backward
@@ -117,22 +122,27 @@ class _Block(object):
                  'out_full', 'out_pool', 'out_ld', 'out_off', 'out_mode', 'has_bn', 'slope', 'first', 'wino_v', 'eff')
 
 
-def _train_operands(dnn, dev):
+def _train_operands(dnn, dev, scope=None):
     """GEMM operands of every convolution block for one parameter version, produced by ONE y2_prep_weights launch from the
     state_dict layout: fprop pack, dgrad pack (rotated, in/out swapped) and, where the Winograd algorithm is eligible, both filter
     transforms.  The optimizer rewrites the weights every step, so this runs once per step (it used to be ~90 separate small
     launches: pack + transform per layer, forward and backward).  Returns {Conv2d block: dict(wp, wd, uf, ud)}; the first layer
     (y2_conv0_fwd reads the state_dict layout) and blocks whose output width is not a multiple of 4 (the 125 / 425-channel head: its
-    data gradient runs zero-padded) are left to the per-layer path."""
+    data gradient runs zero-padded) are left to the per-layer path.
+    scope: the buffer dict of a StepPlan - the operands are derived unconditionally (the launch must be part of every replay of the plan's
+    graph) into buffers that plan owns; the per-model cache is neither read nor written."""
     from model import yolo2 as _yolo2
     key = (dev, dnn._weight_versions(), _hip.split_mode(), _hip.WINOGRAD)       # the convolution weights only: the BatchNorm buffer updates of a forward pass do not move it
-    cache = getattr(dnn, '_train_cache', None)
-    if cache is not None and cache[0] == key:
-        return cache[1]
-    bufs = getattr(dnn, '_train_bufs', None)
-    if bufs is None or bufs[0] != dev:
-        bufs = (dev, {})
-        dnn._train_bufs = bufs
+    if scope is not None:
+        bufs = (dev, scope)
+    else:
+        cache = getattr(dnn, '_train_cache', None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        bufs = getattr(dnn, '_train_bufs', None)
+        if bufs is None or bufs[0] != dev:
+            bufs = (dev, {})
+            dnn._train_bufs = bufs
 
     def buf(tag, n):
         t = bufs[1].get(tag)
@@ -190,7 +200,8 @@ def _train_operands(dnn, dev):
                 d[tag + 's'] = planes[off:off + 16 * cout * cin]
             d['plane'] = usize
             off += 16 * cout * cin
-    dnn._train_cache = (key, ops)
+    if scope is None:
+        dnn._train_cache = (key, ops)
     return ops
 
 
@@ -285,7 +296,7 @@ def _effective(dnn, dev, frozen):
     return out
 
 
-def _darknet_fwd(ctx, dnn, x, params, frozen):
+def _darknet_fwd(ctx, dnn, x, params, frozen, scope=None):
     _hip.require_gpu(x)
     L = _hip.lib()
     st = _hip.stream()
@@ -296,7 +307,7 @@ def _darknet_fwd(ctx, dnn, x, params, frozen):
     dev = x.device
     b1, b2, b3 = dnn._blocks()
     eff = _effective(dnn, dev, frozen)
-    prepared = _train_operands(dnn, dev) if not any(e.padded for e in eff.values()) else {}
+    prepared = _train_operands(dnn, dev, scope) if not any(e.padded for e in eff.values()) else {}
     det = _hip.ensure_deterministic(dev)      # fixed-order reductions: BN statistics by y2_colstats_det instead of epilogue atomics
     # one zero-filled arena for every layer's replicated BN-statistics accumulators (one launch instead of 22 fills)
     arena = None
@@ -418,7 +429,8 @@ def _darknet_fwd(ctx, dnn, x, params, frozen):
     ctx.dnn = dnn
     ctx.blocks = blocks
     ctx.prepared = prepared
-    ctx.prepared_key = dnn._train_cache[0] if prepared else None
+    ctx.prepared_key = dnn._train_cache[0] if (prepared and scope is None) else None
+    ctx.scope = scope
     ctx.geom = (B, cin0, H, W, c_pt, c_l2)
     ctx.x = x
     ctx.frozen = frozen
@@ -431,7 +443,8 @@ def _darknet_bwd(ctx, dout):
     L = _hip.lib()
     st = _hip.stream()
     dnn, blocks = ctx.dnn, ctx.blocks
-    if ctx.prepared and (getattr(dnn, '_train_cache', (None, None))[0] != ctx.prepared_key or ctx.prepared_key[:2] != (dout.device, dnn._weight_versions())):
+    scope = getattr(ctx, 'scope', None)       # a StepPlan's pass: its operands were derived inside this very launch sequence, into buffers the plan owns
+    if ctx.prepared and scope is None and (getattr(dnn, '_train_cache', (None, None))[0] != ctx.prepared_key or ctx.prepared_key[:2] != (dout.device, dnn._weight_versions())):
         raise RuntimeError('model.yolo2: a convolution weight was modified (optimizer step, load_state_dict, in-place edit) between this forward and '
                            'its backward; the per-model GEMM operand buffers this graph was recorded against hold other weights now')
     B, cin0, H, W, c_pt, c_l2 = ctx.geom
@@ -463,17 +476,28 @@ def _darknet_bwd(ctx, dout):
     i_pass = idx['passthrough']
     order = list(range(n - 1, -1, -1))
     main = torch.cuda.current_stream(dev)
-    side = _side_stream(dev) if (BWD_STREAMS > 1 and not _hip.DETERMINISTIC and not torch.cuda.is_current_stream_capturing()) else None
+    # (under capture only a StepPlan - which joins the side stream before it ends a graph segment, ctx.join - may fork: an unjoined stream fails the capture)
+    side = _side_stream(dev) if (BWD_STREAMS > 1 and not _hip.DETERMINISTIC and (not torch.cuda.is_current_stream_capturing() or getattr(ctx, 'fork_ok', False))) else None
     late = []                                         # (parameter, gradient, event) of weight gradients still running on the side stream
+
+    def join():
+        for item in late:
+            if item[2] is not None:
+                main.wait_event(item[2])
+                item[2] = None           # (an event recorded in a capture that has ended must not be waited for in the next one)
+    ctx.join = join
     affine_grads = []                                 # (parameter, offset into sums_arena, length)
 
     # ---- everything that must start from zero, filled by ONE launch: the fp64 sums of all BatchNorm backward passes, the
     # accumulation targets of the direct (split, atomically added) weight gradients and the zero-padded gradient of an unaligned head
     sums_arena = torch.empty(2 * sum(b.cout for b in blocks), dtype=torch.float64, device=dev)
     zero = [sums_arena]
-    bufs = dnn.__dict__.setdefault('_train_bufs', (dev, {}))
-    if bufs[0] != dev:
-        bufs = dnn._train_bufs = (dev, {})
+    if scope is not None:
+        bufs = (dev, scope)
+    else:
+        bufs = dnn.__dict__.setdefault('_train_bufs', (dev, {}))
+        if bufs[0] != dev:
+            bufs = dnn._train_bufs = (dev, {})
 
     def persistent(tag, nel):
         t = bufs[1].get(tag)
@@ -511,7 +535,8 @@ def _darknet_bwd(ctx, dout):
     def flush_weight_grads(keep=0):
         while len(late) > keep:
             prm, g, evt = late.pop(0)
-            main.wait_event(evt)
+            if evt is not None:
+                main.wait_event(evt)
             ready(prm, g)
     for i in order:
         blk = blocks[i]
@@ -603,7 +628,7 @@ def _darknet_bwd(ctx, dout):
                 done.record(side)
             gw.record_stream(main)
             flush_weight_grads(keep=1)
-            late.append((weight, gw, done))
+            late.append([weight, gw, done])
         else:
             ready(weight, weight_grad(st))
         blk.wino_v = None
@@ -681,6 +706,7 @@ def _darknet_bwd(ctx, dout):
         out.append(grads.get(pid))
     ctx.blocks = None
     ctx.prepared = None
+    ctx.join = None
     return tuple(out)
 
 
@@ -696,7 +722,19 @@ class DarknetTrainFn(torch.autograd.Function):
 
 
 class _Tape(object):
-    """Stand-in for an autograd ctx when the training graph is run from inside another Function's backward."""
+    """Stand-in for an autograd ctx when the training graph is run from inside another Function's backward, or without autograd
+    at all (StepPlan): carries what forward() leaves for backward()."""
+    need_dx = False
+    saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
 
 
 class DarknetEvalGradFn(torch.autograd.Function):
@@ -1172,3 +1210,311 @@ class ResNetTrainFn(torch.autograd.Function):
             out.append(grads.get(pid))
         ctx.ops = None
         return tuple(out)
+
+
+# ------------------------------------------------------------------------------------------------ a training step as a plan
+# The reference's step is three Python calls - `_inference`, `loss`, `loss_total.backward()` (train.py:344-351) - and on the autograd
+# path above every one of the ~270 kernels behind them is a ctypes call issued from Python, one by one, every step: 6-18 ms of host
+# time per step, more than half of the GPU time of a 320x320 step, and with eight ranks sharing one host the part that scales worst.
+# A StepPlan runs the SAME launch sequence (the forward / backward bodies of the Functions above, called directly with _Tape objects:
+# no autograd bookkeeping) on static input buffers, and captures it once per problem shape into hipGraph segments; a later step is a
+# copy into the input buffers plus one graph launch per segment.  Segments end where the data-parallel wrapper has a collective to
+# issue (the positive-count sum inside the loss, every gradient bucket that completes during backward): RCCL calls stay ordinary
+# eager calls between two graph launches, in the same order and with the same payloads as on the autograd path, so ranks in graph
+# mode and ranks still warming up on another input size interoperate.
+class _Segments(object):
+    """Capture state of one StepPlan pass: a list of ops - ('graph', CUDAGraph) | ('npos', tensor) | ('buckets', lo, hi) - in issue order."""
+
+    def __init__(self, pool, mode):
+        self.pool, self.mode = pool, mode
+        self.ops, self.graph, self.mark = [], None, 0
+
+    def begin(self):
+        self.graph = torch.cuda.CUDAGraph()
+        # thread_local: calls other threads make meanwhile (a pinned-memory loader thread, RCCL's watchdog) must not abort the capture
+        self.graph.capture_begin(pool=self.pool, capture_error_mode='thread_local')
+        self.mark = _hip.LAUNCHES[0]
+
+    def cut(self, op):
+        """A collective belongs here.  An empty segment is not closed (hipGraphInstantiate of nothing): the op then simply follows its predecessor."""
+        if _hip.LAUNCHES[0] != self.mark:
+            self.graph.capture_end()
+            self.ops.append(('graph', self.graph))
+            self.ops.append(op)
+            self.begin()
+        else:
+            self.ops.append(op)
+
+    def end(self):
+        self.graph.capture_end()
+        if _hip.LAUNCHES[0] != self.mark:
+            self.ops.append(('graph', self.graph))
+        self.graph = None
+
+    def abort(self):
+        if self.graph is not None:
+            try:
+                self.graph.capture_end()
+            except Exception:
+                pass
+            self.graph = None
+
+
+class StepPlan(object):
+    """fwd + region loss + bwd of one training step for ONE problem shape (per-GPU batch, input size, padded box count, label form).
+
+    run(data)  -> dict(pred, loss, loss_total, debug) like train.iterate's; afterwards every parameter's .grad holds this step's
+                  gradient (averaged over the ranks under a DataParallelRCCL wrapper), written in place of - never added to - what was there.
+    The first `WARM` calls run the launch sequence eagerly (per-layer algorithm measurements happen there), the next one captures it,
+    every later one replays.  Results are views of static buffers: valid until the next step."""
+    WARM = 3
+
+    def __init__(self, inference, anchors, hparam, threshold, dp=None, pool=None):
+        import model
+        from model import yolo2 as _yolo2
+        self.inference, self.dnn, self.dp = inference, inference.dnn, dp
+        self.anchors, self.hparam, self.threshold = anchors, dict(hparam), float(threshold)
+        self.darknet = isinstance(self.dnn, _yolo2.Darknet) and not isinstance(self.dnn, _yolo2.Tiny)
+        self.params = [p for p in self.dnn.parameters()]
+        self.buffers = [b for b in self.dnn.buffers()]
+        self.pool = pool if pool is not None else torch.cuda.graph_pool_handle()       # all segments (and, shared by the runner, all shapes) allocate from one pool
+        self.scope = {}
+        self.ops = None             # captured op list
+        self.calls = 0
+        self.static = None
+        self.result = None
+        self.grads = {}
+
+    # ---- static inputs
+    def _alloc(self, data, npad):
+        x = data['tensor']
+        dev = x.device
+        B, _, H, W = x.shape
+        cls = data['cls']
+        st = dict(x=torch.empty(B, x.shape[1], H, W, dtype=torch.float32, device=dev),
+                  gt_min=torch.zeros(B, npad, 2, dtype=torch.float32, device=dev), gt_max=torch.zeros(B, npad, 2, dtype=torch.float32, device=dev),
+                  cls=torch.zeros((B, npad) + tuple(cls.shape[2:]), dtype=torch.int64 if cls.dim() == 2 else torch.float32, device=dev),
+                  npad=npad)
+        self.static = st
+
+    def _load(self, data):
+        """Copy a batch into the static inputs: image as it is, boxes in grid-cell units (train.norm_data: pixels x rows/height,
+        cols/width), rows past this batch's box count zero = the invalid boxes the collate function pads with (utils/data.py:114-133)."""
+        st = self.static
+        st['x'].copy_(data['tensor'], non_blocking=True)
+        H, W = st['x'].shape[-2:]
+        rows, cols = H // 32, W // 32
+        n = data['yx_min'].shape[1]
+        scale = _scale_tensor(rows / H, cols / W, st['x'].device)
+        for key, buf in (('yx_min', st['gt_min']), ('yx_max', st['gt_max'])):
+            v = buf[:, :n]
+            v.copy_(data[key], non_blocking=True)
+            v.mul_(scale)
+            if n < st['npad']:
+                buf[:, n:].zero_()
+        st['cls'][:, :n].copy_(data['cls'], non_blocking=True)
+        if n < st['npad']:
+            st['cls'][:, n:].zero_()
+
+    # ---- the launch sequence
+    def _chain(self, seg, grads):
+        """Issue every launch of the step on the current stream.  seg: None (eager pass: collectives run where they belong) or a
+        _Segments being captured.  grads: dict filled with {id(param): gradient tensor}."""
+        import model
+        dnn, dp, st = self.dnn, self.dp, self.static
+        dev = st['x'].device
+        anchors_dev = model._device_anchors(self.anchors, dev)
+        A = self.anchors.size(0)
+        nb = len(dp._buckets) if dp is not None else 0
+        ready_n = [0] * nb
+        state = dict(next=0)
+
+        def dest(p):
+            if dp is not None:
+                return dp.graph_slot(p)
+            t = grads.get(('dest', id(p)))
+            if t is None:
+                t = grads[('dest', id(p))] = torch.empty_like(p, memory_format=torch.contiguous_format)
+            return t
+
+        def ready(p, g):
+            if dp is None:
+                grads[id(p)] = g
+                return
+            slot = dp.graph_slot(p)
+            if slot is None:
+                raise RuntimeError('StepPlan: a parameter of the plugin is not in the data-parallel wrapper')
+            if g.data_ptr() != slot.data_ptr() or not g.is_contiguous():
+                slot.copy_(g.reshape(slot.shape))
+                _hip.LAUNCHES[0] += 1
+            if id(p) in grads:
+                return
+            grads[id(p)] = slot
+            bi = dp._where[id(p)][0]
+            ready_n[bi] += 1
+            lo = state['next']
+            hi = lo
+            while hi < nb and ready_n[hi] == len(dp._buckets[hi]):
+                hi += 1
+            if hi > lo and hi < nb:          # (the last bucket goes out after the last segment: nothing is left to overlap it with)
+                state['next'] = hi
+                if seg is None:
+                    dp.graph_launch(lo, hi)
+                else:
+                    join = getattr(state['tape'], 'join', None)
+                    if join is not None:
+                        join()               # weight gradients still running on the backward's side stream: a graph segment ends with every forked stream joined
+                    seg.cut(('buckets', lo, hi))
+
+        def npos(t):
+            if seg is None:
+                return dp._sum_small(t)
+            seg.cut(('npos', t))
+            return True
+
+        hooks = (getattr(dnn, 'grad_ready_hook', None), getattr(dnn, 'grad_buffer_hook', None))
+        dnn.grad_ready_hook, dnn.grad_buffer_hook = ready, dest
+        try:
+            tape = state['tape'] = _Tape()
+            tape.fork_ok = GRAPH_FORK
+            if self.darknet:
+                head = _darknet_fwd(tape, dnn, st['x'], self.params, False, scope=self.scope if seg is not None else None)
+            else:
+                head = ResNetTrainFn.forward(tape, dnn, st['x'], False, *self.params)
+            B, rows, cols, _ = head.shape
+            dt, lt = _Tape(), _Tape()
+            iou, co, sn, mn, mx, logits = DecodeFn.forward(dt, head, anchors_dev, A)
+            logits = logits if logits.numel() else None
+            reducer = npos if (dp is not None and dp.world > 1) else None
+            out, best_iou, best_idx, positive = RegionLossFn.forward(lt, iou, co, sn, logits, mn, mx, st['gt_min'], st['gt_max'], st['cls'], anchors_dev,
+                                                                     rows, cols, self.threshold, reducer)
+            keys = ['foreground', 'background', 'center', 'size'] + (['cls'] if logits is not None else [])
+            w = _hparam_tensor(tuple(float(self.hparam[k]) for k in keys) + (0.0,) * (out.numel() - len(keys)), dev)
+            self.scope['held'] = (w, anchors_dev)          # (cache entries other code may drop: a captured graph reads them at every replay)
+            total = torch.empty(1, dtype=torch.float32, device=dev)
+            _hip.check(_hip.lib().y2_small_dot(_hip.ptr(out), _hip.ptr(w), out.numel(), _hip.ptr(total), _hip.stream()), 'y2_small_dot')
+            # ---- backward: d total / d total = 1, so the loss vector's gradient IS the weight vector (what _WeightedTotalFn.backward computes)
+            d_iou, d_co, d_sn, d_lg = RegionLossFn.backward(lt, w)[:4]
+            df = DecodeFn.backward(dt, d_iou, d_co, d_sn, None, None, d_lg)[0]
+            if self.darknet:
+                _darknet_bwd(tape, df)
+            else:
+                ResNetTrainFn.backward(tape, df)
+        finally:
+            dnn.grad_ready_hook, dnn.grad_buffer_hook = hooks
+        missing = [p for p in self.params if p.requires_grad and id(p) not in grads]
+        if missing:
+            raise RuntimeError('StepPlan: %d parameters received no gradient' % len(missing))
+        pred = dict(feature=head.permute(0, 3, 1, 2), iou=iou, center_offset=co, size_norm=sn, yx_min=mn, yx_max=mx)
+        if logits is not None:
+            pred['logits'] = logits
+        result = LossDict(foreground=out[0:1], background=out[1:2], center=out[2:3], size=out[3:4])
+        if logits is not None:
+            result['cls'] = out[4:5]
+        result.vector = out
+        gt_min, gt_max, gt_cls, thr = st['gt_min'], st['gt_max'], st['cls'], self.threshold
+
+        def matched():
+            flat = best_idx.view(B, -1).long()
+            _data = {}
+            for key, t in (('yx_min', gt_min), ('yx_max', gt_max), ('cls', gt_cls)):
+                if t.dim() == 2:
+                    _data[key] = torch.gather(t, 1, flat).view(*best_idx.shape)
+                else:
+                    _data[key] = torch.gather(t, 1, flat.unsqueeze(-1).expand(-1, -1, t.shape[-1])).view(*best_idx.shape, -1)
+            return _data
+        debug = _LazyDebug(dict(iou=lambda: best_iou, data=matched, positive=lambda: positive.bool(),
+                                negative=lambda: ~positive.bool() & (best_iou < thr)))
+        return dict(pred=pred, loss=result, loss_total=total, debug=debug), state['next']
+
+    # ---- one step
+    def _finish(self, grads, launched):
+        """Outstanding collectives, averaging, and the parameters' .grad."""
+        dp = self.dp
+        if dp is not None:
+            dp.graph_launch(launched, len(dp._buckets))
+            dp.graph_finish()
+        for p in self.params:
+            g = grads.get(id(p))
+            if g is not None:
+                p.grad = g
+        if self.buffers:
+            _hip.wrote(self.buffers)          # BatchNorm running statistics / step counters were updated by y2_bn_finalize (raw pointers)
+
+    def run(self, data, capture=True):
+        self.calls += 1
+        if self.dp is not None:
+            self.dp.graph_begin()
+        if self.static is None:
+            raise RuntimeError('StepPlan.run before StepPlan._alloc')
+        self._load(data)
+        if self.ops is None and capture and self.calls > self.WARM:
+            self._capture()
+        if self.ops is None or not capture:          # (capture=False with a captured plan: this one step launch by launch - per-kernel event tables)
+            grads = {}
+            result, launched = self._chain(None, grads)
+            self._finish(grads, launched)
+            return result
+        launched = 0
+        for op in self.ops:
+            if op[0] == 'graph':
+                op[1].replay()
+            elif op[0] == 'npos':
+                self.dp._sum_small(op[1])
+            else:
+                self.dp.graph_launch(op[1], op[2])
+                launched = op[2]
+        self._finish(self.grads, launched)
+        return self.result
+
+    def _capture(self):
+        """Record the launch sequence into hipGraph segments (nothing executes; the caller replays them right away)."""
+        cur = torch.cuda.current_stream()
+        side = _capture_stream(self.static['x'].device)
+        torch.cuda.synchronize()
+        side.wait_stream(cur)
+        seg = _Segments(self.pool, 'capture')
+        grads = {}
+        prev_scope = _hip.SCOPE
+        with torch.cuda.stream(side):
+            _hip.SCOPE = self.scope
+            try:
+                seg.begin()
+                self.result, _ = self._chain(seg, grads)
+                seg.end()
+            except BaseException:
+                seg.abort()
+                raise
+            finally:
+                _hip.SCOPE = prev_scope
+        cur.wait_stream(side)
+        self.ops, self.grads = seg.ops, grads
+
+
+_CAPTURE_STREAMS = {}
+
+
+def _capture_stream(dev):
+    s = _CAPTURE_STREAMS.get(str(dev))
+    if s is None:
+        s = _CAPTURE_STREAMS[str(dev)] = torch.cuda.Stream(device=dev)
+    return s
+
+
+_SCALE_DEV = {}
+
+
+def _scale_tensor(sy, sx, dev):
+    key = (sy, sx, str(dev))
+    t = _SCALE_DEV.get(key)
+    if t is None:
+        t = _SCALE_DEV[key] = torch.tensor([sy, sx], dtype=torch.float32, device=dev).view(1, 1, 2)
+    return t
+
+
+def _hparam_tensor(w, dev):
+    key = (w, str(dev))
+    wd = _HPARAM_DEV.get(key)
+    if wd is None:
+        wd = _HPARAM_DEV[key] = torch.tensor(w, dtype=torch.float32, device=dev)
+    return wd

@@ -145,6 +145,13 @@ class Darknet(nn.Module):
     def _first_block(self):
         return self.layers1[0]
 
+    def backward_param_order(self):
+        """Convolution weights in the order the training backward finishes their gradients (model.train_graph._darknet_bwd walks the
+        forward's block list backwards: layers3, layers2, the passthrough branch, layers1): train.DataParallelRCCL buckets them in it."""
+        b1, b2, b3 = self._blocks()
+        fwd = [m for _, m, _ in b1] + [self.passthrough] + [m for _, m, _ in b2] + [m for _, m, _ in b3]
+        return [m.conv.weight for m in reversed(fwd)]
+
     def _versions(self):
         """Cache key of everything derived from the parameters and buffers: (address, torch version counter) per tensor.  The
         raw-pointer writers (utils.optim, y2_bn_finalize) advance the counters of what they wrote through _hip.wrote, so the key is
@@ -421,6 +428,9 @@ class Tiny(Darknet):
 
     def _first_block(self):
         return self.layers[0]
+
+    def backward_param_order(self):
+        return [m.conv.weight for m in reversed([m for m in self.layers if isinstance(m, Conv2d)])]
 
     def forward_nhwc(self, x):
         _hip.require_gpu(x)

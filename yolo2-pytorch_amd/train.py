@@ -144,7 +144,24 @@ class DataParallelRCCL(nn.Module):
         self._where = {}
         self._buckets = []
         cur, size = [], 0
-        for p in reversed(self._params):
+        # Weights first, in reverse registration order ~ the order in which backward produces them; everything one-dimensional (BatchNorm
+        # affine parameters, biases: 0.1 % of the bytes) goes into ONE last bucket.  The Darknet backward hands the affine gradients of
+        # ALL layers out together after its last layer (one conversion launch, model.train_graph._darknet_bwd): mixed into the weight
+        # buckets they held every bucket back until the end of backward, and no all-reduce overlapped anything.
+        small = [p for p in self._params if p.dim() <= 1]
+        weights = list(reversed([p for p in self._params if p.dim() > 1]))
+        # a plugin that knows the order in which its backward finishes its weight gradients says so (the passthrough branch of Darknet is
+        # registered before layers3 but finished after layers2: in registration order its bucket would hold six others back); the order
+        # is a property of the module's code, identical on every rank
+        told = []
+        for m in self.module.modules():
+            f = getattr(m, 'backward_param_order', None)
+            if callable(f):
+                told += [p for p in f() if p.requires_grad]
+        if told and len({id(p) for p in told}) == len(told) and {id(p) for p in told} <= {id(p) for p in weights}:
+            rest = {id(p) for p in told}
+            weights = told + [p for p in weights if id(p) not in rest]
+        for p in weights:
             cur.append(p)
             size += p.numel() * p.element_size()
             if size >= self.bucket_bytes:
@@ -152,6 +169,8 @@ class DataParallelRCCL(nn.Module):
                 cur, size = [], 0
         if cur:
             self._buckets.append(cur)
+        if small:
+            self._buckets.append(list(reversed(small)))
         self._flat = []
         for bi, bucket in enumerate(self._buckets):
             off = 0
@@ -262,8 +281,8 @@ class DataParallelRCCL(nn.Module):
                     self._flat[bi] = self._flat[bi].to(dev)
                 self._launch_bucket(bi)
             self._next = len(self._buckets)
+            self._wait_all()
             for bi, bucket in enumerate(self._buckets):
-                self._works[bi].wait()
                 flat = self._flat[bi]
                 base = flat.numel() - len(bucket)
                 flags = flat[base:].tolist() if any(id(p) not in self._done for p in bucket) else None
@@ -283,17 +302,75 @@ class DataParallelRCCL(nn.Module):
             self._pending = False
             self._reset()
 
-    def forward(self, *args, **kwargs):
+    def _tick(self):
+        """Start of a step (forward() or a StepPlan's graph_begin): clean bookkeeping, the call count, the tune exchange it triggers."""
         # a backward that raised leaves the bookkeeping half-filled: start every step from a clean slate
         self._pending = False
         self._reset()
         self._calls += 1
         if self.world > 1 and (self._calls in self.SYNC_TUNE_CALLS or self._calls % self.SYNC_TUNE_CALLS[-1] == 0):
-            # the trigger is the wrapper's call count and nothing else: every rank calls forward() once per step, so every rank reaches the
+            # the trigger is the wrapper's call count and nothing else: every rank starts one step per step, so every rank reaches the
             # broadcast at the same point of its collective sequence - whatever input shapes the ranks' own loaders drew (with one process
             # per GPU each rank's collate picks its multi-scale size itself, utils/data.py:135-141; a per-shape trigger would put one rank
             # into the broadcast while the others start a gradient all-reduce)
             self._sync_tune()
+
+    # ---- the same protocol for a step that runs as captured hipGraph segments (model.train_graph.StepPlan): no autograd hooks fire, the
+    # plan writes every gradient into its bucket slice and tells the wrapper where the segments end.  Collectives, their order and their
+    # payloads are those of the hook path - a rank replaying a graph and a rank still warming up on another input size match.
+    def graph_begin(self):
+        self._tick()
+
+    def graph_slot(self, p):
+        w = self._where.get(id(p))
+        if w is None:
+            return None
+        bi, off = w
+        flat = self._flat[bi]
+        if flat.device != p.device:
+            flat = self._flat[bi] = flat.to(p.device)
+        return flat[off:off + p.numel()].view_as(p)
+
+    def graph_launch(self, lo, hi):
+        """All-reduce buckets lo .. hi-1 (complete on this rank), in index order."""
+        for bi in range(lo, hi):
+            assert bi == self._next, (bi, self._next)
+            flat = self._flat[bi]
+            flat[flat.numel() - len(self._buckets[bi]):].fill_(1.0)
+            self._works[bi] = self._all_reduce(flat)
+            self._next = bi + 1
+
+    overlap_stats = None      # set to a list: (event before, event after) the waits for the outstanding all-reduces, one pair per step
+
+    def _wait_all(self):
+        st = self.overlap_stats
+        timed = st is not None and self._flat[0].is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for w in self._works:
+            w.wait()
+        if timed:
+            e1.record()
+            st.append((e0, e1))
+            del st[:-64]
+
+    def graph_finish(self):
+        """Wait for the buckets, average.  (The plan assigns the slices as the parameters' .grad.)"""
+        assert self._next == len(self._buckets)
+        self._wait_all()
+        torch._foreach_mul_([flat[:flat.numel() - len(b)] for flat, b in zip(self._flat, self._buckets)], 1.0 / self.world)
+        self._reset()
+
+    def graph_views(self, params, grads):
+        """The plan made these bucket slices the parameters' .grad: a later hook-path backward must treat them as such (see _start)."""
+        for p in params:
+            g = grads.get(id(p))
+            if g is not None:
+                self._views[id(p)] = g
+
+    def forward(self, *args, **kwargs):
+        self._tick()
         out = self.module(*args, **kwargs)
         # the region loss sums its positive count over THIS wrapper's group (model/__init__.py:162: mean over the positives of the
         # global batch): the reducer travels with the predictions (model.train_graph.DP_TAG)
@@ -359,17 +436,133 @@ def ensure_model(model_):
     return model_
 
 
+GRAPH = os.environ.get('Y2_TRAIN_GRAPH', '1') != '0'       # 0: every training step through autograd, launch by launch (A/B runs, per-kernel event tables)
+
+
+class StepRunner(object):
+    """The StepPlans (model.train_graph) of one model: one per problem shape - per-GPU batch, input size (multi-scale training cycles
+    through ten, utils/data.py:135-141), padded box count, label form - all allocating from one graph memory pool, least recently used
+    dropped beyond `MAX`.  step(data) returns what iterate returns, or None when this step cannot run as a plan (the caller then takes
+    the autograd path)."""
+    MAX = int(os.environ.get('Y2_TRAIN_PLANS', '24'))
+
+    def __init__(self, inference, dp, anchors, hparam, threshold):
+        import collections
+        self.inference, self.dp = inference, dp
+        self.anchors, self.hparam, self.threshold = anchors, dict(hparam), float(threshold)
+        self.plans = collections.OrderedDict()
+        self.warm = {}
+        self.pool = None
+        self.broken = None
+        self.captures = 0
+
+    def same(self, anchors, hparam, threshold):
+        return anchors is self.anchors and dict(hparam) == self.hparam and float(threshold) == self.threshold
+
+    def eligible(self, data):
+        import _hip
+        from model import resnet as _resnet
+        from model import train_graph
+        from model import yolo2 as _yolo2
+        inf, x = self.inference, data.get('tensor')
+        dnn = getattr(inf, 'dnn', None)
+        if self.broken or not isinstance(x, torch.Tensor) or not x.is_cuda or x.dim() != 4 or x.shape[-1] % 32 or x.shape[-2] % 32:
+            return False
+        if not isinstance(inf, model.Inference) or not isinstance(dnn, (_yolo2.Darknet, _resnet.ResNet)) or not (inf.training and dnn.training):
+            return False
+        if _hip.DETERMINISTIC or train_graph.DEBUG_TAP is not None or not torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+            return False
+        if any(k not in data for k in ('yx_min', 'yx_max', 'cls')) or data['yx_min'].dim() != 3 or data['cls'].dim() not in (2, 3):
+            return False
+        ok = getattr(self, '_params_ok', None)
+        if ok is None:
+            ps = list(dnn.parameters())
+            ok = all(p.requires_grad and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps)
+            if ok and isinstance(dnn, _yolo2.Darknet) and not isinstance(dnn, _yolo2.Tiny):
+                ok = train_graph._pad_layout(dnn) is None           # pruned widths run zero-padded through host-side glue: autograd path
+            if ok and self.dp is not None:
+                ok = all(id(p) in self.dp._where for p in ps) and len(ps) == len(self.dp._params)
+            self._params_ok = ok
+        return ok
+
+    def step(self, data):
+        import _hip
+        from model import train_graph
+        if not self.eligible(data):
+            return None
+        x, cls = data['tensor'], data['cls']
+        n = data['yx_min'].shape[1]
+        npad = 8
+        while npad < n:
+            npad *= 2
+        shape = (tuple(x.shape), tuple(cls.shape[2:]), cls.dim())
+        key = shape + (npad, _hip.tune_epoch(), _hip.WINOGRAD, _hip.split_mode(), _hip.FORCE_ALGO, train_graph.GRAD_F43, train_graph.FUSE_CONV0, str(x.device))
+        plan = self.plans.get(key)
+        if plan is None:
+            for k in [k for k in self.plans if k[:3] == shape and k[4] != key[4]]:
+                del self.plans[k]                    # measured on another algorithm table
+            if self.pool is None:
+                self.pool = torch.cuda.graph_pool_handle()
+            plan = train_graph.StepPlan(self.inference, self.anchors, self.hparam, self.threshold, dp=self.dp, pool=self.pool)
+            plan._alloc(data, npad)
+            plan.calls = self.warm.get(shape, 0)      # the per-layer measurements depend on the shape, not on the box count
+            self.plans[key] = plan
+            while len(self.plans) > self.MAX:
+                self.plans.popitem(last=False)
+        else:
+            self.plans.move_to_end(key)
+        self.warm[shape] = self.warm.get(shape, 0) + 1
+        had_graph = plan.ops is not None
+        try:
+            out = plan.run(data, capture=GRAPH)
+        except Exception as e:
+            if had_graph or plan.calls <= plan.WARM:
+                raise
+            # the capture failed (never a replay or an eager pass): this model keeps the autograd path
+            logging.warning('training-step capture failed (%s: %s); autograd path from here on' % (type(e).__name__, e))
+            self.broken = '%s: %s' % (type(e).__name__, e)
+            self.plans.clear()
+            torch.cuda.synchronize()
+            return None
+        if not had_graph and plan.ops is not None:
+            self.captures += 1
+        if self.dp is not None:
+            self.dp.graph_views(plan.params, plan.grads)
+        return out
+
+
+PLAN = os.environ.get('Y2_TRAIN_PLAN', '1') != '0'      # 0: iterate never uses StepPlans (not even eagerly): the reference's three autograd calls
+
+
+def _runner(inference, anchors, hparam, threshold):
+    dp = inference if isinstance(inference, DataParallelRCCL) else None
+    inner = inference.module if dp is not None else inference
+    r = inner.__dict__.get('_y2_step_runner')
+    if r is None or r.dp is not dp or not r.same(anchors, hparam, threshold):
+        r = StepRunner(inner, dp, anchors, hparam, threshold)
+        inner.__dict__['_y2_step_runner'] = r
+    return r
+
+
 def iterate(inference, optimizer, data, loss_hparam, threshold, anchors, clip=None):
-    """Body of Train.iterate (train.py:338-362): forward, region loss, weighted sum, backward, optional clip, step."""
-    tensor = data['tensor']
-    pred = model._inference(inference, tensor)
-    height, width = tensor.size()[-2:]
-    rows, cols = pred['feature'].size()[-2:]
-    loss, debug = model.loss(anchors, norm_data(data, height, width, rows, cols), pred, threshold)
-    loss_total = model.weighted_total(loss, loss_hparam)      # = sum(loss[key] * loss_hparam[key] for key in loss), one launch
-    optimizer.zero_grad()
-    loss_total.backward()
+    """Body of Train.iterate (train.py:338-362): forward, region loss, weighted sum, backward, optional clip, step.
+    When the step has a fixed problem shape on the GPU it runs as a StepPlan: the same kernels in the same order, issued from a captured
+    hipGraph instead of ~270 Python -> ctypes launches under autograd (Y2_TRAIN_GRAPH=0 / Y2_TRAIN_PLAN=0 switch that off)."""
+    out = None
+    if PLAN and isinstance(data.get('tensor'), torch.Tensor) and data['tensor'].is_cuda:
+        out = _runner(inference, anchors, loss_hparam, threshold).step(data)
+    if out is None:
+        tensor = data['tensor']
+        pred = model._inference(inference, tensor)
+        height, width = tensor.size()[-2:]
+        rows, cols = pred['feature'].size()[-2:]
+        loss, debug = model.loss(anchors, norm_data(data, height, width, rows, cols), pred, threshold)
+        loss_total = model.weighted_total(loss, loss_hparam)      # = sum(loss[key] * loss_hparam[key] for key in loss), one launch
+        optimizer.zero_grad()
+        loss_total.backward()
+        out = dict(pred=pred, loss=loss, loss_total=loss_total, debug=debug)
+    # (a StepPlan leaves this step's gradients in .grad - written over, never added to, what was there: zero_grad + backward in one)
     if clip is not None:
         utils.optim.clip_grad_norm_(inference.parameters(), clip)     # fused form of nn.utils.clip_grad_norm (train.py:352-354)
     optimizer.step()
-    return dict(pred=pred, loss=loss, loss_total=loss_total, debug=debug)
+    return out
