@@ -168,7 +168,7 @@ def test_dp_world2_darknet_region_loss_equals_concatenated_batch(tmp_path):
             continue
         assert torch.equal(r0['grads'][k], r1['grads'][k]), k
         e = _rel(r0['grads'][k], v.grad)
-        assert e <= 2e-3, (k, e)          # same tolerance as the single-process training-step test (23 batch-stat BN layers in fp32)
+        assert e <= 2e-4, (k, e)          # the stated gradient tolerance, as in the single-process training-step test
     # loss terms: every rank divides by its LOCAL cnt, so the mean over ranks is the global term; cls uses the GLOBAL positive count
     for k in lo:
         got = 0.5 * (r0['loss'][k] + r1['loss'][k])

@@ -345,3 +345,86 @@ def test_608_coco80_full_width_training_step_against_the_oracle_and_its_fp32_flo
         worst = max(worst, e / max(floor, 1e-30))
         assert e <= max(1e-4, 2.5 * floor), (k, e, floor)
     print('608x608 COCO-80 %s: worst gradient error / fp32 floor = %.2f' % (arch, worst))
+
+
+def _kernel_names(fn):
+    """Names of the library kernels `fn` launches (the per-launch event hooks of include/yolo2_hip.h: y2_prof_*)."""
+    import ctypes
+
+    import _hip
+    L = _hip.lib()
+    torch.cuda.synchronize()
+    L.y2_prof_enable(1)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+    finally:
+        L.y2_prof_enable(0)
+    name, ms, fl = ctypes.create_string_buffer(96), ctypes.c_float(), ctypes.c_double()
+    names = []
+    for i in range(L.y2_prof_count()):
+        if L.y2_prof_get(i, name, 96, ctypes.byref(ms), ctypes.byref(fl)) == 0:
+            names.append(name.value.decode())
+    return out, names
+
+
+@pytest.mark.parametrize('forms', ['4x4-tiles', '2x2-tiles', 'direct'])
+def test_full_width_training_step_with_the_gradient_algorithms_pinned(forms):
+    """The training twin of test_full_batch_under_each_forced_algorithm: in production the per-layer MEASUREMENT decides which gradient
+    algorithm a layer runs, so a parity run exercises whatever won on that box.  Here every eligible layer is pinned - the data gradients
+    on Winograd F(4x4,3x3) and the weight gradients on F(3x3,4x4) (1.2-1.4e-5 x rms per layer: the least accurate forms the library has),
+    then the 2x2-tile Winograd reduction, then the direct kernels - and the full-width 416x416 step is held to the same bound as the
+    production plan: every parameter gradient within 2.5x the oracle's own fp32-vs-fp64 floor (or 1e-4 x rms)."""
+    import _hip
+    import model
+    import model.yolo2
+    import train as y2train
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1'}})
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    sd = odark.init_state_dict(5, 20, seed=0, head_scale=1 / 40.0)
+    dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, 20)
+    dnn.load_state_dict(sd, strict=False)
+    inf = model.Inference(cfg, dnn, anchors).to(dev()).train()
+    n = 4
+    x = synth.images(n, S, seed=3)
+    data = synth.norm_data(synth.labels(n, S, 20, seed=4), S, S, S // 32, S // 32)
+    saved = (_hip.FORCE_GRAD, _hip.FORCE_WGRAD, _hip.AUTOTUNE)
+    _hip.FORCE_GRAD, _hip.FORCE_WGRAD = {'4x4-tiles': ('f43', 'f34'), '2x2-tiles': (None, 'wino'), 'direct': ('direct', 'direct')}[forms]
+    _hip.AUTOTUNE = False            # forward layers: the library's fixed table (no timing-based selection anywhere in this test)
+
+    def step():
+        pred = model._inference(inf, x.to(dev()))
+        loss, _ = model.loss(anchors, data, pred, 0.6)
+        model.weighted_total(loss, oloss.HPARAM).backward()
+        return loss
+    try:
+        loss, names = _kernel_names(step)
+    finally:
+        _hip.FORCE_GRAD, _hip.FORCE_WGRAD, _hip.AUTOTUNE = saved
+    ours = {k: p.grad.detach().cpu() for k, p in dnn.named_parameters()}
+    if forms == '4x4-tiles':
+        # 14 weight gradients (every 3x3 layer with >= 32 input channels) and the data gradients with >= 128 gradient channels on maps <= 52x52
+        assert names.count('wino6_dw_kernel') >= 13 and names.count('wino6_out_kernel') >= 8, (names.count('wino6_dw_kernel'), names.count('wino6_out_kernel'))
+    elif forms == '2x2-tiles':
+        assert names.count('wino_dw_kernel') >= 13 and 'wino6_dw_kernel' not in names
+    else:
+        assert not any(k.startswith('wino6') or k == 'wino_dw_kernel' for k in names)
+    torch.set_num_threads(64)
+    ref = {}
+    for name, dt in (('fp64', torch.float64), ('fp32', torch.float32)):
+        sdx = {k: (v.to(dt).requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+        f = odark.forward(x.to(dt), sdx, training=True)
+        lo, _ = oloss.loss(anchors.to(dt), {k: (v.to(dt) if v.is_floating_point() else v) for k, v in data.items()}, ohead.decode(f, anchors.to(dt)), 0.6)
+        oloss.total(lo).backward()
+        ref[name] = ({k: v.grad for k, v in sdx.items() if getattr(v, 'grad', None) is not None}, lo)
+    for k in loss:
+        np.testing.assert_allclose(loss[k].item(), ref['fp64'][1][k].item(), rtol=1e-5)
+    g64, g32 = ref['fp64'][0], ref['fp32'][0]
+    worst = 0.0
+    for k in g64:
+        floor = rms_rel(g32[k], g64[k])
+        e = rms_rel(ours[k], g64[k])
+        worst = max(worst, e / max(floor, 1e-30))
+        assert e <= max(1e-4, 2.5 * floor), (forms, k, e, floor)
+    print('gradient algorithms pinned to %s: worst gradient error / fp32 floor = %.2f' % (forms, worst))

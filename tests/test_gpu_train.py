@@ -369,6 +369,9 @@ def test_region_loss_random_configurations_vs_oracle(rows, B, nmax, C, seed):
     np.testing.assert_allclose(f.grad.cpu().numpy(), gr, rtol=5e-4, atol=2e-6 * np.abs(gr).max())
 
 
+GRAD_TOL = 2e-4        # README 'Tolerances': max |gradient error| / rms(gradient) against the oracle's fp64 autograd, narrow network
+
+
 def build(sd, num_cls=20, bn=True):
     import model
     import model.yolo2
@@ -412,7 +415,7 @@ def test_darknet_training_step_matches_oracle_autograd(bn):
             assert ours[k].grad is not None, k
             e = rel(ours[k].grad, v.grad)
             worst = max(worst, e)
-            assert e <= 2e-3, (k, e)   # gradients pass through up to 23 BN layers in fp32; fp64 oracle
+            assert e <= GRAD_TOL, (k, e)   # the stated gradient tolerance (README): 2e-4 x rms vs the fp64 oracle at this width (measured 3.3e-5)
     bufs = dict(inf.dnn.named_buffers())
     for prefix, (rm, rv) in stats.items():
         np.testing.assert_allclose(bufs[prefix + '.bn.running_mean'].cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-6)

@@ -68,3 +68,28 @@ def test_static_weight_gradient_preferences(monkeypatch, cin, hw, want):
     assert _hip.wgrad_choice(64, hw, hw, cin, cin, 2 * cin, 2 * cin, 1, True, 'cuda:0') == 0          # 1x1 layers: the direct kernel
     monkeypatch.setattr(_hip, 'DETERMINISTIC', True)
     assert _hip.wgrad_choice(64, hw, hw, cin, cin, 2 * cin, 2 * cin, 3, True, 'cuda:0') == (1 if cin >= 128 else 0)
+
+
+def test_default_tune_table_is_adopted_only_for_the_kernels_it_was_measured_on(monkeypatch, tmp_path):
+    """The committed table (yolo2-pytorch_amd/tune/default_gfx950.json) carries the hash of the kernel sources: entries are adopted for the
+    device they are asked for, never over a choice this process already holds, and not at all when the sources have changed."""
+    import json
+
+    import _hip
+    monkeypatch.setattr(_hip, '_TUNE', {('mine', 'cuda:2'): [1, 5]})
+    monkeypatch.setattr(_hip, '_DEFAULTS_SEEN', {})
+    monkeypatch.setattr(_hip, 'TUNE_DEFAULTS', True)
+    h = _hip.kernel_hash()
+    assert h is not None and len(h) == 16 and h == _hip.kernel_hash()
+    good = tmp_path / 'good.json'
+    json.dump({'kernels': h, 'entries': [[['mine', '@dev'], [0, 0]], [['wgrad', 64, 13, 13, 512, 512, 1024, 1024, True, '@dev'], 2], [[32, 13, 13, True, '@dev', False], [1, 5]]]}, open(good, 'w'))
+    assert _hip.load_tune_defaults('cuda:2', str(good)) == 2
+    assert _hip._TUNE[('mine', 'cuda:2')] == [1, 5]                       # what the process held stays
+    assert _hip._TUNE[('wgrad', 64, 13, 13, 512, 512, 1024, 1024, True, 'cuda:2')] == 2 and _hip._TUNE[(32, 13, 13, True, 'cuda:2', False)] == [1, 5]
+    stale = tmp_path / 'stale.json'
+    json.dump({'kernels': '0' * 16, 'entries': [[['other', '@dev'], [2, 0]]]}, open(stale, 'w'))
+    assert _hip.load_tune_defaults('cuda:2', str(stale)) == 0 and ('other', 'cuda:2') not in _hip._TUNE
+    # the committed file, when there is one, parses and names a hash
+    if os.path.exists(_hip.DEFAULTS_PATH):
+        d = json.load(open(_hip.DEFAULTS_PATH))
+        assert len(d['kernels']) == 16 and all(len(e) == 2 for e in d['entries'])

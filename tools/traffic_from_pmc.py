@@ -7,8 +7,17 @@ FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch (TCC-EA requests, summe
 FETCH_SIZE counts half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) and is doubled.  The conv
 chain = conv_fwd_dma_kernel family + split-K fix-up + the Winograd transform kernels; steps = conv0 dispatches."""
 import json
+import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'yolo2-pytorch_amd'))
+try:
+    import _hip
+    KERNELS = _hip.kernel_hash()
+except Exception:
+    KERNELS = None
 
 FAMILY = re.compile(r'conv_fwd_dma_kernel|conv_splitk_fixup_kernel|wino_(input|output|fused2?|tile_table)_kernel|conv0_kernel|gemm_split_kernel|wino_input_split_kernel')
 TRAIN = len(sys.argv) > 2 and sys.argv[2] == 'train'       # every kernel of the training step; steps = loss_fwd_kernel dispatches
@@ -29,10 +38,11 @@ for k, c, n, v in rows:
             launches += n
 fetch, write = tot['FETCH_SIZE'] / steps, tot['WRITE_SIZE'] / steps
 print(json.dumps({
-    'source': ('rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile_r3.sh) on `tools/train_steady.py` (autotune cache pre-populated): every kernel of the training step' if TRAIN else
-               'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile_r3.sh) on `bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3 --no-split-leg --no-multiscale` (autotune cache pre-populated); conv0 + conv_fwd_dma_kernel family + split-K fix-up + all Winograd kernels'),
+    'source': ('rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile_r4.sh) on `tools/train_steady.py` (autotune cache pre-populated): every kernel of the training step' if TRAIN else
+               'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile_r4.sh) on `bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3 --no-split-leg --no-multiscale` (autotune cache pre-populated); conv0 + conv_fwd_dma_kernel family + split-K fix-up + all Winograd kernels'),
     'kernel_launches_profiled': launches, 'steps_profiled': steps,
     'fetch_size_bytes_raw_per_step': fetch, 'write_size_bytes_raw_per_step': write,
     'correction': 'gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE uncorrected; counters are L2 memory-side requests, Infinity-Cache hits included',
     'traffic_bytes_per_step': 2 * fetch + write,
+    'kernels': KERNELS,          # hash of the kernel sources the profile was taken on: bench.py reports the figure only for the same sources
 }, indent=1))

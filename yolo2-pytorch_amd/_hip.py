@@ -355,6 +355,62 @@ if TUNE_CACHE and os.path.exists(TUNE_CACHE):
         pass
 
 
+# ---- committed default table: the per-layer choices measured on an MI355X for the BASELINE shapes (tools/make_tune_table.py), so that a
+# fresh box - and each of the eight ranks of a node - starts on the measured plans instead of spending 1.4-6 s per new input shape on
+# timing runs.  It is valid for the kernels it was measured on: the file carries a hash of csrc/*.hip + headers and is ignored when the
+# sources differ.  Entries never override what this process measured or loaded from Y2_TUNE_CACHE.  Y2_TUNE_DEFAULTS=0: do not load.
+TUNE_DEFAULTS = os.environ.get('Y2_TUNE_DEFAULTS', '1') != '0'
+DEFAULTS_PATH = os.path.join(_HERE, 'tune', 'default_gfx950.json')
+_DEFAULTS_SEEN = {}
+
+
+def kernel_hash():
+    """sha256 (16 hex digits) of the kernel sources the library is built from; None when the sources are not there."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(_HERE, 'csrc', '*.hip'))) + [os.path.join(_HERE, 'csrc', 'common.h'), os.path.join(os.path.dirname(_HERE), 'include', 'yolo2_hip.h')]
+    if len(files) < 3 or not all(os.path.exists(f) for f in files):
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def load_tune_defaults(dev, path=None):
+    """Adopt the committed default choices for device `dev` (once per device).  Returns the number of entries adopted."""
+    key = str(dev)
+    if key in _DEFAULTS_SEEN and path is None:
+        return _DEFAULTS_SEEN[key]
+    n = 0
+    path = path or DEFAULTS_PATH
+    if TUNE_DEFAULTS and os.path.exists(path):
+        try:
+            import json as _json
+            d = _json.load(open(path))
+            if d.get('kernels') is not None and d.get('kernels') == kernel_hash():
+                for k, v in d['entries']:
+                    kk = tuple(key if e == '@dev' else e for e in k)
+                    if kk not in _TUNE:
+                        _TUNE[kk] = v
+                        n += 1
+        except Exception:
+            n = 0
+    _DEFAULTS_SEEN[key] = n
+    return n
+
+
+def save_tune_defaults(path=None, note=''):
+    """tools/make_tune_table.py: write this process's measured choices as the default table for the current kernel sources."""
+    import json as _json
+    path = path or DEFAULTS_PATH
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    entries = [[list(k), v] for k, v in export_tune()]
+    _json.dump({'kernels': kernel_hash(), 'note': note, 'entries': entries}, open(path, 'w'), indent=0)
+    return len(entries)
+
+
 WINOGRAD = os.environ.get('Y2_WINOGRAD', '1') != '0'     # 0: never pick the Winograd F(2x2,3x3) algorithm
 WGRAD_F34 = os.environ.get('Y2_WGRAD_F34', '1') != '0'     # offer the 4x4-tile Winograd weight gradient (F(3x3, 4x4)) to the per-layer measurement
 FORCE_ALGO = os.environ.get('Y2_FORCE_ALGO') or None     # 'direct' | 'winograd' | 'fused' | 'implicit' | 'fused3' | 'implicit3' | 'split': no autotune, that algorithm wherever the library accepts it
@@ -399,6 +455,12 @@ def split_planes(t, mode=None):
     return out
 
 
+# Pinned gradient algorithms (tests: the training twin of Y2_FORCE_ALGO): every eligible data gradient on Winograd F(4x4,3x3) ('f43') or the
+# direct kernel ('direct'); every eligible weight gradient on the direct kernel / the 2x2-tile / the 4x4-tile Winograd reduction.
+FORCE_GRAD = os.environ.get('Y2_FORCE_GRAD_ALGO') or None
+FORCE_WGRAD = os.environ.get('Y2_FORCE_WGRAD') or None
+if FORCE_GRAD not in (None, 'f43', 'direct') or FORCE_WGRAD not in (None, 'direct', 'wino', 'f34'):
+    raise ValueError('Y2_FORCE_GRAD_ALGO must be f43 or direct, Y2_FORCE_WGRAD direct, wino or f34')
 IMPLICIT = os.environ.get('Y2_WINO_IMPLICIT', '1') != '0'  # 0: never offer Y2_ALGO_WINOGRAD_IMPLICIT (A/B runs)
 WINO_MIN_CIN = 32                                        # below this the transforms cost more than the GEMM saves (measured; 32: the 208x208 layer, one K slab per tile of the fused kernels)
 
@@ -467,6 +529,13 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
         params.w = wino_split.data_ptr() if algo in (4, 5) else wino_w.data_ptr() if algo in (1, 2, 3) else f43_w().data_ptr() if algo == 6 else w_direct
         params.w_plane = split_plane if algo in (4, 5) else 0
         return choice
+    if FORCE_GRAD is not None and f43 is not None:
+        # a data gradient under a pinned gradient algorithm (no measurement, no cache)
+        if FORCE_GRAD == 'f43' and f43_ok:
+            apply((6, 5))
+            if lib().y2_conv_fwd_workspace_bytes(ctypes.byref(params)) >= 0:
+                return (6, 5)
+        return apply((0, 0))
     if FORCE_ALGO is not None:
         # deterministic algorithm coverage (tests, A/B runs): every eligible layer takes the named algorithm, everything else the
         # direct kernel with the library's own tile choice; no measurement, no cache
@@ -480,6 +549,8 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
             if lib().y2_conv_fwd_workspace_bytes(ctypes.byref(params)) >= 0:
                 return want
         return apply((0, 0))
+    if str(dev) not in _DEFAULTS_SEEN:
+        load_tune_defaults(dev)
     hit = None if DETERMINISTIC else _TUNE.get(key)      # deterministic mode ignores measured choices (they may differ between runs)
     if hit is not None:
         return apply(tuple(hit) if isinstance(hit, (list, tuple)) else (0, hit))
@@ -592,10 +663,14 @@ def wgrad_choice(B, H, W, cin, ldx, cout, ldz, k, has_v, dev):
     transformed input; overwrites), None = eligible for all and not measured yet (conv_wgrad will time them and zero the buffer itself)."""
     if not (wino_eligible(cout, cin, k) and not (ldx % 4) and not (ldz % 4)):
         return 0
+    if FORCE_WGRAD is not None and not DETERMINISTIC:
+        return {'direct': 0, 'wino': 1, 'f34': 2}[FORCE_WGRAD]
     if DETERMINISTIC or not AUTOTUNE:
         if not DETERMINISTIC and WGRAD_F34 and cin >= 128 and H * W <= 19 * 19:
             return 2                    # what the measurements converge to on the 13x13 (19x19) layers
         return 1 if cin >= 128 else 0
+    if str(dev) not in _DEFAULTS_SEEN:
+        load_tune_defaults(dev)
     return _TUNE.get(('wgrad', B, H, W, cin, ldx, cout, ldz, bool(has_v), str(dev)))
 
 
