@@ -369,7 +369,7 @@ def test_region_loss_random_configurations_vs_oracle(rows, B, nmax, C, seed):
     np.testing.assert_allclose(f.grad.cpu().numpy(), gr, rtol=5e-4, atol=2e-6 * np.abs(gr).max())
 
 
-GRAD_TOL = 2e-4        # README 'Tolerances': max |gradient error| / rms(gradient) against the oracle's fp64 autograd, narrow network
+GRAD_TOL = 2e-4        # README 'Tolerances': max |gradient error| / rms(gradient) against the oracle's fp64 autograd, or 2.5 x what the oracle's own fp32 run differs from it
 
 
 def build(sd, num_cls=20, bn=True):
@@ -408,14 +408,20 @@ def test_darknet_training_step_matches_oracle_autograd(bn):
     oloss.total(lo).backward()
     for k in lo:
         np.testing.assert_allclose(loss[k].item(), lo[k].item(), rtol=1e-4)
+    # the same step on the oracle in fp32: where a gradient is a cancellation residue (the weights in front of a batch-statistics BatchNorm) fp32
+    # itself is further from fp64 than 2e-4, whatever the implementation - the stated bound is max(2e-4, 2.5 x that floor)
+    sd32 = {k: v.clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    l32, _ = oloss.loss(anchors, data, ohead.decode(odark.forward(x, sd32, training=True), anchors), 0.6)
+    oloss.total(l32).backward()
     ours = dict(inf.dnn.named_parameters())
     worst = 0.0
     for k, v in sd64.items():
         if v.requires_grad:
             assert ours[k].grad is not None, k
             e = rel(ours[k].grad, v.grad)
+            floor = rel(sd32[k].grad, v.grad)
             worst = max(worst, e)
-            assert e <= GRAD_TOL, (k, e)   # the stated gradient tolerance (README): 2e-4 x rms vs the fp64 oracle at this width (measured 3.3e-5)
+            assert e <= max(GRAD_TOL, 2.5 * floor), (k, e, floor)
     bufs = dict(inf.dnn.named_buffers())
     for prefix, (rm, rv) in stats.items():
         np.testing.assert_allclose(bufs[prefix + '.bn.running_mean'].cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-6)

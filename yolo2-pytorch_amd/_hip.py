@@ -528,6 +528,9 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
         params.algo, params.tile = algo, tile
         params.w = wino_split.data_ptr() if algo in (4, 5) else wino_w.data_ptr() if algo in (1, 2, 3) else f43_w().data_ptr() if algo == 6 else w_direct
         params.w_plane = split_plane if algo in (4, 5) else 0
+        # the 4x4-tile filter operand exists only here: it must outlive this function (the caller launches with params AFTER it returns, and a
+        # workspace that grows in between would be handed the freed block): the tensor rides on the params object
+        params._f43_operand = f43_t if algo == 6 else None
         return choice
     if FORCE_GRAD is not None and f43 is not None:
         # a data gradient under a pinned gradient algorithm (no measurement, no cache)

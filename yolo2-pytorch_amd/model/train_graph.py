@@ -1009,6 +1009,47 @@ def _gen_conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, stride, pad, stats=No
     _hip.check(L.y2_conv_fwd(ctypes.byref(p), st), 'y2_conv_fwd')
 
 
+def _resnet_operands(net, dev, scope=None):
+    """{nn.Conv2d: dict(wp, wd)}: the forward / data-gradient GEMM operands of every convolution of a ResNet / Tiny plugin whose channel
+    counts need no padding, derived by ONE y2_prep_weights launch per parameter version (the per-layer path costs two y2_pack_weight
+    launches per convolution and step: 107 for ResNet-50).  scope: see _train_operands."""
+    import torch.nn as nn
+    convs = [m for m in net.modules() if isinstance(m, nn.Conv2d)]
+    key = (dev, tuple((c.weight.data_ptr(), c.weight._version) for c in convs))
+    if scope is not None:
+        bufs = scope
+    else:
+        cache = net.__dict__.get('_train_cache')
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        held = net.__dict__.get('_train_bufs')
+        if held is None or held[0] != dev:
+            held = net.__dict__['_train_bufs'] = (dev, {})
+        bufs = held[1]
+    items, ops = [], {}
+    for i, c in enumerate(convs):
+        w = c.weight.detach()
+        cout, cin, k, _ = w.shape
+        if cout % 4 or cin % 4 or not w.is_contiguous() or w.dtype != torch.float32 or not w.is_cuda:
+            continue          # the 3-channel stem and the 425-wide head run zero-padded: per-layer path
+        d = {}
+        for tag, mode in (('wp', _hip.PREP_FPROP), ('wd', _hip.PREP_DGRAD)):
+            t = bufs.get(('rn', i, tag))
+            if t is None or t.numel() != w.numel():
+                t = bufs[('rn', i, tag)] = torch.empty(w.numel(), dtype=torch.float32, device=dev)
+            d[tag] = t
+            items.append((w, t, cout, cin, k, mode))
+        ops[c] = d
+    if items:
+        table = (_hip.PrepItem * len(items))()
+        for e, (src, dst, cout, cin, k, mode) in zip(table, items):
+            e.src, e.dst, e.Cout, e.Cin, e.ksize, e.mode = src.data_ptr(), dst.data_ptr(), cout, cin, k, mode
+        _hip.check(_hip.lib().y2_prep_weights(table, len(items), _hip.stream()), 'y2_prep_weights')
+    if scope is None:
+        net.__dict__['_train_cache'] = (key, ops)
+    return ops
+
+
 class ResNetTrainFn(torch.autograd.Function):
     """Training graph of model.resnet.ResNet (model/resnet.py:29-158): per convolution {raw general conv with BN statistics in the
     epilogue -> y2_bn_finalize (momentum 0.1) -> y2_bn_act_fwd_ex (affine [+ residual] + ReLU)}; backward in reverse with
@@ -1030,6 +1071,17 @@ class ResNetTrainFn(torch.autograd.Function):
         dev = x.device
         ops = []
         ctx.frozen = frozen
+        scope = getattr(ctx, 'scope', None)
+        prepared = ctx.prepared = _resnet_operands(net, dev, scope)
+        ctx.prepared_key = net.__dict__['_train_cache'][0] if scope is None else None
+        import torch.nn as nn
+        # one zero-filled arena for the replicated BatchNorm-statistics accumulators of every convolution (one launch instead of 53 fills)
+        arena = None
+        if not frozen:
+            arena = torch.empty(_hip.STATS_REPL * 2 * sum(m.num_features for m in net.modules() if isinstance(m, nn.BatchNorm2d)), dtype=torch.float64, device=dev)
+            if arena.numel():
+                _hip.multi([(_hip.MULTI_ZERO, arena, None)])
+        used = [0]
         cpad = (cin0 + 3) // 4 * 4
         x4 = _new(dev, B, H, W, cpad)
         _hip.check(L.y2_nchw_to_nhwc(_hip.ptr(x), _hip.ptr(x4), B, cin0, H, W, cpad, st), 'y2_nchw_to_nhwc')
@@ -1045,11 +1097,17 @@ class ResNetTrainFn(torch.autograd.Function):
                 wpad = torch.zeros(cout, ldx, k, k, dtype=torch.float32, device=dev)
                 wpad[:, :cin_true] = weight
                 weight = wpad
-            wp = _new(dev, weight.numel())
-            _hip.check(L.y2_pack_weight(_hip.ptr(weight), _hip.ptr(wp), cout, ldx, k, 0, st), 'y2_pack_weight')
+            if conv in prepared and cin_true == ldx:
+                wp = prepared[conv]['wp']
+            else:
+                wp = _new(dev, weight.numel())
+                _hip.check(L.y2_pack_weight(_hip.ptr(weight), _hip.ptr(wp), cout, ldx, k, 0, st), 'y2_pack_weight')
             ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
             z = _new(dev, B, ho, wo, cout)
-            stats = torch.zeros(_hip.STATS_REPL * 2 * cout, dtype=torch.float64, device=dev) if (bn is not None and not frozen) else None
+            stats = None
+            if bn is not None and not frozen:
+                stats = arena[used[0]:used[0] + _hip.STATS_REPL * 2 * cout]
+                used[0] += _hip.STATS_REPL * 2 * cout
             det = _hip.ensure_deterministic(dev)
             _gen_conv(L, st, xin, wp, z, B, h, w, ldx, ldx, cout, k, stride, pad, stats=None if det else stats)
             if det and stats is not None:
@@ -1133,13 +1191,48 @@ class ResNetTrainFn(torch.autograd.Function):
         st = _hip.stream()
         net, ops, B = ctx.net, ctx.ops, ctx.B
         dev = dout.device
+        prepared = getattr(ctx, 'prepared', None) or {}
+        if prepared and getattr(ctx, 'prepared_key', None) is not None and net.__dict__.get('_train_cache', (None,))[0] != ctx.prepared_key:
+            raise RuntimeError('model.resnet: a convolution weight was modified between this forward and its backward; the per-model GEMM operand '
+                               'buffers this graph was recorded against hold other weights now')
         grads = {}
         hook = getattr(net, 'grad_ready_hook', None)
+        buffer_hook = getattr(net, 'grad_buffer_hook', None)
 
         def ready(param, g):
             grads[id(param)] = g
             if hook is not None:
                 hook(param, g)
+
+        def dest(param):
+            t = buffer_hook(param) if buffer_hook is not None else None
+            return t if t is not None else _new(dev, *param.shape)
+        convs = [op for op in ops if op.kind == 'conv']
+        # everything that must start from zero, filled by ONE launch: the fp64 sums of every BatchNorm backward, the accumulation targets of the
+        # direct (split, atomically added) weight gradients, the zero-padded gradient of the 425-wide head
+        sums_arena = torch.empty(2 * sum(op.cout for op in convs), dtype=torch.float64, device=dev)
+        zero = [sums_arena]
+        plan = {}
+        off = 0
+        for op in convs:
+            cout, cin, k = op.cout, op.ldx, op.k
+            cop = (cout + 3) // 4 * 4
+            e = plan[id(op)] = dict(sums=sums_arena[off:off + 2 * cout], off=off)
+            off += 2 * cout
+            e['dz'] = None
+            if cop != cout:
+                e['dz'] = _new(dev, B, op.ho, op.wo, cop)
+                zero.append(e['dz'])
+            wino = k == 3 and op.stride == 1 and op.pad == 1
+            e['wino'] = wino
+            if not wino:
+                # [cop][k*k][cin]: for a 1x1 convolution that IS the state_dict layout - the kernel writes the gradient tensor itself
+                direct_out = k == 1 and cop == cout and cin == op.cin
+                e['dwp'] = dest(op.conv.weight).view(-1) if direct_out else _new(dev, cop * k * k * cin)
+                e['final'] = direct_out
+                zero.append(e['dwp'])
+        _hip.multi([(_hip.MULTI_ZERO, t, None) for t in zero], st)
+        affine = []
         G = {id(ops[-1].y): [_hip.f32c(dout)]}      # gradient sources per activation tensor
         for op in reversed(ops):
             srcs = G.pop(id(op.y), [])
@@ -1153,8 +1246,8 @@ class ResNetTrainFn(torch.autograd.Function):
                 continue
             cout, cin, k, ho, wo = op.cout, op.ldx, op.k, op.ho, op.wo
             cop = (cout + 3) // 4 * 4
-            sums = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
-            dz = _new(dev, B, ho, wo, cop) if cop == cout else torch.zeros(B, ho, wo, cop, dtype=torch.float32, device=dev)
+            e = plan[id(op)]
+            sums, dz = e['sums'], (e['dz'] if e['dz'] is not None else _new(dev, B, ho, wo, cop))
             dres = _new(dev, B, ho, wo, cout) if op.residual is not None else None
             has_bn = op.bn is not None
             _hip.check(L.y2_bn_act_bwd_ex(_hip.ptr(op.z), _hip.ptr(op.scale), _hip.ptr(op.shift), _hip.ptr(op.mean), _hip.ptr(op.invstd),
@@ -1165,41 +1258,60 @@ class ResNetTrainFn(torch.autograd.Function):
                                           _hip.ptr(sums), _hip.ptr(dz), cop, B, ho, wo, cout, cout, (2 if ctx.frozen else 1) if has_bn else 0, st), 'y2_bn_act_bwd_ex')
             if op.residual is not None:
                 G.setdefault(id(op.residual), []).append(dres)
+            # parameter gradients of the affine part = the fp64 sums of pass 1: converted for ALL layers by one launch after the loop
             if has_bn:
-                gb = _new(dev, 2 * cout)
-                _hip.check(L.y2_f64_to_f32(_hip.ptr(sums), _hip.ptr(gb), 2 * cout, 1.0, st), 'y2_f64_to_f32')
-                ready(op.bn.bias, gb[:cout])
-                ready(op.bn.weight, gb[cout:])
+                affine.append((op.bn.bias, e['off'], cout))
+                affine.append((op.bn.weight, e['off'] + cout, cout))
             elif op.conv.bias is not None:
-                gb = _new(dev, cout)
-                _hip.check(L.y2_f64_to_f32(_hip.ptr(sums), _hip.ptr(gb), cout, 1.0, st), 'y2_f64_to_f32')
-                ready(op.conv.bias, gb)
+                affine.append((op.conv.bias, e['off'], cout))
             # ---- weight gradient
-            if k == 3 and op.stride == 1 and op.pad == 1:
+            if e['wino']:
                 dwp = _hip.conv_wgrad(op.x, dz, B, op.h, op.w, cin, cin, cop, cop, k)     # direct or Winograd, by measurement
             else:
-                dwp = torch.zeros(cop * k * k * cin, dtype=torch.float32, device=dev)
+                dwp = e['dwp']
                 _hip.check(L.y2_conv_wgrad_ex(_hip.ptr(op.x), _hip.ptr(dz), _hip.ptr(dwp), B, op.h, op.w, cin, cin, cop, cop, k, op.stride, op.pad, st), 'y2_conv_wgrad_ex')
-            dw = _new(dev, cop, cin, k, k)
-            _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cop, cin, k, st), 'y2_unpack_weight_grad')
-            ready(op.conv.weight, dw if (cop == cout and cin == op.cin) else dw[:cout, :op.cin].contiguous())
+            if not e['wino'] and e['final']:
+                ready(op.conv.weight, dwp.view(cout, cin, 1, 1))
+            else:
+                dw = dest(op.conv.weight) if (cop == cout and cin == op.cin) else _new(dev, cop, cin, k, k)
+                _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cop, cin, k, st), 'y2_unpack_weight_grad')
+                ready(op.conv.weight, dw if (cop == cout and cin == op.cin) else dw[:cout, :op.cin].contiguous())
             op.z = None
             if op.first and not ctx.need_dx:
                 continue
             # ---- data gradient (of the first layer only when the image's gradient is wanted: its result is the 4-channel NHWC image gradient)
-            wsrc = _hip.f32c(op.conv.weight.detach())
-            if cop != cout or wsrc.shape[1] != cin:          # zero rows for padded output channels, zero columns for the stem's padded input channels
-                wpad = torch.zeros(cop, cin, k, k, dtype=torch.float32, device=dev)
-                wpad[:cout, :wsrc.shape[1]] = wsrc
-                wsrc = wpad
-            wd = _new(dev, wsrc.numel())
-            _hip.check(L.y2_pack_weight(_hip.ptr(wsrc), _hip.ptr(wd), cop, cin, k, 1, st), 'y2_pack_weight')
+            ready_ops = prepared.get(op.conv)
+            if ready_ops is not None and cop == cout and op.cin == cin:
+                wd = ready_ops['wd']          # rotated / in-out-swapped operand prepared with the forward's (same parameter version)
+            else:
+                wsrc = _hip.f32c(op.conv.weight.detach())
+                if cop != cout or wsrc.shape[1] != cin:          # zero rows for padded output channels, zero columns for the stem's padded input channels
+                    wpad = torch.zeros(cop, cin, k, k, dtype=torch.float32, device=dev)
+                    wpad[:cout, :wsrc.shape[1]] = wsrc
+                    wsrc = wpad
+                wd = _new(dev, wsrc.numel())
+                _hip.check(L.y2_pack_weight(_hip.ptr(wsrc), _hip.ptr(wd), cop, cin, k, 1, st), 'y2_pack_weight')
             dx = _new(dev, B, op.h, op.w, cin)
             if op.stride == 1:
                 _gen_conv(L, st, dz, wd, dx, B, ho, wo, cop, cop, cin, k, 1, k - 1 - op.pad)
             else:
                 _gen_conv(L, st, dz, wd, dx, B, ho, wo, cop, cop, cin, k, op.stride, op.pad, transposed=True, out_hw=(op.h, op.w))
             G.setdefault(id(op.x), []).append(dx)
+        # ---- affine-parameter gradients: fp64 sums -> fp32, one launch; straight into the data-parallel bucket slices when there are any
+        items, handed, gb_all = [], [], None
+        for prm, o, ln in affine:
+            t = buffer_hook(prm) if buffer_hook is not None else None
+            if t is None:
+                if gb_all is None:
+                    gb_all = _new(dev, sums_arena.numel())
+                    items.append((_hip.MULTI_F64_TO_F32, gb_all, sums_arena))
+                t = gb_all[o:o + ln]
+            else:
+                items.append((_hip.MULTI_F64_TO_F32, t, sums_arena[o:o + ln]))
+            handed.append((prm, t))
+        _hip.multi(items, st)
+        for prm, t in handed:
+            ready(prm, t)
         dx_img = None
         if ctx.need_dx:
             gx = G.pop(id(ctx.x4), None)
@@ -1209,6 +1321,7 @@ class ResNetTrainFn(torch.autograd.Function):
         for pid in ctx.param_ids:
             out.append(grads.get(pid))
         ctx.ops = None
+        ctx.prepared = None
         return tuple(out)
 
 
@@ -1380,6 +1493,7 @@ class StepPlan(object):
             if self.darknet:
                 head = _darknet_fwd(tape, dnn, st['x'], self.params, False, scope=self.scope if seg is not None else None)
             else:
+                tape.scope = self.scope if seg is not None else None
                 head = ResNetTrainFn.forward(tape, dnn, st['x'], False, *self.params)
             B, rows, cols, _ = head.shape
             dt, lt = _Tape(), _Tape()
