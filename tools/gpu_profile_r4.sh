@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.." || exit 1
 R=$PWD; O=$R/gpurun_out/prof4; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
 export Y2_TRAIN_GRAPH=0      # the traced training steps issue the launch sequence eagerly (the same kernels the timed step replays from its hipGraph)
-DET="python $R/bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3 --no-split-leg --no-multiscale"
+DET="python $R/bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3 --no-split-leg --no-multiscale --no-latency --no-resnet"
 TRN="python $R/tools/train_steady.py ${TRAIN_STEPS:-12}"
 export Y2_TUNE_CACHE=/tmp/y2_tune_r4.json
 $DET > /dev/null 2>&1; $TRN > $O/train_plain.json 2>/dev/null      # populate the algorithm cache: the profiled runs contain steady-state launches only
