@@ -283,3 +283,32 @@ def test_dp_world2_graph_segments_interoperate_with_the_hook_path(tmp_path):
         for k, v in out[name][0]['grads'].items():
             assert torch.equal(v, out[name][1]['grads'][k]), (name, k)
             assert rel(v, out['hooks'][0]['grads'][k]) <= 50 * STEP_TOL, (name, 'grad', k)
+
+
+def test_plans_are_recaptured_after_the_model_moved_to_the_cpu_and_back():
+    """train.py:423-432: Train.eval moves the inference module to the CPU and back between training steps.  The Parameters are the same
+    objects afterwards but live in new memory: a captured graph would read the old addresses.  The runner must notice and re-capture."""
+    import train as y2train
+    import utils
+    inf, anchors = build('darknet')
+    opt = utils.optim.SGD(inf.parameters(), 0.0, momentum=0.9)
+    data = batches(96, 3)
+    for i in range(5):
+        r = y2train.iterate(inf, opt, data[i % 3], oloss.HPARAM, 0.6, anchors)
+    runner = inf.__dict__['_y2_step_runner']
+    assert runner.captures == 1
+    before = [float(r['loss'][k].detach()) for k in r['loss']]
+    g_before = {k: p.grad.detach().clone() for k, p in inf.dnn.named_parameters()}
+    inf.cpu()
+    torch.cuda.empty_cache()
+    junk = torch.full((64 << 20,), float('nan'), device=dev())          # whatever the old parameter memory is handed to next
+    inf.cuda()
+    opt = utils.optim.SGD(inf.parameters(), 0.0, momentum=0.9)
+    for i in range(5):                                                    # same batch as the step whose results were kept (i = 4 -> data[1])
+        r = y2train.iterate(inf, opt, data[1], oloss.HPARAM, 0.6, anchors)
+    assert runner.captures == 2 and not runner.broken
+    after = [float(r['loss'][k].detach()) for k in r['loss']]
+    np.testing.assert_allclose(after, before, rtol=2e-5)
+    for k, p in inf.dnn.named_parameters():
+        assert rel(p.grad, g_before[k]) <= 1e-3, k
+    del junk

@@ -1603,6 +1603,19 @@ class StepPlan(object):
                 _hip.SCOPE = prev_scope
         cur.wait_stream(side)
         self.ops, self.grads = seg.ops, grads
+        self._baked = self._addresses()
+
+    def _addresses(self):
+        """What a captured graph holds by ADDRESS besides its own pool: parameters, BatchNorm buffers, the wrapper's flat buckets."""
+        a = [t.data_ptr() for t in self.params] + [t.data_ptr() for t in self.buffers]
+        if self.dp is not None:
+            a += [f.data_ptr() for f in self.dp._flat]
+        return a
+
+    def valid(self):
+        """False when the memory a captured graph was recorded against has moved: `Train.eval` takes the model to the CPU and back between
+        training steps (train.py:423-432) - the Parameters are the same objects afterwards, their storage is not."""
+        return self.ops is None or self._baked == self._addresses()
 
 
 _CAPTURE_STREAMS = {}

@@ -498,6 +498,10 @@ class StepRunner(object):
         shape = (tuple(x.shape), tuple(cls.shape[2:]), cls.dim())
         key = shape + (npad, _hip.tune_epoch(), _hip.WINOGRAD, _hip.split_mode(), _hip.FORCE_ALGO, train_graph.GRAD_F43, train_graph.FUSE_CONV0, str(x.device))
         plan = self.plans.get(key)
+        if plan is not None and not plan.valid():
+            self.plans.clear()          # the model (or the wrapper's buckets) moved - .cpu() / .cuda() around an evaluation: every graph holds dead addresses
+            self._params_ok = None
+            plan = None
         if plan is None:
             for k in [k for k in self.plans if k[:3] == shape and k[4] != key[4]]:
                 del self.plans[k]                    # measured on another algorithm table
