@@ -108,6 +108,10 @@ CASES = [
     (2, 32, 64, 16, 24, 3, 1), (2, 32, 64, 16, 24, 3, 2), (2, 32, 64, 16, 24, 3, 3), (2, 32, 64, 16, 24, 3, 4), (2, 32, 64, 16, 24, 3, 5),
     (1, 64, 128, 13, 13, 3, 0), (2, 32, 64, 16, 24, 3, 7), (3, 512, 256, 13, 13, 3, 7), (2, 64, 125, 9, 7, 1, 7), (2, 16, 48, 10, 6, 3, 7), (3, 128, 64, 13, 13, 1, 0), (2, 96, 125, 7, 9, 1, 0), (2, 40, 72, 10, 6, 3, 1),
     (2, 64, 160, 20, 24, 3, 8), (2, 96, 288, 13, 13, 3, 9), (3, 128, 128, 16, 16, 1, 8), (2, 40, 72, 10, 6, 3, 9),
+    # persistent workgroups (tile ids 11 / 12 / 13 / 15): more tiles than resident workgroups (several tiles per workgroup, odd and even slab counts per
+    # tile: the LDS buffer parity carries over), fewer tiles than workgroups, ragged rows / channels, one K slab per tile, 3x3 taps
+    (37, 64, 96, 40, 44, 1, 13), (37, 64, 96, 40, 44, 1, 15), (21, 96, 200, 52, 52, 1, 12), (9, 160, 136, 64, 60, 1, 11), (33, 32, 72, 48, 50, 1, 13),
+    (2, 128, 64, 13, 13, 1, 15), (25, 32, 64, 36, 40, 3, 13), (12, 96, 125, 30, 34, 3, 15), (40, 224, 64, 40, 40, 1, 13),
     (2, 6, 20, 8, 8, 3, 0), (2, 64, 32, 16, 24, 3, 6), (3, 512, 256, 13, 13, 3, 5), (2, 1024, 125, 13, 13, 1, 3), (2, 64, 24, 16, 24, 3, 0), (1, 13, 33, 5, 7, 1, 2), (2, 256, 512, 13, 13, 3, 0),
 ]
 

@@ -461,6 +461,7 @@ FORCE_GRAD = os.environ.get('Y2_FORCE_GRAD_ALGO') or None
 FORCE_WGRAD = os.environ.get('Y2_FORCE_WGRAD') or None
 if FORCE_GRAD not in (None, 'f43', 'direct') or FORCE_WGRAD not in (None, 'direct', 'wino', 'f34'):
     raise ValueError('Y2_FORCE_GRAD_ALGO must be f43 or direct, Y2_FORCE_WGRAD direct, wino or f34')
+PERSIST = os.environ.get('Y2_CONV_PERSIST', '1') != '0'      # 0: never offer the persistent-workgroup tiles (11 / 12 / 13 / 15) of the direct kernel (A/B runs)
 IMPLICIT = os.environ.get('Y2_WINO_IMPLICIT', '1') != '0'  # 0: never offer Y2_ALGO_WINOGRAD_IMPLICIT (A/B runs)
 WINO_MIN_CIN = 32                                        # below this the transforms cost more than the GEMM saves (measured; 32: the 208x208 layer, one K slab per tile of the fused kernels)
 
@@ -582,6 +583,8 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
     big = params.B * params.H * params.W >= 65536 and params.Cout >= 128 and params.ksize in (1, 3) and params.stride in (0, 1) \
         and params.pad_plus1 in (0, (params.ksize - 1) // 2 + 1) and not params.transposed and not params.residual
     cands = [(0, t) for t in [5, 3, 2, 1] + ([6] if params.Cout <= 32 else []) + ([8, 9] if big else [])]      # 8, 9: 512-thread 256x128 / 128x256 tiles
+    if PERSIST and params.ksize == 1 and params.stride in (0, 1) and params.pad_plus1 in (0, 1) and not params.transposed and not params.y_pool and params.Cin % 32 == 0:
+        cands += [(0, t) for t in (15, 13, 12, 11)]      # 1x1 layers (short K loops): persistent workgroups, next tile's first slab fetched under the current tile's last
     if wino_ok:
         cands += [(1, t) for t in (5, 3, 2, 1)]
         if params.Cin % 32 == 0:

@@ -418,9 +418,16 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvArgs a) {
 //   * 2-deep ring: iteration s = {vmcnt(0); barrier; issue DMA of slab s+1; 16 ds_read_b128 + 64 MFMA on slab s}.
 // Requirements (host checks, else the register-staged kernel runs): Cin, ldx multiples of 4, 16-B aligned bases,
 // tensors < 2^31 bytes.
-template <int BM, int BN, int WAVES_M, bool POOLORD, bool CTAIL, int STAGES = 2, bool GEN = false, int NTH = NT>
+//
+// PERSIST (round 4; tile ids 11 / 12 / 13 / 15 = the 128x128 / 128x64 / 64x64 / 64x128 tiles): a workgroup keeps its CU slot and walks
+// tiles b, b + G, b + 2G, ... (G = resident workgroups of the launch); the first K slab of the NEXT tile is requested behind the barrier of
+// the current tile's last slab, so its DMA latency runs under the last slab's MFMAs and the epilogue.  Aimed at the short-K layers (1x1
+// convolutions: 2 ... 32 slabs per tile), where every tile of the one-tile-per-workgroup form starts with an exposed first fetch - and
+// all workgroups of a CU reach that point together, because they were launched together and their tiles cost the same.
+template <int BM, int BN, int WAVES_M, bool POOLORD, bool CTAIL, int STAGES = 2, bool GEN = false, int NTH = NT, bool PERSIST = false>
 __global__ __launch_bounds__(NTH) void conv_fwd_dma_kernel(const ConvArgs a) {
     constexpr int BK = 32;
+    static_assert(!PERSIST || (!GEN && STAGES == 2), "the persistent form covers the standard two-stage kernel");
     constexpr int WAVES_N = (NTH / 64) / WAVES_M;
     constexpr int RPP = NTH / 8;                  // rows staged per DMA pass (8 lanes per 128-B row)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(NTH) void conv_fwd_dma_kernel(const ConvArgs a) {
     const float* gw_ptr = a.w + (size_t)grp * a.gw;
     const int tile_n = tile % a.tiles_n;
     const int tile_m = tile / a.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    int m0 = tile_m * BM, n0 = tile_n * BN;                    // (PERSIST: moved to the next tile by setup_tile)
 
     // ---- staging assignment: lane -> physical 16-B slot p = lane & 7 of row (t>>3) + 32*i; it fetches logical chunk p ^ swz(row)
     const int srow = t >> 3;                                   // 0..31 (rows 8*wave .. 8*wave+7)
@@ -470,6 +477,39 @@ __global__ __launch_bounds__(NTH) void conv_fwd_dma_kernel(const ConvArgs a) {
     int a_yb[AR], a_xb[AR];                                     // GEN: input coordinates of tap (0,0) for this output pixel
     const int up_left = (a.taps == 9) ? (a.W + 1) : 0;
     const int ktot = GEN ? a.K : a.taps * a.Cin;
+    unsigned b_base[BR];
+    // PERSIST: the row / column bookkeeping of tile number v (virtual block index: the XCD remap sees the same b % 8 for every tile of a workgroup)
+    auto setup_tile = [&](int v) {
+        const int tl = y2_xcd_remap(v, a.full_tiles);
+        const int tn = tl % a.tiles_n, tm = tl / a.tiles_n;
+        m0 = tm * BM; n0 = tn * BN;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int m = m0 + srow + RPP * i;
+            unsigned mask = 0;
+            int pix = 0;
+            if (m < a.M) {
+                int y, x;
+                decode_row<POOLORD>(a, m, pix, y, x);
+                if (a.taps == 9) {
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) {
+                        const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                        if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) mask |= 1u << tp;
+                    }
+                } else {
+                    mask = 1u;
+                }
+            }
+            a_mask[i] = mask;
+            a_base[i] = (unsigned)(((long long)(pix - up_left) * a.ldx + 4 * lchunk) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int n = n0 + srow + RPP * i;
+            b_base[i] = n < a.Cout ? (unsigned)(((size_t)n * ktot + 4 * lchunk) * 4) : OOB;
+        }
+    };
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + srow + RPP * i;
@@ -508,7 +548,6 @@ __global__ __launch_bounds__(NTH) void conv_fwd_dma_kernel(const ConvArgs a) {
             a_base[i] = (unsigned)(((long long)(pix - up_left) * a.ldx + 4 * lchunk) * 4);   // may wrap below 0: only used when the tap is valid
         }
     }
-    unsigned b_base[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
         const int n = n0 + srow + RPP * i;
@@ -662,6 +701,44 @@ __global__ __launch_bounds__(NTH) void conv_fwd_dma_kernel(const ConvArgs a) {
         for (int j = (TOTAL + EVERY - 1) / EVERY; j < NPIECES; ++j) issue_piece(ntap, nc0, nbuf, j);
     };
 
+    if constexpr (PERSIST) {
+        // ---- tiles b, b + G, ...: slab s of a tile lives in LDS buffer (pb + s) & 1; the barrier in front of a tile's LAST slab has seen every
+        // wave finish slab nk-2, whose buffer is the one the next tile's first slab is fetched into
+        const int nkp = a.taps * a.cchunks;
+        int v = blockIdx.x, pb = 0;
+        setup_tile(v);                  // (the remap must be the one of the whole tile list for EVERY tile of the walk, the first included)
+        issue_slab(0, 0, 0, 0);
+        for (;;) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            int ptap = 0, pc0 = 0;
+            for (int ks = 0; ks < nkp - 1; ++ks) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                pc0 += BK;
+                if (pc0 >= a.Cin) { pc0 = 0; ++ptap; }
+                compute_slab_spread((pb + ks) & 1, ptap, pc0, (pb + ks + 1) & 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int cm0 = m0, cn0 = n0;
+            const int vn = v + (int)gridDim.x;
+            const bool more = vn < a.full_tiles;
+            if (more) {
+                setup_tile(vn);
+                issue_slab(0, 0, 0, (pb + nkp) & 1);
+            }
+            compute_slab((pb + nkp - 1) & 1);
+            conv_epilogue<MB, NB, WM, WN, POOLORD>(a, acc, cm0, cn0, wm, wn, l31, half);
+            if (!more) return;
+            v = vn;
+            pb = (pb + nkp) & 1;
+        }
+    }
     const int nk_all = GEN ? (a.K + BK - 1) / BK : a.taps * a.cchunks;
     int ks0 = 0, ks1 = nk_all;
     if (is_split) {
@@ -821,7 +898,7 @@ inline void plan_split(long long tiles, int nk, long long tile_elems, size_t ws_
     full_tiles = (int)(tiles - rem); ksplit = bs;
 }
 
-template <int BM, int BN, int WAVES_M, bool POOLORD, bool GEN = false, int NTH = NT>
+template <int BM, int BN, int WAVES_M, bool POOLORD, bool GEN = false, int NTH = NT, bool PERSIST = false>
 int launch_dma(const ConvArgs& a0, hipStream_t stream, float* ws, size_t ws_bytes, size_t* ws_need) {
     ConvArgs a = a0;
     a.tiles_m = y2_cdiv(a.M, BM);
@@ -838,6 +915,33 @@ int launch_dma(const ConvArgs& a0, hipStream_t stream, float* ws, size_t ws_byte
         int ft, ks;
         plan_split(tiles, nk_all, (long long)BM * BN, (size_t)-1, ft, ks);
         *ws_need = (size_t)(tiles - ft) * ks * BM * BN * sizeof(float);
+        return Y2_OK;
+    }
+    if (PERSIST) {
+        // persistent workgroups: as many as the chip holds at once (never split: the tile loop evens the rounds out)
+        if (GEN || ctail || a.groups > 1) return Y2_ENOSUP;
+        if (ws_need != nullptr) { *ws_need = 0; return Y2_OK; }
+        a.full_tiles = (int)tiles; a.ksplit = 1; a.partial = nullptr;
+        auto kern = conv_fwd_dma_kernel<BM, BN, WAVES_M, POOLORD, false, 2, false, NTH, PERSIST>;
+        static Y2LdsAttr attr_p;
+        if (const int rc_ = attr_p.ensure(reinterpret_cast<const void*>(kern))) return rc_;
+        static int resident = 0;                           // workgroups one CU holds (registers, LDS), asked once per instantiation
+        if (resident == 0) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NTH, lds) != hipSuccess || nb < 1) nb = 1;
+            resident = nb > 4 ? 4 : nb;
+        }
+        const long long slots = (long long)Y2_NUM_CU * resident;
+        long long g = tiles;
+        if (tiles > slots) {
+            // every workgroup walks the same number of tiles where that is possible: ceil(tiles / rounds) workgroups (a multiple of 8: a
+            // workgroup's tiles stay on its XCD's chunk of the list) instead of `slots` of which some would walk one tile more
+            const long long rounds = (tiles + slots - 1) / slots;
+            g = ((tiles + rounds - 1) / rounds + 7) / 8 * 8;
+            if (g > slots) g = slots;
+        }
+        Y2_LAUNCH("conv_fwd_dma_kernel[persistent]", 2.0 * (double)a.M * a.Cout * a.taps * a.Cin, kern, dim3((unsigned)g), dim3(NTH), lds, stream, a);
+        Y2_LAUNCH_CHECK();
         return Y2_OK;
     }
     plan_split(tiles, nk_all, (long long)BM * BN, ws != nullptr ? ws_bytes : 0, a.full_tiles, a.ksplit);
@@ -1107,6 +1211,11 @@ int dispatch_dma(const ConvArgs& a, int tile, hipStream_t s, float* ws, size_t w
         case 3: return launch_dma<64, 64, 2, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);
         case 5: return launch_dma<64, 128, 2, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);
         case 6: return launch_dma<128, 32, 4, POOLORD, GEN>(a, s, ws, ws_bytes, ws_need);
+        // persistent workgroups with the next tile's first slab fetched under the current tile's last one (un-pooled standard convolutions)
+        case 11: if (!GEN && !POOLORD) return launch_dma<128, 128, 2, false, false, NT, true>(a, s, ws, ws_bytes, ws_need); return Y2_ENOSUP;
+        case 12: if (!GEN && !POOLORD) return launch_dma<128, 64, 2, false, false, NT, true>(a, s, ws, ws_bytes, ws_need); return Y2_ENOSUP;
+        case 13: if (!GEN && !POOLORD) return launch_dma<64, 64, 2, false, false, NT, true>(a, s, ws, ws_bytes, ws_need); return Y2_ENOSUP;
+        case 15: if (!GEN && !POOLORD) return launch_dma<64, 128, 2, false, false, NT, true>(a, s, ws, ws_bytes, ws_need); return Y2_ENOSUP;
         case 8: if (!GEN) return launch_dma<256, 128, 4, POOLORD, false, 512>(a, s, ws, ws_bytes, ws_need); return Y2_ENOSUP;   // 8 waves: 2 per SIMD, 96 KB LDS, 6 B/clk operand DMA
         case 9: if (!GEN) return launch_dma<128, 256, 2, POOLORD, false, 512>(a, s, ws, ws_bytes, ws_need); return Y2_ENOSUP;
         case 7: if (!GEN) return launch_wave<POOLORD>(a, s, ws, ws_bytes, ws_need); return Y2_ENOSUP;   // barrier-free wave-private 64x64 tiles   // narrow outputs (Cout <= 32: dgrad into the first layers)
@@ -1244,9 +1353,11 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
     // variants and small Cin (K handled as one linear axis) use the GEN instantiation of the DMA kernel.
     const unsigned long long xb = (unsigned long long)Min * p->ldx * 4ull, wb = (unsigned long long)p->Cout * a.taps * p->Cin * 4ull;
     if (tile == 7 && (!standard || (p->Cin % 16) != 0 || groups > 1)) tile = 3;      // the wave-private kernel covers the standard convolutions only
-    const bool dma_tile = (tile == 1 || tile == 2 || tile == 3 || tile == 5 || tile == 6 || tile == 7 || tile == 8 || tile == 9);
+    const bool persist = tile == 11 || tile == 12 || tile == 13 || tile == 15;
+    if (persist && (!standard || groups > 1 || pool || (p->Cin % 32) != 0 || !vec)) return Y2_ENOSUP;      // (the caller offered a form this problem has none of)
+    const bool dma_tile = (tile == 1 || tile == 2 || tile == 3 || tile == 5 || tile == 6 || tile == 7 || tile == 8 || tile == 9 || persist);
     const bool dma_ok = vec && xb < 0x7fffffffull && wb < 0x7fffffffull && dma_tile;
-    const bool gen = !standard || (groups == 1 && dma_ok && tile != 7 && tile != 8 && tile != 9 && p->Cin < 32 && !pool && p->out_mode == 0);
+    const bool gen = !standard || (groups == 1 && dma_ok && tile != 7 && tile != 8 && tile != 9 && !persist && p->Cin < 32 && !pool && p->out_mode == 0);
     if (groups > 1 && (!dma_ok || gen || pool || p->out_mode != 0 || p->stats != nullptr || p->residual != nullptr)) return Y2_ENOSUP;
     float* ws = p->workspace;
     const size_t wsb = (ws != nullptr && y2_aligned16(ws)) ? (size_t)p->workspace_bytes : 0;
@@ -1255,6 +1366,7 @@ static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws
         a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
         return dispatch_dma<false, true>(a, tile, s, ws, wsb, ws_need);
     }
+    if (persist && !dma_ok) return Y2_ENOSUP;
     if (dma_ok) {
         a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
         return pool ? dispatch_dma<true>(a, tile, s, ws, wsb, ws_need) : dispatch_dma<false>(a, tile, s, ws, wsb, ws_need);
