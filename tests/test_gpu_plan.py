@@ -299,10 +299,12 @@ def test_plans_are_recaptured_after_the_model_moved_to_the_cpu_and_back():
     assert runner.captures == 1
     before = [float(r['loss'][k].detach()) for k in r['loss']]
     g_before = {k: p.grad.detach().clone() for k, p in inf.dnn.named_parameters()}
+    old = [t.data for t in list(inf.parameters()) + list(inf.buffers())]      # held: the round trip cannot land on the same addresses
     inf.cpu()
-    torch.cuda.empty_cache()
-    junk = torch.full((64 << 20,), float('nan'), device=dev())          # whatever the old parameter memory is handed to next
     inf.cuda()
+    for t in old:
+        if t.dtype.is_floating_point:
+            t.fill_(float('nan'))                                          # whoever still reads the old memory computes NaN
     opt = utils.optim.SGD(inf.parameters(), 0.0, momentum=0.9)
     for i in range(5):                                                    # same batch as the step whose results were kept (i = 4 -> data[1])
         r = y2train.iterate(inf, opt, data[1], oloss.HPARAM, 0.6, anchors)
@@ -311,4 +313,4 @@ def test_plans_are_recaptured_after_the_model_moved_to_the_cpu_and_back():
     np.testing.assert_allclose(after, before, rtol=2e-5)
     for k, p in inf.dnn.named_parameters():
         assert rel(p.grad, g_before[k]) <= 1e-3, k
-    del junk
+    del old
