@@ -505,7 +505,8 @@ class StepRunner(object):
         if plan is None:
             for k in [k for k in self.plans if k[:3] == shape and k[4] != key[4]]:
                 del self.plans[k]                    # measured on another algorithm table
-            if self.pool is None:
+            if self.pool is None or not any(p.ops is not None for p in self.plans.values()):
+                # (a pool lives as long as a graph captured into it: once the last one is gone its handle is dead - torch asserts on reuse)
                 self.pool = torch.cuda.graph_pool_handle()
             plan = train_graph.StepPlan(self.inference, self.anchors, self.hparam, self.threshold, dp=self.dp, pool=self.pool)
             plan._alloc(data, npad)
