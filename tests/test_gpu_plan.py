@@ -314,3 +314,86 @@ def test_plans_are_recaptured_after_the_model_moved_to_the_cpu_and_back():
     for k, p in inf.dnn.named_parameters():
         assert rel(p.grad, g_before[k]) <= 1e-3, k
     del old
+
+
+@pytest.mark.parametrize('B,HW,cin,cout', [(64, 52, 128, 256), (16, 104, 64, 128), (64, 13, 512, 1024)])
+@pytest.mark.parametrize('flags', [1, 3])
+def test_winograd_weight_gradient_is_replay_safe(B, HW, cin, cout, flags):
+    """A captured library call must re-establish everything it reads: the Winograd weight gradients zero their split accumulators first - with
+    hipMemsetAsync until round 4, and a memset node of a captured hipGraph ran at the graph's FIRST launch only on this runtime: the first replay of
+    a training step was right, every later one accumulated onto whatever the scratch held.  Replays on changing inputs with the scratch poisoned in
+    between must equal eager calls."""
+    import _hip
+    L = _hip.lib()
+    d = dev()
+    x = torch.randn(B, HW, HW, cin, device=d)
+    dz = torch.randn(B, HW, HW, cout, device=d) * 1e-3
+    ws = torch.empty(L.y2_wino_wgrad_workspace_bytes(B, HW, HW, cin, cout) // 4 + 4, device=d)
+    out, ref = torch.empty(cout, cin, 3, 3, device=d), torch.empty(cout, cin, 3, 3, device=d)
+
+    def call(dst):
+        _hip.check(L.y2_wino_wgrad_ex(_hip.ptr(x), _hip.ptr(dz), _hip.ptr(dst), B, HW, HW, cin, cin, cout, cout, None, _hip.ptr(ws), ws.numel() * 4, flags, _hip.stream()), 'wgrad')
+    call(ref)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        g.capture_begin()
+        call(out)
+        g.capture_end()
+    torch.cuda.current_stream().wait_stream(s)
+    for rep in range(3):
+        x.normal_()
+        dz.normal_().mul_(1e-3)
+        ws.fill_(float('nan') if rep == 1 else 1e30)
+        g.replay()
+        torch.cuda.synchronize()
+        got = out.clone()
+        ws.zero_()
+        call(ref)
+        torch.cuda.synchronize()
+        assert rel(got, ref) <= 1e-4, (rep, rel(got, ref))         # (split partial sums are added atomically: not bit-equal)
+
+
+def test_full_width_replays_equal_the_autograd_step():
+    """The narrow networks above never split a Winograd weight-gradient reduction; the full-width network does (that is where the memset bug hid).
+    Full-width Darknet-19, 416x416, batch 4: the 6th step of train.iterate (its 2nd and 3rd REPLAY, learning rate 0) against the autograd path on
+    the same batches."""
+    import model
+    import model.yolo2
+    import train as y2train
+    import utils
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1'}})
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    sd = odark.init_state_dict(5, 20, seed=0, head_scale=1 / 40.0)
+    data = []
+    for i in range(2):
+        d = {k: v.to(dev()) for k, v in synth.labels(4, 416, 20, nmax=6, seed=40 + i).items()}
+        d['tensor'] = synth.images(4, 416, seed=50 + i).to(dev())
+        data.append(d)
+    runs = {}
+    for plan in (False, True):
+        y2train.PLAN = plan
+        try:
+            dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, 20)
+            dnn.load_state_dict(sd, strict=False)
+            inf = model.Inference(cfg, dnn, anchors).to(dev()).train()
+            opt = utils.optim.SGD(inf.parameters(), 0.0)
+            rows = []
+            for i in range(7):
+                r = y2train.iterate(inf, opt, data[i % 2], oloss.HPARAM, 0.6, anchors)
+                rows.append(([float(r['loss'][k].detach()) for k in r['loss']], {k: p.grad.detach().clone() for k, p in dnn.named_parameters()} if i >= 5 else None))
+            torch.cuda.synchronize()
+            runs[plan] = rows
+            if plan:
+                assert inf.__dict__['_y2_step_runner'].captures == 1
+        finally:
+            y2train.PLAN = True
+    for i, ((la, ga), (lb, gb)) in enumerate(zip(runs[False], runs[True])):
+        np.testing.assert_allclose(lb, la, rtol=2e-5, err_msg='step %d' % i)
+        if ga is not None:
+            for k in ga:
+                # run-to-run noise of the cancellation-residue gradients (completion-order atomics in front of 23 batch-statistics BatchNorm layers)
+                assert rel(gb[k], ga[k]) <= 2e-2, (i, k, rel(gb[k], ga[k]))

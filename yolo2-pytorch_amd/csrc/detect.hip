@@ -350,10 +350,22 @@ extern "C" int y2_decode(const float* feature, const float* anchors, int B, int 
     return Y2_OK;
 }
 
+namespace {
+// (a kernel, not hipMemsetAsync: memset nodes of a captured hipGraph ran at the first launch only on this runtime, see wino.hip: zero_fill_kernel)
+__global__ void zero_i32_kernel(int32_t* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+}  // namespace
+
 extern "C" int y2_filter_visible(const float* iou, const float* prob, int B, int n, int C, int fix, float thr,
                                  int32_t* count, int32_t* index, float* prob_cls, int32_t* cls, y2_stream_t stream) {
     if (!iou || !count || !index || B <= 0 || n < 0) return Y2_EINVAL;
-    if (n == 0) { (void)hipMemsetAsync(count, 0, sizeof(int32_t) * B, y2_s(stream)); return Y2_OK; }
+    if (n == 0) {
+        Y2_LAUNCH("zero_i32_kernel", 0.0, zero_i32_kernel, dim3(y2_cdiv(B, 256)), dim3(256), 0, y2_s(stream), count, B);
+        Y2_LAUNCH_CHECK();
+        return Y2_OK;
+    }
     if (prob != nullptr) {
         if (!prob_cls || !cls || C < 1) return Y2_EINVAL;
         const long long rows = (long long)B * n;

@@ -1819,6 +1819,21 @@ extern "C" int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, 
     return y2_wino_wgrad_ex(x, dz, dw_packed, B, H, W, Cin, ldx, Cout, ldz, v_transformed, workspace, workspace_bytes, 0, stream);
 }
 
+// Zero fill of the split accumulators by a KERNEL, not hipMemsetAsync: a memset captured into a hipGraph ran at the graph's first launch only on this
+// runtime (ROCm 7.0 / 7.2: tools/debug/replay_wgrad.py - every later replay accumulated onto whatever the scratch held), and the training step is a
+// replayed graph (model.train_graph.StepPlan).
+__global__ void zero_fill_kernel(float4* __restrict__ p, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+static int zero_fill(float* p, size_t bytes, hipStream_t s) {      // bytes % 16 == 0, p 16-byte aligned (workspace sections are 256-byte aligned)
+    const size_t n4 = bytes / 16;
+    if (n4 == 0) return Y2_OK;
+    const unsigned grid = (unsigned)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048);
+    Y2_LAUNCH("zero_fill_kernel", 0.0, zero_fill_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<float4*>(p), n4);
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
 // F(3x3, 4x4): x and dz transformed on 4x4 gradient tiles, 36 grouped reductions, dW = A^T dU A (see wino6_in_kernel)
 static int wino6_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int ldx, int Cout, int ldz, float* workspace, bool native, y2_stream_t stream) {
     if (x == nullptr) return Y2_EINVAL;                  // (a transformed input of the 2x2 form is of no use here)
@@ -1831,8 +1846,7 @@ static int wino6_wgrad(const float* x, const float* dz, float* dw, int B, int H,
     float* DU = DM + align256((size_t)36 * T * Cout * 4) / 4;
     hipStream_t s = y2_s(stream);
     if (y2_internal_wgrad_needs_zero(T, Cin, Cout, 36)) {
-        hipError_t e = hipMemsetAsync(DU, 0, (size_t)36 * Cout * Cin * 4, s);
-        if (e != hipSuccess) return -(1000 + (int)e);
+        if (const int rc = zero_fill(DU, (size_t)36 * Cout * Cin * 4, s)) return rc;
     }
     Wino6Args a;
     a.B = B; a.H = H; a.W = W; a.th = th; a.tw = tw; a.T = (int)T;
@@ -1869,8 +1883,7 @@ extern "C" int y2_wino_wgrad_ex(const float* x, const float* dz, float* dw_packe
     hipStream_t s = y2_s(stream);
     const size_t du_bytes = (size_t)16 * Cout * Cin * 4;
     if (y2_internal_wgrad_needs_zero(T, Cin, Cout, 16)) {      // split partial sums are added atomically; an unsplit launch (the deep layers) stores
-        hipError_t e = hipMemsetAsync(DU, 0, du_bytes, s);
-        if (e != hipSuccess) return -(1000 + (int)e);
+        if (const int rc = zero_fill(DU, du_bytes, s)) return rc;
     }
 
     WinoInArgs ia;

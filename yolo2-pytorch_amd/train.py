@@ -508,7 +508,7 @@ class StepRunner(object):
             if self.pool is None or not any(p.ops is not None for p in self.plans.values()):
                 # (a pool lives as long as a graph captured into it: once the last one is gone its handle is dead - torch asserts on reuse)
                 self.pool = torch.cuda.graph_pool_handle()
-            plan = train_graph.StepPlan(self.inference, self.anchors, self.hparam, self.threshold, dp=self.dp, pool=self.pool)
+            plan = train_graph.StepPlan(self.inference, self.anchors, self.hparam, self.threshold, dp=self.dp, pool=None if os.environ.get('Y2_PLAN_POOL') == 'private' else self.pool)
             plan._alloc(data, npad)
             plan.calls = self.warm.get(shape, 0)      # the per-layer measurements depend on the shape, not on the box count
             self.plans[key] = plan
@@ -529,6 +529,7 @@ class StepRunner(object):
             self.plans.clear()
             torch.cuda.synchronize()
             return None
+        self.last = (npad, 'replay' if had_graph else ('capture' if plan.ops is not None else 'eager'))      # (tools/soak_multiscale.py reads it)
         if not had_graph and plan.ops is not None:
             self.captures += 1
         if self.dp is not None:
