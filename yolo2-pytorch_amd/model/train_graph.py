@@ -1393,6 +1393,8 @@ class StepPlan(object):
         self.pool = pool if pool is not None else torch.cuda.graph_pool_handle()       # all segments (and, shared by the runner, all shapes) allocate from one pool
         self.scope = {}
         self.ops = None             # captured op list
+        self.last_grads = {}
+        self.capture_error = None   # what a failed capture raised (the plan then stays on eager launches)
         self.calls = 0
         self.static = None
         self.result = None
@@ -1552,6 +1554,7 @@ class StepPlan(object):
             g = grads.get(id(p))
             if g is not None:
                 p.grad = g
+        self.last_grads = grads
         if self.buffers:
             _hip.wrote(self.buffers)          # BatchNorm running statistics / step counters were updated by y2_bn_finalize (raw pointers)
 
@@ -1562,8 +1565,13 @@ class StepPlan(object):
         if self.static is None:
             raise RuntimeError('StepPlan.run before StepPlan._alloc')
         self._load(data)
-        if self.ops is None and capture and self.calls > self.WARM:
-            self._capture()
+        if self.ops is None and capture and self.calls > self.WARM and self.capture_error is None:
+            try:
+                self._capture()
+            except Exception as e:          # (the capture executes nothing: this very call goes on eagerly, the runner decides what the error means)
+                self.capture_error = e
+                self.ops = None
+                torch.cuda.synchronize()
         if self.ops is None or not capture:          # (capture=False with a captured plan: this one step launch by launch - per-kernel event tables)
             grads = {}
             result, launched = self._chain(None, grads)

@@ -453,7 +453,8 @@ class StepRunner(object):
         self.plans = collections.OrderedDict()
         self.warm = {}
         self.pool = None
-        self.broken = None
+        self.broken = None          # a capture failed for a reason other than memory: no more captures (steps keep running as eager plans)
+        self.eager_only = set()     # shapes whose capture failed
         self.captures = 0
 
     def same(self, anchors, hparam, threshold):
@@ -466,7 +467,7 @@ class StepRunner(object):
         from model import yolo2 as _yolo2
         inf, x = self.inference, data.get('tensor')
         dnn = getattr(inf, 'dnn', None)
-        if self.broken or not isinstance(x, torch.Tensor) or not x.is_cuda or x.dim() != 4 or x.shape[-1] % 32 or x.shape[-2] % 32:
+        if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dim() != 4 or x.shape[-1] % 32 or x.shape[-2] % 32:
             return False
         if not isinstance(inf, model.Inference) or not isinstance(dnn, (_yolo2.Darknet, _resnet.ResNet)) or not (inf.training and dnn.training):
             return False
@@ -492,48 +493,57 @@ class StepRunner(object):
             return None
         x, cls = data['tensor'], data['cls']
         n = data['yx_min'].shape[1]
-        npad = 8
-        while npad < n:
-            npad *= 2
         shape = (tuple(x.shape), tuple(cls.shape[2:]), cls.dim())
-        key = shape + (npad, _hip.tune_epoch(), _hip.WINOGRAD, _hip.split_mode(), _hip.FORCE_ALGO, train_graph.GRAD_F43, train_graph.FUSE_CONV0, str(x.device))
-        plan = self.plans.get(key)
-        if plan is not None and not plan.valid():
-            self.plans.clear()          # the model (or the wrapper's buckets) moved - .cpu() / .cuda() around an evaluation: every graph holds dead addresses
+        tail = (_hip.tune_epoch(), _hip.WINOGRAD, _hip.split_mode(), _hip.FORCE_ALGO, train_graph.GRAD_F43, train_graph.FUSE_CONV0, str(x.device))
+        # ONE plan per shape: a batch with fewer boxes runs in the plan captured for more (zero rows are the collate function's own padding); a batch
+        # with more boxes than any plan of its shape holds supersedes them (label rows: powers of two from 16)
+        mine = [k for k in self.plans if k[:3] == shape]
+        for k in [k for k in mine if k[4:] != tail or not self.plans[k].valid()]:
+            del self.plans[k]                        # measured on another algorithm table, or the model's memory moved (.cpu() / .cuda() around an evaluation)
             self._params_ok = None
-            plan = None
-        if plan is None:
-            for k in [k for k in self.plans if k[:3] == shape and k[4] != key[4]]:
-                del self.plans[k]                    # measured on another algorithm table
+        mine = [k for k in self.plans if k[:3] == shape]
+        fit = sorted((k for k in mine if k[3] >= n), key=lambda k: k[3])
+        if fit:
+            key = fit[0]
+            plan = self.plans[key]
+            self.plans.move_to_end(key)
+        else:
+            npad = 16
+            while npad < n:
+                npad *= 2
+            for k in mine:
+                del self.plans[k]
+            key = shape + (npad,) + tail
             if self.pool is None or not any(p.ops is not None for p in self.plans.values()):
                 # (a pool lives as long as a graph captured into it: once the last one is gone its handle is dead - torch asserts on reuse)
                 self.pool = torch.cuda.graph_pool_handle()
-            plan = train_graph.StepPlan(self.inference, self.anchors, self.hparam, self.threshold, dp=self.dp, pool=None if os.environ.get('Y2_PLAN_POOL') == 'private' else self.pool)
+            plan = train_graph.StepPlan(self.inference, self.anchors, self.hparam, self.threshold, dp=self.dp, pool=self.pool)
             plan._alloc(data, npad)
             plan.calls = self.warm.get(shape, 0)      # the per-layer measurements depend on the shape, not on the box count
             self.plans[key] = plan
             while len(self.plans) > self.MAX:
                 self.plans.popitem(last=False)
-        else:
-            self.plans.move_to_end(key)
+        npad = key[3]
         self.warm[shape] = self.warm.get(shape, 0) + 1
         had_graph = plan.ops is not None
-        try:
-            out = plan.run(data, capture=GRAPH)
-        except Exception as e:
-            if had_graph or plan.calls <= plan.WARM:
-                raise
-            # the capture failed (never a replay or an eager pass): this model keeps the autograd path
-            logging.warning('training-step capture failed (%s: %s); autograd path from here on' % (type(e).__name__, e))
-            self.broken = '%s: %s' % (type(e).__name__, e)
-            self.plans.clear()
-            torch.cuda.synchronize()
-            return None
+        out = plan.run(data, capture=GRAPH and not self.broken and shape not in self.eager_only)
         self.last = (npad, 'replay' if had_graph else ('capture' if plan.ops is not None else 'eager'))      # (tools/soak_multiscale.py reads it)
+        if plan.capture_error is not None and shape not in self.eager_only:
+            # the capture failed; the step itself ran (eagerly).  Out of memory: every captured step is dropped (their shared pool goes back to
+            # the allocator) and this shape stays on eager launches; anything else: no more captures for this model.
+            e = plan.capture_error
+            logging.warning('training-step capture failed (%s: %s); %s' % (type(e).__name__, str(e)[:200], 'eager launches for this input shape' if isinstance(e, torch.cuda.OutOfMemoryError) else 'eager launches from here on'))
+            self.eager_only.add(shape)
+            if isinstance(e, torch.cuda.OutOfMemoryError):
+                for k in [k for k in self.plans if self.plans[k] is not plan]:
+                    del self.plans[k]
+                torch.cuda.empty_cache()
+            else:
+                self.broken = '%s: %s' % (type(e).__name__, e)
         if not had_graph and plan.ops is not None:
             self.captures += 1
         if self.dp is not None:
-            self.dp.graph_views(plan.params, plan.grads)
+            self.dp.graph_views(plan.params, plan.last_grads)
         return out
 
 
