@@ -64,7 +64,7 @@ def test_dp_wrapper_rccl_world1_equals_plain_backward():
 
 def test_rccl_collectives_between_replayed_graph_segments_world1():
     """train.iterate under the wrapper on RCCL itself (world size 1, the one GPU there is): from the 4th step on the step is a chain of
-    hipGraph segments with eager RCCL all-reduces of the gradient buckets between them, on the same stream.  Seven steps at learning rate 0
+    hipGraph segments with eager RCCL all-reduces of the gradient buckets between them, on the same stream.  Eight steps at learning rate 0
     must reproduce the un-wrapped autograd step (averaging over one rank is the identity) - graph replays, RCCL launches and the
     wrapper's waits in their real interplay."""
     import train
@@ -89,7 +89,7 @@ def test_rccl_collectives_between_replayed_graph_segments_world1():
                 m = train.DataParallelRCCL(inf, bucket_bytes=4096) if wrap else inf
                 opt = utils.optim.SGD(m.parameters(), 0.0, momentum=0.9)
                 rows = []
-                for i in range(7):
+                for i in range(8):
                     r = train.iterate(m, opt, data[i % 3], oloss.HPARAM, 0.6, anchors)
                     rows.append(([float(r['loss'][k].detach()) for k in r['loss']], {k: p.grad.detach().clone() for k, p in inf.dnn.named_parameters()}))
                 torch.cuda.synchronize()

@@ -351,7 +351,7 @@ extern "C" int y2_decode(const float* feature, const float* anchors, int B, int 
 }
 
 namespace {
-// (a kernel, not hipMemsetAsync: memset nodes of a captured hipGraph ran at the first launch only on this runtime, see wino.hip: zero_fill_kernel)
+// (a kernel, not hipMemsetAsync: a memset node of a captured hipGraph is not reliably ordered in front of the kernels behind it on this runtime, see wino.hip: zero_fill_kernel)
 __global__ void zero_i32_kernel(int32_t* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0;

@@ -1460,8 +1460,9 @@ class StepPlan(object):
             if slot is None:
                 raise RuntimeError('StepPlan: a parameter of the plugin is not in the data-parallel wrapper')
             if g.data_ptr() != slot.data_ptr() or not g.is_contiguous():
-                slot.copy_(g.reshape(slot.shape))
-                _hip.LAUNCHES[0] += 1
+                # (a copy KERNEL: torch's contiguous device-to-device copy_ is a memcpy node under capture, and memset nodes already proved to run at a
+                # graph's first launch only on this runtime - nothing of that kind goes into a captured step)
+                _hip.multi([(_hip.MULTI_COPY, slot.view(-1), _hip.f32c(g).view(-1))])
             if id(p) in grads:
                 return
             grads[id(p)] = slot
