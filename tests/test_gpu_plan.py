@@ -214,7 +214,7 @@ def _free_port():
     return port
 
 
-def _dp_rank(rank, world, port, tmp, modes):
+def _dp_rank(rank, world, port, tmp, modes, kind='darknet'):
     import sys
     from conftest import APP, ROOT
     for p in (ROOT, APP):
@@ -230,7 +230,7 @@ def _dp_rank(rank, world, port, tmp, modes):
     import utils
     assert y2train.init_distributed() == world
     y2train.PLAN, y2train.GRAPH = modes[rank]
-    inf, anchors = build('darknet')
+    inf, anchors = build(kind)
     m = y2train.ensure_model(inf)
     assert isinstance(m, y2train.DataParallelRCCL)
     m.bucket_bytes = 4096
@@ -257,6 +257,27 @@ def _dp_rank(rank, world, port, tmp, modes):
                 'ops': ops, 'captures': None if runner is None else runner.captures}, os.path.join(tmp, 'rank%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_dp_world2_resnet_graph_segments_equal_the_hook_path(tmp_path):
+    """The same protocol for the ResNet plugins (BASELINE configs[4] runs them data parallel): their backward finishes weights in another order
+    (`backward_param_order`), writes 1x1 gradients straight into the bucket slices and copies the others there with a kernel."""
+    import torch.multiprocessing as mp
+    world = 2
+    out = {}
+    for name, modes in (('hooks', [(False, False)] * 2), ('graphs', [(True, True)] * 2)):
+        d = tmp_path / name
+        d.mkdir()
+        mp.spawn(_dp_rank, args=(world, _free_port(), str(d), modes, 'resnet18'), nprocs=world, join=True)
+        out[name] = [torch.load(str(d / ('rank%d.pt' % r)), weights_only=False) for r in range(world)]
+    g0 = out['graphs'][0]
+    assert g0['captures'] == 1 and g0['ops'].count('graph') >= 3 and 'buckets' in g0['ops'], g0['ops']
+    for r in range(world):
+        np.testing.assert_allclose(np.array(out['graphs'][r]['losses']), np.array(out['hooks'][r]['losses']), rtol=5e-5)
+    for k, v in out['graphs'][0]['grads'].items():
+        assert torch.equal(v, out['graphs'][1]['grads'][k]), k
+        assert rel(v, out['hooks'][0]['grads'][k]) <= 5e-3, (k, rel(v, out['hooks'][0]['grads'][k]))
 
 
 @pytest.mark.timeout(900)
