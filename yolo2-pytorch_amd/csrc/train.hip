@@ -135,6 +135,7 @@ struct ActBwdArgs {
     float* dres; int lddr;              // optional output: gradient w.r.t. that residual (= gradient of the pre-activation sum)
     double* sums;      // [2C]: sum g, sum g*zhat
     float* partial;    // deterministic mode (pass 1): [threads / Cg][2C] per-thread sums, plain stores (added by det_reduce_rows_kernel)
+    float* block_partial;   // pass 1: [blocks][2C] per-WORKGROUP sums, plain stores (added in a fixed order by bn_bwd_block_reduce_kernel) instead of 2C fp64 atomics per workgroup
     float* dz;         // [B,H,W,C] stride ldd
     int B, H, W, C, ldz, ldf, foff, fmode, ldp, poff, ldd;
     float slope;
@@ -273,10 +274,37 @@ __global__ void bn_act_bwd_kernel(const ActBwdArgs a, long long total) {
 #pragma unroll
         for (int e = 0; e < CV; ++e) { atomicAdd(&red[c + e], s1[e]); atomicAdd(&red[a.C + c + e], s2[e]); }
         __syncthreads();
+        if (a.block_partial != nullptr) {
+            float* row = a.block_partial + (size_t)blockIdx.x * 2 * a.C;
+            for (int i = threadIdx.x; i < 2 * a.C; i += blockDim.x) row[i] = red[i];
+            return;
+        }
         for (int i = threadIdx.x; i < 2 * a.C; i += blockDim.x) {
             const float v = red[i];
             if (v != 0.f) atomicAdd(a.sums + i, (double)v);
         }
+    }
+}
+
+// sums[i] += sum over the workgroups' rows of part[row][i] (fp64).  Pass 1 used to end with 2C fp64 atomics PER WORKGROUP on the same 2C addresses (2048
+// workgroups x 128 addresses for a 64-channel layer): ~30 microseconds of same-address serialisation per launch, which kept pass 1 at 2.2-4.1 TB/s next to
+// pass 2's 5.2-5.5 (profiles/r04_train_b64_traffic_by_kernel.txt).  Block = 64 columns x 16 row lanes over one slice of the rows (gridDim.y slices: a
+// single slice per column block was latency-bound at 30 microseconds, 128 dependent loads per thread); one fp64 atomic per column and slice.
+__global__ __launch_bounds__(1024) void bn_bwd_block_reduce_kernel(const float* __restrict__ part, int rows, int n, double* __restrict__ sums) {
+    __shared__ double acc[16][65];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    const int per = (rows + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    double s = 0.0;
+    if (col < n)
+        for (int r = r0 + lane; r < r1; r += 16) s += (double)part[(size_t)r * n + col];
+    acc[lane][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (lane == 0 && col < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += acc[l][threadIdx.x & 63];
+        atomicAdd(sums + col, t);
     }
 }
 
@@ -681,6 +709,8 @@ extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float*
     const size_t lds = (size_t)2 * C * sizeof(float);
     hipStream_t s = y2_s(stream);
     a.partial = nullptr;
+    // per-workgroup partial sums parked in the (not yet written) dz buffer when it is dense and large enough; else the atomics
+    a.block_partial = (dz != nullptr && !y2_det.on && ldd == C && grid > 16 && (long long)grid * 2 * C <= (long long)B * H * W * ldd) ? dz : nullptr;
     const long long prow = (long long)grid * 256 / Cg;            // rows of per-thread partials (grid * 256 is a multiple of Cg)
     if (y2_det.on) {
         if ((size_t)prow * 2 * C * sizeof(float) > y2_det.bytes || prow > 0x7fffffffLL) return Y2_EINVAL;
@@ -693,6 +723,8 @@ extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float*
             const int rc_ = y2_det_reduce_f32(a.partial, (int)prow, (long long)2 * C, (long long)2 * C, sums, nullptr, s);            \
             if (rc_ != Y2_OK) return rc_;                                                                            \
         }                                                                                                            \
+        if (a.block_partial != nullptr)                                                                              \
+            Y2_LAUNCH("bn_bwd_block_reduce_kernel", 0.0, bn_bwd_block_reduce_kernel, dim3((unsigned)y2_cdiv(2 * C, 64), (unsigned)(grid >= 512 ? 16 : (grid >= 64 ? 4 : 1))), dim3(1024), 0, s, a.block_partial, grid, 2 * C, sums);            \
         if (dz != nullptr) Y2_LAUNCH("bn_act_bwd_kernel", 0.0, (bn_act_bwd_kernel<POOL, CV, true>), dim3(grid), dim3(256), 0, s, a, total);               \
     } while (0)
     if (pool) { if (vec) Y2_BWD(true, 4); else Y2_BWD(true, 1); }
