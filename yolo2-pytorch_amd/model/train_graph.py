@@ -1592,24 +1592,35 @@ class StepPlan(object):
 
     def _capture(self):
         """Record the launch sequence into hipGraph segments (nothing executes; the caller replays them right away)."""
+        import gc
         cur = torch.cuda.current_stream()
         side = _capture_stream(self.static['x'].device)
+        # Nothing may be destroyed while a capture is underway: a collected reference cycle that holds an older plan's CUDAGraph (or tensors of its
+        # pool) releases graph memory from inside the capture and the runtime aborts the process.  Collect now, and keep the cyclic collector off
+        # until the capture has ended (torch.cuda.graph() collects too, but leaves the collector on).
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         torch.cuda.synchronize()
         side.wait_stream(cur)
         seg = _Segments(self.pool, 'capture')
         grads = {}
         prev_scope = _hip.SCOPE
-        with torch.cuda.stream(side):
-            _hip.SCOPE = self.scope
-            try:
-                seg.begin()
-                self.result, _ = self._chain(seg, grads)
-                seg.end()
-            except BaseException:
-                seg.abort()
-                raise
-            finally:
-                _hip.SCOPE = prev_scope
+        try:
+            with torch.cuda.stream(side):
+                _hip.SCOPE = self.scope
+                try:
+                    seg.begin()
+                    self.result, _ = self._chain(seg, grads)
+                    seg.end()
+                except BaseException:
+                    seg.abort()
+                    raise
+                finally:
+                    _hip.SCOPE = prev_scope
+        finally:
+            if gc_was_on:
+                gc.enable()
         cur.wait_stream(side)
         self.ops, self.grads = seg.ops, grads
         self._baked = self._addresses()
