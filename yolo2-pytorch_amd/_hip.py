@@ -415,7 +415,10 @@ def save_tune_defaults(path=None, note=''):
     path = path or DEFAULTS_PATH
     os.makedirs(os.path.dirname(path), exist_ok=True)
     entries = [[list(k), v] for k, v in export_tune()]
-    _json.dump({'kernels': kernel_hash(), 'note': note, 'entries': entries}, open(path, 'w'), indent=0)
+    with open(path, 'w') as f:          # one entry per line: diffs of a regenerated table stay readable
+        f.write('{"kernels": %s, "note": %s, "entries": [\n' % (_json.dumps(kernel_hash()), _json.dumps(note)))
+        f.write(',\n'.join(_json.dumps(e) for e in entries))
+        f.write('\n]}\n')
     return len(entries)
 
 
