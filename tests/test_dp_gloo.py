@@ -134,6 +134,38 @@ def worker(rank, world, port, tmp):
     (((r1 - y) ** 2).mean() + (r1 ** 2).mean()).backward()
     for (n, a), b in zip(m.named_parameters(), ref.parameters()):
         assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6), ('two backwards', n)
+    # a step issued as captured graph segments (model.train_graph.StepPlan) drives the wrapper through graph_begin / graph_slot / graph_launch /
+    # graph_finish instead of the autograd hooks: same collectives, same order, same payloads - rank 0 on that protocol and rank 1 on the hooks
+    # must meet (a rank replaying graphs and a rank still warming up on another input size do exactly this)
+    for step in range(2):
+        for p in dp.parameters():
+            p.grad = None
+        if rank == 0:
+            hooks = (m[2].grad_ready_hook, m[2].grad_buffer_hook)
+            m[2].grad_ready_hook = m[2].grad_buffer_hook = None          # (a StepPlan takes the module's hook slots over for its own pass, too)
+            local = torch.autograd.grad(((m(x[shard]) - y[shard]) ** 2).mean(), list(m.parameters()))
+            m[2].grad_ready_hook, m[2].grad_buffer_hook = hooks
+            dp.graph_begin()
+            nb = len(dp._buckets)
+            done = 0
+            for bi, bucket in enumerate(dp._buckets):           # gradients land in their slices; buckets go out as they complete
+                for p in bucket:
+                    g = local[[id(q) for q in m.parameters()].index(id(p))]
+                    dp.graph_slot(p).copy_(g)
+                if bi < nb - 1:
+                    dp.graph_launch(bi, bi + 1)
+                    done = bi + 1
+            dp.graph_launch(done, nb)
+            dp.graph_finish()
+            for p in m.parameters():
+                p.grad = dp.graph_slot(p)
+        else:
+            ((dp(x[shard]) - y[shard]) ** 2).mean().backward()
+        for p in ref.parameters():
+            p.grad = None
+        ((ref(x) - y) ** 2).mean().backward()
+        for (n, a), b in zip(m.named_parameters(), ref.parameters()):
+            assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6), ('graph protocol vs hooks', n, step, rank)
     # the reducer of the region loss travels with the wrapper's outputs
     from model import train_graph
     out = dp(x[shard])

@@ -93,3 +93,74 @@ def test_default_tune_table_is_adopted_only_for_the_kernels_it_was_measured_on(m
     if os.path.exists(_hip.DEFAULTS_PATH):
         d = json.load(open(_hip.DEFAULTS_PATH))
         assert len(d['kernels']) == 16 and all(len(e) == 2 for e in d['entries'])
+
+
+def test_step_runner_keeps_one_plan_per_shape_and_degrades_per_shape(monkeypatch):
+    """train.StepRunner's bookkeeping without a GPU (the plans are stand-ins): a batch with fewer boxes runs in the plan captured for more, a batch with
+    more supersedes it, warm-up is counted per input shape, a capture that runs out of memory drops the OTHER captured steps and leaves that shape on
+    eager launches, any other capture failure stops capturing - and no failure ever stops the step from running."""
+    import torch
+
+    import train
+    from model import train_graph
+
+    made = []
+
+    class FakePlan(object):
+        WARM = 3
+
+        def __init__(self, inference, anchors, hparam, threshold, dp=None, pool=None):
+            self.ops, self.capture_error, self.calls, self.static, self.params, self.last_grads = None, None, 0, None, [], {}
+            self.fail = None
+            made.append(self)
+
+        def _alloc(self, data, npad):
+            self.static = {'npad': npad}
+
+        def valid(self):
+            return True
+
+        def run(self, data, capture=True):
+            self.calls += 1
+            if self.ops is None and capture and self.calls > self.WARM and self.capture_error is None:
+                if self.fail is not None:
+                    self.capture_error = self.fail
+                else:
+                    self.ops = [('graph', None)]
+            return {'ran': self.calls}
+    monkeypatch.setattr(train_graph, 'StepPlan', FakePlan)
+    monkeypatch.setattr(torch.cuda, 'graph_pool_handle', lambda: object())
+    monkeypatch.setattr(torch.cuda, 'empty_cache', lambda: None)
+    monkeypatch.setattr(train.StepRunner, 'eligible', lambda self, data: True)
+    r = train.StepRunner(object(), None, object(), {'foreground': 5.0}, 0.6)
+
+    def batch(S, n):
+        return {'tensor': torch.zeros(2, 3, S, S), 'yx_min': torch.zeros(2, n, 2), 'yx_max': torch.zeros(2, n, 2), 'cls': torch.zeros(2, n, dtype=torch.int64)}
+    for _ in range(5):
+        assert r.step(batch(96, 6))['ran']
+    assert len(r.plans) == 1 and r.captures == 1 and made[-1].static['npad'] == 16
+    assert r.step(batch(96, 3)) and len(r.plans) == 1 and len(made) == 1                 # fewer boxes: the same plan
+    assert r.step(batch(96, 40)) and len(r.plans) == 1 and len(made) == 2               # more boxes: a 64-row plan supersedes it ...
+    assert made[-1].static['npad'] == 64 and r.captures == 2                             # ... captured at its first call (the shape is warm)
+    assert r.step(batch(96, 6)) and len(made) == 2                                       # and serves the small batches from now on
+    for _ in range(4):
+        r.step(batch(128, 6))
+    assert len(r.plans) == 2 and r.captures == 3
+    # out of memory while capturing a third shape: the step runs, the other captured steps are dropped, the shape stays eager
+    for i in range(3):
+        r.step(batch(160, 6))
+    made[-1].fail = torch.cuda.OutOfMemoryError('HIP out of memory')
+    assert r.step(batch(160, 6))['ran'] == 4
+    assert len(r.plans) == 1 and not r.broken and len(r.eager_only) == 1
+    assert r.step(batch(160, 6))['ran'] == 5 and made[-1].ops is None                   # no second attempt for that shape
+    for _ in range(4):
+        r.step(batch(96, 6))                                                             # the others capture again, in a fresh pool
+    assert r.captures == 4
+    # any other failure: no more captures for this model, steps keep running
+    for i in range(3):
+        r.step(batch(192, 6))
+    made[-1].fail = RuntimeError('boom')
+    assert r.step(batch(192, 6))['ran'] == 4 and r.broken
+    for _ in range(5):
+        assert r.step(batch(224, 6))
+    assert made[-1].ops is None and r.captures == 4
