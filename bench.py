@@ -23,7 +23,13 @@ Roofline (N = 1, measured in this run with the library's per-kernel HIP-event ho
                    with >= 1 % of the step; `conv_chain` gives the whole 23-conv chain (executed and direct-equivalent rates).
   conv3x3_b64      north_star's target quantity: the 3x3 convolutions at batch 64, per-layer event pairs, Winograd on and off.
   train.roofline   the same per-kernel table for the training step (executed FLOPs of fprop / dgrad / wgrad kernels).
-  cpu_baseline     the CPU oracle (port of the reference path) on this box's host cores, bounded sample, rank 0 at N = 1 only.
+  cpu_baseline     the CPU oracle (port of the reference path) on this box's host cores, bounded sample, rank 0 at N = 1 only: batch-16 chunks, the
+                   reference's own one-image-per-call shape (BASELINE configs[0]), one batch-8 training step, NMS at 200 candidates.
+  latency          (round 4) configs[0] on the GPU: batch 1 / batch 8, one hipGraph, serial replays, with plan, launch count and both floors.
+  resnet50_608     (round 4) BASELINE configs[4] per GPU: ResNet-50 plugin, 608x608, COCO-80, batch 32: detect, train, per-kernel table.
+  multiscale       BASELINE configs[3] per GPU: COCO-80, sizes 320..608, resize every 10 batches.
+  The training legs go through train.iterate: a captured hipGraph per input shape (model.train_graph.StepPlan); `host_issue_ms_per_step` is the host
+  time to issue one step with the GPU idle.
 """
 import argparse
 import json
@@ -845,7 +851,12 @@ def cpu_baseline(sd, anchors, size, sample):
     for _ in range(20):
         onms.nms(sc, mn, mx, 0.45, 200)
     nms_ms = (time.perf_counter() - t0) / 20 * 1e3
-    return {'value': round(sample / dt, 3), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+    cpu_model = None
+    try:
+        cpu_model = next(l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name'))
+    except Exception:
+        pass
+    return {'value': round(sample / dt, 3), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port', 'cpu_model': cpu_model, 'cpu_count': cores,
             'sample': '%d synthetic %dx%d images in batches of 16, oracle conv stack (torch-CPU fp32, best of %d/%d/%d/%d threads) + decode + filter(fix=1) + NMS, %.1f s'
                       % (sample, size, size, cores, cores // 2, cores // 4, cores // 8, dt),
             'b1_ms_per_image': round(b1_ms, 2), 'b1_images_per_sec': round(1e3 / b1_ms, 2), 'b1_sample': '%d calls of ONE %dx%d image: conv stack + decode + filter + NMS (BASELINE configs[0], detect.py:141-153)' % (n1, size, size),
