@@ -440,8 +440,8 @@ GRAPH = os.environ.get('Y2_TRAIN_GRAPH', '1') != '0'       # 0: every training s
 
 
 class StepRunner(object):
-    """The StepPlans (model.train_graph) of one model: one per problem shape - per-GPU batch, input size (multi-scale training cycles
-    through ten, utils/data.py:135-141), padded box count, label form - all allocating from one graph memory pool, least recently used
+    """The StepPlans (model.train_graph) of one model: one per input shape - per-GPU batch, input size (multi-scale training cycles
+    through ten, utils/data.py:135-141), label form; its label buffers hold the largest box count met so far - all allocating from one graph memory pool, least recently used
     dropped beyond `MAX`.  step(data) returns what iterate returns, or None when this step cannot run as a plan (the caller then takes
     the autograd path)."""
     MAX = int(os.environ.get('Y2_TRAIN_PLANS', '24'))
