@@ -17,6 +17,7 @@ import train as y2train  # noqa: E402
 import utils  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+y2train.GRAPH = False          # the event hooks bracket launches: the step's launch sequence issued eagerly (what the captured graph replays)
 dev = torch.device('cuda:0')
 inf, anchors = bench_data.build_model(20, dev, 'darknet')
 inf.train()
