@@ -96,6 +96,21 @@ def test_full_batch_matches_fp64_oracle_on_sampled_images(net, batch, truth):
         assert rel(got[j:j + 1], truth[j:j + 1]) <= 2e-5, (i, rel(got[j:j + 1], truth[j:j + 1]))
 
 
+def test_single_image_matches_fp64_oracle(net, batch, truth):
+    """BASELINE configs[0], the reference's own usage: ONE image per call (`detect.py:141-153`).  At batch 1 the per-layer selection lands on other
+    algorithms / tiles than at batch 32 (split-K over the idle CUs, the three-kernel Winograd form on the 52x52 layers, `bench.py` latency leg): the
+    same images, one at a time, against the same fp64 truth and the same 2e-5 x rms - in each precision mode of the module's fixture."""
+    inf, anchors, sd = net
+    x, feat = batch
+    for j, i in enumerate(SAMPLED[:3]):
+        with torch.no_grad():
+            one = inf.dnn.forward_nhwc(x[i:i + 1].to(dev())).permute(0, 3, 1, 2)
+        e = rel(one, truth[j:j + 1])
+        assert e <= 2e-5, (i, e)
+        # and the batch-32 run of the same image agrees with it to the same bound (another plan, another summation order)
+        assert rel(one, feat[i:i + 1].permute(0, 3, 1, 2).cpu()) <= 2e-5, i
+
+
 @pytest.mark.parametrize('algo', ['direct', 'winograd', 'fused', 'implicit', 'fused3', 'implicit3', 'split', 'split16'])
 def test_full_batch_under_each_forced_algorithm(net, batch, truth, algo, monkeypatch):
     """Deterministic algorithm coverage of the whole-model path: with autotune out of the picture every eligible 3x3 layer runs the
