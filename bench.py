@@ -87,6 +87,7 @@ def parse_args():
     ap.add_argument('--no-latency', action='store_true', help='skip the batch-1 / batch-8 detect latency leg (BASELINE configs[0] twin on the GPU)')
     ap.add_argument('--no-resnet', action='store_true', help='skip the ResNet-50 608x608 COCO-80 leg (BASELINE configs[4] per GPU)')
     ap.add_argument('--resnet-batch', type=int, default=32, help='per-GPU batch of the ResNet-50 leg')
+    ap.add_argument('--tables', default='', help='where the long form of the result (per-kernel tables, plans) is written (default gpurun_out/bench_full.json)')
     ap.add_argument('--dry-run', action='store_true', help='no GPU: exercise launch / rendezvous / DP wrapper / timing protocol with a stand-in CPU workload (gloo); the numbers mean nothing')
     return ap.parse_args()
 
@@ -314,6 +315,23 @@ def detect_leg(args, ctx):
         table = kernel_table(eager, min(steps, 8)) if want_table else None
         runs = None
         nstreams = max(1, min(args.streams if want_streams is None else want_streams, len(xs))) if (not args.no_graph and args.model == 'darknet') else 1
+        measure.table2 = None
+        if want_table and nstreams > 1:
+            # the same launches issued the way the TIMED region runs them: consecutive batches alternate between two streams (private buffer
+            # slots), so a kernel's launch duration contains what the co-running kernels of the other batch cost it - the figure a rocprofv3
+            # trace of this command shows; the single-stream table above is the uncontended one
+            ss = [torch.cuda.Stream() for _ in range(nstreams)]
+
+            def eager2(i):
+                with torch.cuda.stream(ss[i % nstreams]), torch.no_grad():
+                    return detect.detect_batch(dnn.forward_nhwc(xs[i % len(xs)], i % nstreams), anchors, **kw)
+            try:
+                for i in range(2 * nstreams):
+                    eager2(i)
+                ctx.sync()
+                measure.table2 = kernel_table(eager2, max(nstreams * 4, min(steps, 16)))
+            except Exception as e:
+                print('two-stream kernel table failed (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
         if not args.no_graph:
             try:      # one captured graph per resident batch; graph i runs in buffer slot i % nstreams on stream i % nstreams: graphs of one
                       # slot share intermediate buffers and are serial on their stream, different slots overlap
@@ -340,6 +358,7 @@ def detect_leg(args, ctx):
 
     dt, host, table, graphed = measure(args.steps, args.warmup, ctx.world == 1)
     pipelined = getattr(measure, 'nstreams', 1)
+    table2 = getattr(measure, 'table2', None)
     serial_dt = None
     if pipelined > 1 and ctx.world == 1:          # the same graphs strictly one after the other: the latency of a step, reported beside the throughput
         serial_steps = min(args.steps, 24)
@@ -356,7 +375,15 @@ def detect_leg(args, ctx):
         out['autotune_choices_synced'] = getattr(measure, 'tune_synced', None)
     roof = None
     if table is not None:
-        roof = roofline_from(table, 'detect step, batch %d (eager launches of the same kernels the timed hipGraph replays)' % args.batch)
+        roof = roofline_from(table, 'detect step, batch %d (eager single-stream launches of the same kernels the timed hipGraph replays)' % args.batch)
+        if table2 is not None:
+            # headline `frac`: the dominant kernel's duration UNDER THE TIMED SCHEDULE (two pipelined streams); the uncontended figure beside it
+            r2 = roofline_from(table2, 'detect step, batch %d: launch durations under the timed two-stream schedule (eager launches alternating between the streams)' % args.batch)
+            k2 = next((r for r in r2['top_kernels'] if r['kernel'] == roof['kernel']), None)
+            if k2 is not None and k2['frac'] is not None:
+                roof.update(frac_uncontended=roof['frac'], achieved_uncontended=roof['achieved'], avg_launch_us_uncontended=roof['avg_launch_us'],
+                            frac=k2['frac'], achieved=k2['executed_tflops'], avg_launch_us=k2['avg_launch_us'], what=r2['what'])
+            roof['two_stream_top_kernels'] = r2['top_kernels']
         plan = dnn._plan_cache[1] if dnn._plan_cache else None
         if plan is not None and 'flops_executed' in plan:
             conv_ms = sum(e['ms'] for k, e in table.items() if k.startswith(('conv', 'wino')))
@@ -366,6 +393,8 @@ def detect_leg(args, ctx):
                                   'direct_equiv_tflops': round(alg / conv_ms / 1e9, 2),
                                   'direct_equiv_note': 'ALGORITHMIC conv FLOPs (SURVEY.md 8d, 2*Cin*Cout*k*k*H*W) / kernel time: what a direct convolution would have to sustain; not a roofline fraction',
                                   'winograd_layers': int(sum(plan['algos'])), 'flops_per_step': alg, 'executed_flops_per_step': exe}
+            # the whole TIMED step (conv chain + decode + filter + NMS, pipelined) against the fp32-MFMA peak, in executed multiply-adds
+            roof['timed_step_executed_frac'] = round(exe / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
         tr, src = static_traffic('detect_b32') if (args.batch == 32 and args.size == 416 and args.model == 'darknet') else (None, None)
         roof['traffic'], roof['traffic_source'] = tr, src
         if _hip.WINOGRAD and args.model == 'darknet' and not args.no_direct_leg:
@@ -642,7 +671,7 @@ def multiscale_leg(args, ctx):
            'images_per_sec': round(images / dt, 2), 'steps': len(schedule), 'ms_per_step_mean': round(dt / len(schedule) * 1e3, 3), 'host_ms_per_step_mean': round(host / len(schedule) * 1e3, 3),
            'host_issue_ms_per_step': {str(S): v for S, v in issue.items()},
            'switch_cost_ms_mean': round(sum(switch) / len(switch), 3), 'switch_cost_ms_max': round(max(switch), 3),
-           'first_visit_ms_mean': round(sum(first_visit.values()) / len(first_visit) * 1e3, 1), 'first_visit_ms_total': round(sum(first_visit.values()) * 1e3, 1),
+           'first_visit_ms_mean': round(sum(first_visit.values()) / len(first_visit) * 1e3, 1), 'first_visit_ms_max': round(max(first_visit.values()) * 1e3, 1), 'first_visit_ms_total': round(sum(first_visit.values()) * 1e3, 1),
            'per_gpu_batch': B, 'global_batch': B * ctx.world, 'loss_total': float(last['r']['loss_total'].detach()),
            'parallelism': 'dp%d' % ctx.world if ctx.world > 1 else 'single GPU', 'per_size': table}
     if per_img is not None:
@@ -702,11 +731,15 @@ def latency_leg(args, ctx):
         mfma_floor = flops / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
         hbm_floor = hbm / (PEAK_HBM_TBS * 1e12) * 1e3
         kms = sum(e['ms'] for e in table.values())
+        executed = float(plan['flops_executed'] + plan['flops0']) if 'flops_executed' in plan else flops      # Winograd layers execute 16/36 of their direct count
         out['b%d' % B] = {'batch': B, 'ms_per_step': round(ms, 4), 'ms_per_image': round(ms / B, 4), 'images_per_sec': round(B / ms * 1e3, 1), 'host_ms_per_step': round(host / steps * 1e3, 4),
                           'launches_per_step': round(sum(e['launches'] for e in table.values()), 1), 'kernel_ms_sum_eager': round(kms, 4),
                           'algorithmic_gflop': round(flops / 1e9, 2), 'min_hbm_mbytes': round(hbm / 1e6, 1),
                           'mfma_floor_ms': round(mfma_floor, 4), 'hbm_floor_ms': round(hbm_floor, 4), 'bound': 'mfma' if mfma_floor >= hbm_floor else 'hbm',
-                          'frac_of_bound': round(max(mfma_floor, hbm_floor) / ms, 4), 'achieved_tflops_direct_equiv': round(flops / ms / 1e9, 2), 'achieved_hbm_tbs_min_bytes': round(hbm / ms / 1e9, 3),
+                          'direct_equiv_frac': round(mfma_floor / ms, 4), 'direct_equiv_note': 'ALGORITHMIC conv FLOPs / fp32-MFMA peak / time: not a roofline fraction when layers run Winograd',
+                          'executed_gflop': round(executed / 1e9, 2), 'executed_mfma_frac': round(executed / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                          'achieved_tflops_direct_equiv': round(flops / ms / 1e9, 2), 'achieved_hbm_tbs_min_bytes': round(hbm / ms / 1e9, 3),
+                          'weight_bytes_tbs': round(WEIGHT_BYTES / ms / 1e9, 3),
                           'winograd_layers': int(sum(1 for l in layers if l['algo'] != 'direct')), 'plan': layers,
                           'top_kernels': top_kernels(table, 0.03)[0]}
         del g
@@ -896,6 +929,62 @@ def dry_run(args, ctx):
            {'images_per_sec': round(args.train_batch * args.steps * ctx.world / dt_d, 2), 'ms_per_step': round(dt_d / args.steps * 1e3, 4)}
 
 
+
+LINE_LIMIT = 6000        # bytes of the final stdout line: the driver parses the LAST line of stdout and keeps a bounded tail of it (round 4's 30 KB line was not parsed)
+ROOF_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'avg_launch_us', 'kernel_share_of_step', 'frac_uncontended', 'avg_launch_us_uncontended',
+             'timed_step_executed_frac', 'kernel_ms_per_step', 'what', 'traffic_source')
+# scalars that go first when the line would exceed LINE_LIMIT (least important first)
+DROP_ORDER = ('split_bf16x6_detect_images_per_sec', 'split_f16x3_detect_images_per_sec', 'latency_b8_launches', 'latency_b1_launches', 'resnet50_608_train_kernel_ms_sum',
+              'resnet50_608_train_mfma_ms_per_step', 'train_mfma_ms_per_step', 'train_kernel_ms_sum_single_stream', 'train_dominant_avg_launch_us', 'multiscale_switch_cost_ms_max',
+              'latency_b8_direct_equiv_frac', 'latency_b1_direct_equiv_frac', 'detect_streams', 'resnet50_608_detect_images_per_sec', 'multiscale_ms_per_step_mean')
+
+
+def scalar_name(kernel):
+    return kernel.replace('[', '_').replace(']', '').replace('<', '_').replace('>', '').replace(',', '_').replace(' ', '')
+
+
+def write_tables(full, path):
+    """The long form of the result (per-kernel tables, plans, per-size tables): a JSON file next to the run, never the stdout line."""
+    path = path or os.path.join(ROOT, 'gpurun_out', 'bench_full.json')
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, 'w') as f:
+            json.dump(full, f)
+        return os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT) else path
+    except Exception as e:
+        print('bench.py: tables not written (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
+        return None
+
+
+def compact_line(head, roof, extra, cb, tables_at=None, limit=LINE_LIMIT):
+    """The ONE stdout line: top-level contract keys + config + roofline (scalars only, each once) + cpu_baseline, at most `limit` bytes."""
+    out = dict(head)
+    if roof is not None:
+        r = {k: roof[k] for k in ROOF_KEYS if k in roof and not isinstance(roof[k], (dict, list))}
+        for k in ('what', 'traffic_source'):
+            if isinstance(r.get(k), str) and len(r[k]) > 160:
+                r[k] = r[k][:157] + '...'
+        r.update({k: v for k, v in extra.items() if not isinstance(v, (dict, list))})
+        out['roofline'] = r
+    if cb is not None:
+        keep = ('value', 'unit', 'cores', 'kind', 'sample', 'cpu_model', 'cpu_count', 'b1_ms_per_image', 'train_b8_images_per_sec', 'nms_n200_ms', 'error')
+        c = {k: cb[k] for k in keep if k in cb}
+        if isinstance(c.get('sample'), str) and len(c['sample']) > 200:
+            c['sample'] = c['sample'][:197] + '...'
+        out['cpu_baseline'] = c
+    if tables_at:
+        out['tables'] = tables_at
+    line = json.dumps(out, separators=(',', ':'))
+    drop = list(DROP_ORDER)
+    while len(line) > limit and 'roofline' in out:
+        k = drop.pop(0) if drop else next((k for k in reversed(list(out['roofline'])) if k not in ROOF_KEYS[:6]), None)
+        if k is None:
+            break
+        out['roofline'].pop(k, None)
+        line = json.dumps(out, separators=(',', ':'))
+    return line
+
+
 def main():
     args = parse_args()
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -995,44 +1084,8 @@ def main():
             value, msps, steps, workload = det['images_per_sec'], det['ms_per_step'], det['steps'], det_workload
             metric = 'images/sec (%dx%d) train+detect, %s YOLOv2: value = DETECT (configs[1]); train (configs[2]) = roofline.train_images_per_sec' % (args.size, args.size, label)
         ok = lambda d: d is not None and 'error' not in d
-        # ---- scalars the driver's record keeps (it preserves the scalar members of `roofline`, `config`, `cpu_baseline`)
+        # ---- scalars of the ONE line the driver parses (it keeps `roofline`, `config`, `cpu_baseline`): every leg's headline numbers, once
         extra = {}
-        if ok(tr):
-            extra.update(train_images_per_sec=tr['images_per_sec'], train_ms_per_step=tr['ms_per_step'], train_host_ms_per_step=tr['host_ms_per_step'],
-                         train_host_issue_ms_per_step=tr.get('host_issue_ms_per_step'))
-            if 'dp_exposed_comm_ms_per_step' in tr:
-                extra['train_dp_exposed_comm_ms_per_step'] = tr['dp_exposed_comm_ms_per_step']
-            r = tr.get('roofline')
-            if r:
-                extra.update(train_traffic_bytes_per_step=r.get('traffic'), train_mfma_frac=r['all_mfma_kernels']['frac'], train_mfma_ms_per_step=r['all_mfma_kernels']['ms_per_step'],
-                             train_kernel_ms_sum_single_stream=r.get('kernel_ms_sum_single_stream'), train_dominant_kernel=r['kernel'], train_dominant_frac=r['frac'],
-                             train_dominant_avg_launch_us=r['avg_launch_us'])
-        if ok(conv3):
-            extra['conv3x3_b64_mfma_util'] = conv3['autotuned']['mfma_utilisation']
-            extra['conv3x3_b64_ms'] = conv3['autotuned']['ms']
-            if 'direct_only' in conv3:
-                extra['conv3x3_b64_direct_only_util'] = conv3['direct_only']['mfma_utilisation']
-        if ok(lat):
-            for B in (1, 8):
-                e = lat['b%d' % B]
-                extra.update({'latency_b%d_ms' % B: e['ms_per_step'], 'latency_b%d_launches' % B: e['launches_per_step'], 'latency_b%d_frac_of_%s_floor' % (B, e['bound']): e['frac_of_bound'],
-                              'latency_b%d_winograd_layers' % B: e['winograd_layers']})
-        if ok(rn):
-            extra.update(resnet50_608_detect_images_per_sec=rn['detect']['images_per_sec'], resnet50_608_detect_direct_equiv_frac=rn['detect']['direct_equiv_frac'],
-                         resnet50_608_train_images_per_sec=rn['train']['images_per_sec'], resnet50_608_train_ms_per_step=rn['train']['ms_per_step'],
-                         resnet50_608_train_direct_equiv_frac=rn['train']['direct_equiv_frac'], resnet50_608_train_host_ms_per_step=rn['train']['host_ms_per_step'])
-            r = rn['train'].get('roofline')
-            if r:
-                extra.update(resnet50_608_train_mfma_frac=r['all_mfma_kernels']['frac'], resnet50_608_train_mfma_ms_per_step=r['all_mfma_kernels']['ms_per_step'],
-                             resnet50_608_train_kernel_ms_sum=r['kernel_ms_per_step'])
-                for row in r.get('top_kernels', [])[:8]:
-                    if row['frac'] is not None:
-                        extra['resnet50_frac_' + row['kernel'].replace('[', '_').replace(']', '').replace('<', '_').replace('>', '').replace(',', '_').replace(' ', '')] = row['frac']
-        if ok(ms):
-            for S, v in ms.get('host_issue_ms_per_step', {}).items():
-                extra['multiscale_host_issue_ms_s%s' % S] = v
-            extra.update(multiscale_images_per_sec=ms['images_per_sec'], multiscale_ms_per_step_mean=ms['ms_per_step_mean'], multiscale_switch_cost_ms_mean=ms['switch_cost_ms_mean'],
-                         multiscale_switch_cost_ms_max=ms['switch_cost_ms_max'], multiscale_first_visit_ms_mean=ms['first_visit_ms_mean'])
         if ok(det):
             extra.update(detect_images_per_sec=det['images_per_sec'], detect_ms_per_step=det['ms_per_step'], detect_streams=det.get('streams'),
                          detect_serial_images_per_sec=det.get('serial_images_per_sec'), detect_serial_ms_per_step=det.get('serial_ms_per_step'))
@@ -1041,55 +1094,67 @@ def main():
                 extra.update(conv_chain_ms_per_step=roof['conv_chain']['ms_per_step'], conv_chain_frac=roof['conv_chain']['frac'])
             if isinstance(roof.get('direct_only'), dict) and 'frac' in roof['direct_only']:
                 extra['detect_direct_only_frac'] = roof['direct_only']['all_mfma_kernels']['frac']
+            for r in roof.get('top_kernels', []):
+                if r['frac'] is not None:       # one scalar per MFMA kernel of the detect step (uncontended single-stream launches): frac_<kernel>
+                    extra['frac_' + scalar_name(r['kernel'])] = r['frac']
+        if ok(tr):
+            extra.update(train_images_per_sec=tr['images_per_sec'], train_ms_per_step=tr['ms_per_step'], train_host_issue_ms_per_step=tr.get('host_issue_ms_per_step'))
+            for k in ('dp_exposed_comm_ms_per_step', 'ms_per_step_contended', 'single_gpu_images_per_sec'):
+                if k in tr:
+                    extra['train_' + k] = tr[k]
+            r = tr.get('roofline')
+            if r:
+                extra.update(train_traffic_bytes_per_step=r.get('traffic'), train_mfma_frac=r['all_mfma_kernels']['frac'], train_mfma_ms_per_step=r['all_mfma_kernels']['ms_per_step'],
+                             train_kernel_ms_sum_single_stream=r.get('kernel_ms_sum_single_stream'), train_dominant_kernel=r['kernel'], train_dominant_frac=r['frac'],
+                             train_dominant_avg_launch_us=r['avg_launch_us'])
+        if ok(conv3):
+            extra['conv3x3_b64_mfma_util'] = conv3['autotuned']['mfma_utilisation']
+            if 'direct_only' in conv3:
+                extra['conv3x3_b64_direct_only_util'] = conv3['direct_only']['mfma_utilisation']
+        if ok(lat):
+            for B in (1, 8):
+                e = lat['b%d' % B]
+                extra.update({'latency_b%d_ms' % B: e['ms_per_step'], 'latency_b%d_launches' % B: e['launches_per_step'],
+                              'latency_b%d_executed_mfma_frac' % B: e['executed_mfma_frac'], 'latency_b%d_direct_equiv_frac' % B: e['direct_equiv_frac']})
+            extra['latency_b1_weight_tbs'] = lat['b1']['weight_bytes_tbs']
+        if ok(rn):
+            extra.update(resnet50_608_detect_images_per_sec=rn['detect']['images_per_sec'], resnet50_608_train_images_per_sec=rn['train']['images_per_sec'],
+                         resnet50_608_train_ms_per_step=rn['train']['ms_per_step'], resnet50_608_train_direct_equiv_frac=rn['train']['direct_equiv_frac'])
+            r = rn['train'].get('roofline')
+            if r:
+                extra.update(resnet50_608_train_mfma_frac=r['all_mfma_kernels']['frac'], resnet50_608_train_mfma_ms_per_step=r['all_mfma_kernels']['ms_per_step'],
+                             resnet50_608_train_kernel_ms_sum=r['kernel_ms_per_step'])
+        if ok(ms):
+            extra.update(multiscale_images_per_sec=ms['images_per_sec'], multiscale_ms_per_step_mean=ms['ms_per_step_mean'], multiscale_switch_cost_ms_max=ms['switch_cost_ms_max'],
+                         multiscale_first_visit_ms_mean=ms['first_visit_ms_mean'], multiscale_first_visit_ms_max=ms.get('first_visit_ms_max'))
+        if roof is not None:
             for tag in ('split_bf16x6', 'split_f16x3'):
                 sp = roof.get(tag)
                 if isinstance(sp, dict) and 'images_per_sec' in sp:
-                    extra.update({tag + '_detect_images_per_sec': sp['images_per_sec'], tag + '_detect_ms_per_step': sp['ms_per_step'],
-                                  tag + '_feature_diff_over_rms': sp['feature_max_abs_diff_over_rms_vs_fp32_mfma_plan'], tag + '_layers': sp['layers_on_split_gemm']})
-                    if sp.get('gemm_split_kernel'):
-                        extra.update({tag + '_gemm_tflops': sp['gemm_split_kernel']['executed_tflops'], tag + '_gemm_frac_of_its_peak': sp['gemm_split_kernel']['frac']})
-            for r in roof.get('top_kernels', []):
-                if r['frac'] is not None:       # one scalar per MFMA kernel of the detect step: frac_<kernel>
-                    extra['frac_' + r['kernel'].replace('[', '_').replace(']', '').replace('<', '_').replace('>', '').replace(',', '_')] = r['frac']
+                    extra[tag + '_detect_images_per_sec'] = sp['images_per_sec']
         if roof is None and ok(tr) and tr.get('roofline'):
             r = tr['roofline']
-            roof = {'bound': 'mfma', 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'what': r['what'], 'kernel': r['kernel'], 'achieved': r['achieved'], 'frac': r['frac'], 'traffic': None}
-        out = {'metric': metric, 'value': value, 'unit': 'images/sec', 'n_gpus': ctx.world, 'ranks_seen': ctx.ranks_seen, 'steps': steps, 'warmup': args.warmup,
-               'ms_per_step': msps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'headline': headline,
-               'config': {'workload': workload, 'classes': args.classes, 'global_batch': (args.batch if headline == 'detect' else args.train_batch) * ctx.world,
-                          'parallelism': (ms if args.multiscale else tr if headline == 'train' else det)['parallelism'], 'weights': 'random-init seed 0 (bench_data.randomize)'}}
-        # the long per-kernel tables first, the compact records the driver keeps LAST (its log keeps the tail of this line)
-        if conv3 is not None:
-            out['conv3x3_b64'] = conv3
-        if det is not None:
-            out['detect'] = dict(det, workload=det_workload)
-        if tr is not None:
-            out['train'] = dict(tr, workload=tr_workload)
-        if ms is not None:
-            out['multiscale'] = ms
-        if lat is not None:
-            out['latency'] = lat
-        if rn is not None:
-            out['resnet50_608'] = rn
-        if roof is not None:
-            tables = {k: roof.pop(k) for k in ('top_kernels', 'definition', 'split_bf16x6', 'split_f16x3', 'direct_only', 'conv_chain', 'all_mfma_kernels') if k in roof}
-            out['detect_kernel_table'] = tables
-            roof.update(extra)
-            out['roofline'] = roof
+            roof = {'bound': 'mfma', 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'what': r['what'], 'kernel': r['kernel'], 'achieved': r['achieved'], 'frac': r['frac'],
+                    'avg_launch_us': r['avg_launch_us'], 'traffic': r.get('traffic'), 'traffic_source': r.get('traffic_source')}
+        head = {'metric': metric, 'value': value, 'unit': 'images/sec', 'n_gpus': ctx.world, 'ranks_seen': ctx.ranks_seen, 'steps': steps, 'warmup': args.warmup,
+                'ms_per_step': msps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'headline': headline,
+                'config': {'workload': workload, 'classes': args.classes, 'global_batch': (args.batch if headline == 'detect' else args.train_batch) * ctx.world,
+                           'parallelism': (ms if args.multiscale else tr if headline == 'train' else det)['parallelism'], 'weights': 'random-init seed 0 (bench_data.randomize)'}}
+        cb = None
         if state is not None:
             try:
-                out['cpu_baseline'] = cpu_baseline(state, anchors, args.size, args.cpu_sample)
+                cb = cpu_baseline(state, anchors, args.size, args.cpu_sample)
             except Exception as e:
-                out['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
-        cb = out.get('cpu_baseline') or {}
-        if 'b1_ms_per_image' in cb:
-            extra.update(cpu_b1_ms=cb['b1_ms_per_image'], cpu_train_b8_img_s=cb['train_b8_images_per_sec'], cpu_nms_n200_ms=cb['nms_n200_ms'])
-            if out.get('roofline') is not None:
-                out['roofline'].update(cpu_b1_ms=cb['b1_ms_per_image'], cpu_train_b8_img_s=cb['train_b8_images_per_sec'], cpu_nms_n200_ms=cb['nms_n200_ms'])
-        out['summary'] = dict(extra, headline=headline, value=value, unit='images/sec', n_gpus=ctx.world,
-                              roofline_kernel=(roof or {}).get('kernel'), roofline_frac=(roof or {}).get('frac'),
-                              cpu_baseline_images_per_sec=(out.get('cpu_baseline') or {}).get('value'))
-        print(json.dumps(out))
+                cb = {'error': '%s: %s' % (type(e).__name__, e)}
+        # ---- everything (per-kernel tables, per-layer plans, per-size tables) goes to a FILE; stdout carries one compact line
+        full = dict(head)
+        for k, v in (('conv3x3_b64', conv3), ('detect', None if det is None else dict(det, workload=det_workload)), ('train', None if tr is None else dict(tr, workload=tr_workload)),
+                     ('multiscale', ms), ('latency', lat), ('resnet50_608', rn), ('roofline', roof), ('cpu_baseline', cb)):
+            if v is not None:
+                full[k] = v
+        full['scalars'] = extra
+        tables_at = write_tables(full, args.tables)
+        print(compact_line(head, roof, extra, cb, tables_at))
     if ctx.world > 1:
         ctx.dist.destroy_process_group()
 

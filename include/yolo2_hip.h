@@ -389,7 +389,9 @@ int y2_bn_act_bwd(const float* z, const float* scale, const float* shift, const 
 
 /* Extended forms for residual networks (model/resnet.py:29-104): `residual` (pixel stride ldr) is added before the
  * activation in the forward; the backward takes an optional second full-resolution gradient source dy_full2 (fan-out),
- * uses the residual to rebuild the activation mask and can emit dres = gradient w.r.t. the residual input. */
+ * uses the residual to rebuild the activation mask and can emit dres = gradient w.r.t. the residual input.
+ * Aliasing: dz may be one of the gradient inputs (the op is element-wise); a dense dz (ldd == C) that overlaps NO input
+ * additionally serves as scratch for the per-workgroup partial sums of pass 1 (an overlapping dz falls back to atomics). */
 int y2_bn_act_fwd_ex(const float* z, const float* scale, const float* shift, float slope, const float* residual, int ldr, float* y, float* y_pool,
                      int B, int H, int W, int C, int ldz, int ldy, int coff, int ldp, int poff, int out_mode, y2_stream_t stream);
 int y2_bn_act_bwd_ex(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,

@@ -192,6 +192,30 @@ def worker(rank, world, port, tmp):
         assert (dp2.tune_synced is not None) == (call >= 4)
     assert _hip._TUNE[(64, 10, 10, 512, 'cpu')] == [1, 0] and _hip._TUNE[('mine', rank, 'cpu')] == [2, 0]
     assert (('mine', 0, 'cpu') in _hip._TUNE) and len(_hip._TUNE) == (2 if rank == 0 else 3)
+    # only TRAINING steps advance that schedule: rank 0 alone runs evaluation / no_grad forwards through the wrapper (the summary
+    # worker, an eval pass) between training steps; were they counted, rank 0 would reach the tune broadcast one training step before rank 1,
+    # which would meet it with a gradient all-reduce on the same group - a hang or garbage
+    lin = nn.Linear(3, 3)
+    dp3 = train.DataParallelRCCL(lin)
+    xs = torch.randn(4, 3, generator=torch.Generator().manual_seed(5))
+    for call in range(1, 6):
+        if rank == 0:
+            with torch.no_grad():
+                dp3(xs)                                         # rank-local, gradients off
+            lin.eval()
+            dp3(xs)                                             # rank-local, eval mode
+            lin.train()
+        for p in lin.parameters():
+            p.grad = None
+        dp3(xs[rank * 2:rank * 2 + 2]).pow(2).mean().backward()
+        assert dp3._calls == call, (rank, dp3._calls, call)
+        assert (dp3.tune_synced is not None) == (call >= 4), (rank, call)
+        red = [p.grad.clone() for p in lin.parameters()]
+        for p in lin.parameters():
+            p.grad = None
+        lin(xs).pow(2).mean().backward()
+        for a, p in zip(red, lin.parameters()):
+            assert torch.allclose(a, p.grad, rtol=1e-5, atol=1e-6), ('eval calls between training steps', rank, call)
     if rank == 0:
         open(os.path.join(tmp, 'ok'), 'w').write('ok')
     dist.barrier()

@@ -1,0 +1,119 @@
+"""BASELINE configs[2] AT ITS OWN SHAPE on the code path that produces the benchmark number.
+
+The reference's training recipe is `train.py -b 64` (quick_start.sh:71) through `Train.iterate` (train.py:338-362).  bench.py times
+`train.iterate` at batch 64, 416x416, VOC-20: after three eager plan steps the step is captured and every later step is a hipGraph REPLAY of
+model.train_graph.StepPlan.  Tile shapes, split-K factors and the Winograd forms a layer takes all depend on the batch size, and round 4's
+memset bug lived in replay-only, full-width-only behaviour - so this test holds exactly that: full-width Darknet-19, batch 64, the REPLAYED
+step, on two alternating batches, against the oracle's fp64 autograd of the same step (oracle/darknet.py, oracle/loss.py), with the oracle's
+own fp32 run as the arithmetic floor (the production rule of tests/test_gpu_fullsize.py).  Learning rate 0: every step is the same function
+of (weights, batch), so the replays of one batch must agree with each other, too."""
+import configparser
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import darknet as odark
+from oracle import head as ohead
+from oracle import loss as oloss
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+B, S, C = 64, 416, 20
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def rms_rel(got, ref):
+    ref = ref.double()
+    return ((got.double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-30)).item()
+
+
+def oracle_step(sd, anchors, x, data, dt):
+    """fwd (batch statistics) + region loss + backward of the oracle in dtype `dt`: (loss terms, parameter gradients)."""
+    sdx = {k: (v.to(dt).requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+    f = odark.forward(x.to(dt), sdx, training=True)
+    lo, _ = oloss.loss(anchors.to(dt), {k: (v.to(dt) if v.is_floating_point() else v) for k, v in data.items()}, ohead.decode(f, anchors.to(dt)), 0.6)
+    oloss.total(lo).backward()
+    return {k: float(v.detach()) for k, v in lo.items()}, {k: v.grad for k, v in sdx.items() if getattr(v, 'grad', None) is not None}
+
+
+@pytest.mark.timeout(1500)
+def test_batch64_replayed_training_step_equals_the_oracle():
+    import model
+    import model.yolo2
+    import train as y2train
+    import utils
+    assert y2train.PLAN and y2train.GRAPH, 'this test is about the captured path (Y2_TRAIN_PLAN / Y2_TRAIN_GRAPH must be on)'
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({'batch_norm': {'enable': '1'}})
+    anchors = torch.from_numpy(synth.ANCHORS_VOC)
+    sd = odark.init_state_dict(5, C, seed=0, head_scale=1 / 40.0)
+    dnn = model.yolo2.Darknet(model.ConfigChannels(cfg, sd), anchors, C)
+    dnn.load_state_dict(sd, strict=False)
+    inf = model.Inference(cfg, dnn, anchors).to(dev()).train()
+    opt = utils.optim.SGD(inf.parameters(), 0.0)          # the fused optimizer still runs every step (y2_opt_sgd), it just moves nothing
+    host, data = [], []
+    for i in range(2):
+        lab = synth.labels(B, S, C, nmax=8, seed=60 + i)
+        x = synth.images(B, S, seed=70 + i)
+        host.append((x, synth.norm_data(lab, S, S, S // 32, S // 32)))
+        d = {k: v.to(dev()) for k, v in lab.items()}
+        d['tensor'] = x.to(dev())
+        data.append(d)
+    # ---- 3 eager plan steps, the capture (4th call, replayed right away), then 6 more replays: 7 replays over the two batches
+    runner = None
+    seen = {0: [], 1: []}
+    for i in range(10):
+        r = y2train.iterate(inf, opt, data[i % 2], oloss.HPARAM, 0.6, anchors)
+        runner = inf.__dict__['_y2_step_runner']
+        if runner.last[1] == 'replay' or (i >= 3 and runner.last[1] == 'capture'):
+            seen[i % 2].append(({k: float(r['loss'][k].detach()) for k in r['loss']}, {k: p.grad.detach().clone() for k, p in dnn.named_parameters()}, runner.last[1]))
+    torch.cuda.synchronize()
+    assert runner.captures == 1 and runner.broken is None and not runner.eager_only, (runner.captures, runner.broken, runner.eager_only)
+    assert all(len(v) >= 3 for v in seen.values()), {k: [m for _, _, m in v] for k, v in seen.items()}
+    assert sum(1 for v in seen.values() for _, _, m in v if m == 'replay') >= 6
+    for p in dnn.parameters():
+        assert torch.isfinite(p.grad).all()
+    # ---- replays of the same batch agree with each other (what differs: completion-order atomics of split reductions and BatchNorm sums)
+    for b, rows in seen.items():
+        for lo, gr, _ in rows[1:]:
+            for k in lo:
+                np.testing.assert_allclose(lo[k], rows[0][0][k], rtol=2e-5, err_msg='batch %d loss %s between replays' % (b, k))
+    # ---- against the oracle
+    torch.set_num_threads(max(1, min(128, os.cpu_count() or 1)))
+    worst = 0.0
+    for b in (0, 1):
+        x, nd = host[b]
+        t0 = time.time()
+        l64, g64 = oracle_step(sd, anchors, x, nd, torch.float64)
+        t1 = time.time()
+        l32, g32 = oracle_step(sd, anchors, x, nd, torch.float32)
+        print('oracle batch-%d step: fp64 %.1f s, fp32 %.1f s' % (B, t1 - t0, time.time() - t1))
+        lo, gr, mode = seen[b][-1]
+        assert mode == 'replay'
+        assert set(lo) == set(l64) and len(lo) == 5
+        for k in lo:
+            np.testing.assert_allclose(lo[k], l64[k], rtol=1e-5, err_msg='batch %d loss %s' % (b, k))
+        assert set(gr) == set(g64)
+        rows = []
+        for k in g64:
+            floor = rms_rel(g32[k], g64[k])
+            e = rms_rel(gr[k], g64[k])
+            rows.append((e / max(1e-4 / 2.5, floor), k, e, floor))
+            # the other replays of this batch are the same step: hold them to the same bound
+            for _, gother, _ in seen[b][:-1]:
+                eo = rms_rel(gother[k], g64[k])
+                assert eo <= max(1e-4, 2.5 * floor), ('earlier replay', b, k, eo, floor)
+        rows.sort(reverse=True)
+        print('batch %d of 2, REPLAYED batch-64 step vs fp64 oracle: worst gradient error / fp32 floor = %.2f' % (b, rows[0][0]))
+        for r in rows[:5]:
+            print('    %-28s error %.3e  fp32 floor %.3e  ratio %.2f' % (r[1], r[2], r[3], r[0]))
+        worst = max(worst, rows[0][0])
+        assert rows[0][0] <= 2.5, rows[0]
+    print('batch-64 replayed step: worst ratio %.2f (bound 2.5)' % worst)

@@ -151,7 +151,8 @@ def test_boxes_within_1e4_iou_and_oracle_equal_survivors(net, batch, truth):
     (b) the filter -> NMS -> class expansion stages are bit-exact against the oracle given the same decoded inputs (full size:
         845 candidates per image, limit 200);
     (c) the end-to-end survivor lists equal those of the pure-oracle pipeline (fp64 feature -> decode -> filter -> NMS) on every
-        sampled image that has no decision within rounding distance of a threshold (at least 6 of the 8 must qualify)."""
+        sampled image that has no decision within rounding distance of a threshold (at least 5 of the 8 must qualify; every
+        differing list must be EXPLAINED by such a decision, see below)."""
     import detect
     from oracle import detect as odet
     inf, anchors, sd = net

@@ -413,9 +413,64 @@ def test_full_width_replays_equal_the_autograd_step():
                 assert inf.__dict__['_y2_step_runner'].captures == 1
         finally:
             y2train.PLAN = True
+    # What "equal" means at full width (README "Tolerances"): the weight gradients in front of a batch-statistics BatchNorm are cancellation
+    # residues - the oracle's own fp32 run is 0.5-0.9 % (rms) away from its fp64 run there, and two fp32 runs that add in different orders
+    # (completion-order atomics: the autograd path and a replay, or two replays) differ by about that floor.  So both paths are held to the
+    # ORACLE with the production rule (rms error <= max(1e-4, 2.5 x the fp32 floor), tests/test_gpu_fullsize.py), and to each other with
+    # rms error <= max(1e-3, 2.5 x floor); a wrong replay (stale scratch, a missing zero fill) is off by O(1).
+    from oracle import head as ohead
+    torch.set_num_threads(64)
+
+    def rms_rel(got, ref):
+        ref = ref.double().cpu()
+        return ((got.double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-30)).item()
+    ref = {}
+    for b in range(2):
+        x = data[b]['tensor'].cpu()
+        nd = synth.norm_data({k: v.cpu() for k, v in data[b].items() if k != 'tensor'}, 416, 416, 13, 13)
+        for name, dt in (('fp64', torch.float64), ('fp32', torch.float32)):
+            sdx = {k: (v.to(dt).requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+            f = odark.forward(x.to(dt), sdx, training=True)
+            lo, _ = oloss.loss(anchors.to(dt), {k: (v.to(dt) if v.is_floating_point() else v) for k, v in nd.items()}, ohead.decode(f, anchors.to(dt)), 0.6)
+            oloss.total(lo).backward()
+            ref[(b, name)] = {k: v.grad for k, v in sdx.items() if getattr(v, 'grad', None) is not None}
+    worst = [0.0, 0.0, 0.0]
     for i, ((la, ga), (lb, gb)) in enumerate(zip(runs[False], runs[True])):
         np.testing.assert_allclose(lb, la, rtol=2e-5, err_msg='step %d' % i)
         if ga is not None:
+            g64, g32 = ref[(i % 2, 'fp64')], ref[(i % 2, 'fp32')]
+            assert set(ga) == set(g64)
             for k in ga:
-                # run-to-run noise of the cancellation-residue gradients (completion-order atomics in front of 23 batch-statistics BatchNorm layers)
-                assert rel(gb[k], ga[k]) <= 2e-2, (i, k, rel(gb[k], ga[k]))
+                floor = rms_rel(g32[k], g64[k])
+                ea, eb, ab = rms_rel(ga[k], g64[k]), rms_rel(gb[k], g64[k]), rms_rel(gb[k], ga[k])
+                worst = [max(worst[0], ea / max(4e-5, floor)), max(worst[1], eb / max(4e-5, floor)), max(worst[2], ab / max(4e-4, floor))]
+                assert ea <= max(1e-4, 2.5 * floor), ('autograd vs oracle', i, k, ea, floor)
+                assert eb <= max(1e-4, 2.5 * floor), ('replay vs oracle', i, k, eb, floor)
+                assert ab <= max(1e-3, 2.5 * floor), ('replay vs autograd', i, k, ab, floor)
+    print('full-width batch-4 steps: autograd / replay error over the fp32 floor %.2f / %.2f, replay vs autograd %.2f' % tuple(worst))
+
+
+def test_a_parameter_frozen_after_the_first_steps_drops_the_plans():
+    """A plan snapshots the parameter list at creation and writes every gradient: freezing a layer later (requires_grad = False, a
+    fine-tuning schedule) must take the step off the captured plans - the frozen parameter receives no gradient any more and does not move."""
+    import train as y2train
+    import utils
+    inf, anchors = build('darknet')
+    opt = utils.optim.SGD(inf.parameters(), 1e-3, momentum=0.0)
+    data = batches(96, 2)
+    for i in range(6):
+        y2train.iterate(inf, opt, data[i % 3], oloss.HPARAM, 0.6, anchors)
+    runner = inf.__dict__['_y2_step_runner']
+    assert runner.captures == 1 and len(runner.plans) == 1
+    frozen = inf.dnn.layers1[2].conv.weight
+    frozen.requires_grad_(False)
+    frozen.grad = None
+    before = frozen.detach().clone()
+    other = inf.dnn.layers1[4].conv.weight
+    moved = other.detach().clone()
+    r = y2train.iterate(inf, opt, data[0], oloss.HPARAM, 0.6, anchors)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(r['loss_total']))
+    assert len(runner.plans) == 0                      # no plan holds the stale parameter list
+    assert frozen.grad is None and torch.equal(frozen.detach(), before)
+    assert other.grad is not None and not torch.equal(other.detach(), moved)

@@ -19,7 +19,7 @@ try:
 except Exception:
     KERNELS = None
 
-FAMILY = re.compile(r'conv_fwd_dma_kernel|conv_splitk_fixup_kernel|wino_(input|output|fused2?|tile_table)_kernel|conv0_kernel|gemm_split_kernel|wino_input_split_kernel')
+FAMILY = re.compile(r'conv_fwd_dma_kernel|conv_splitk_fixup_kernel|wino_(input|output|fused\d*|tile_table)_kernel|conv0_kernel|gemm_split_kernel|wino_input_split_kernel')
 TRAIN = len(sys.argv) > 2 and sys.argv[2] == 'train'       # every kernel of the training step; steps = loss_fwd_kernel dispatches
 if TRAIN:
     FAMILY = re.compile(r'.')

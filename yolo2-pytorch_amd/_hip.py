@@ -568,7 +568,10 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
         load_tune_defaults(dev)
     hit = None if DETERMINISTIC else _TUNE.get(key)      # deterministic mode ignores measured choices (they may differ between runs)
     if hit is not None:
-        return apply(tuple(hit) if isinstance(hit, (list, tuple)) else (0, hit))
+        hit = tuple(hit) if isinstance(hit, (list, tuple)) else (0, hit)
+        if PERSIST or not (hit[0] == 0 and hit[1] in (11, 12, 13, 15)):
+            return apply(hit)
+        # Y2_CONV_PERSIST=0 (A/B switch): a table entry that names a persistent tile does not count - measure (or fall back) without them
     if not AUTOTUNE or DETERMINISTIC or torch.cuda.is_current_stream_capturing():
         # no measurement possible (or, deterministic mode: a timed choice may differ from run to run and with it the rounding): the choices the measurements converge to on MI355X (profiles/r01_detect_b32_layer_table.txt)
         prefer = []

@@ -710,7 +710,19 @@ extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float*
     hipStream_t s = y2_s(stream);
     a.partial = nullptr;
     // per-workgroup partial sums parked in the (not yet written) dz buffer when it is dense and large enough; else the atomics
-    a.block_partial = (dz != nullptr && !y2_det.on && ldd == C && grid > 16 && (long long)grid * 2 * C <= (long long)B * H * W * ldd) ? dz : nullptr;
+    // (pass 1 of OTHER workgroups still reads its inputs while a finished one parks its sums: a dz that aliases any input - the element-wise
+    //  in-place use dz == dy_full is legal for this entry point - keeps the atomics)
+    const long long npix = (long long)B * H * W;
+    auto overlaps = [&](const float* p, long long floats) {
+        if (p == nullptr) return false;
+        const char* lo = (const char*)dz; const char* hi = lo + (size_t)npix * ldd * sizeof(float);
+        const char* q = (const char*)p;
+        return q < hi && lo < q + (size_t)floats * sizeof(float);
+    };
+    const long long opix = pix;      // pooled gradient: one pixel per window
+    const bool aliased = dz != nullptr && (overlaps(z, npix * ldz) || overlaps(dy_full, (fmode == 1 ? npix / 4 : npix) * (long long)ldf) || overlaps(dy_pool, opix * ldp) ||
+                                           overlaps(dy_full2, npix * ld2) || overlaps(residual, npix * ldr) || overlaps(dres, npix * lddr));
+    a.block_partial = (dz != nullptr && !aliased && !y2_det.on && ldd == C && grid > 16 && (long long)grid * 2 * C <= npix * ldd) ? dz : nullptr;
     const long long prow = (long long)grid * 256 / Cg;            // rows of per-thread partials (grid * 256 is a multiple of Cg)
     if (y2_det.on) {
         if ((size_t)prow * 2 * C * sizeof(float) > y2_det.bytes || prow > 0x7fffffffLL) return Y2_EINVAL;

@@ -1341,6 +1341,7 @@ class _Segments(object):
     def __init__(self, pool, mode):
         self.pool, self.mode = pool, mode
         self.ops, self.graph, self.mark = [], None, 0
+        self.held = []
 
     def begin(self):
         self.graph = torch.cuda.CUDAGraph()
@@ -1348,8 +1349,15 @@ class _Segments(object):
         self.graph.capture_begin(pool=self.pool, capture_error_mode='thread_local')
         self.mark = _hip.LAUNCHES[0]
 
-    def cut(self, op):
-        """A collective belongs here.  An empty segment is not closed (hipGraphInstantiate of nothing): the op then simply follows its predecessor."""
+    def cut(self, op, maybe_foreign=False):
+        """A collective belongs here.  A segment without any launch is not closed (hipGraphInstantiate of nothing): the op then simply follows
+        its predecessor.  _hip.LAUNCHES counts the LIBRARY's launches only; a caller that may have enqueued torch-native kernels since the last
+        cut says so (maybe_foreign): the segment is then closed behind one trivial library launch, so that nothing it holds can be reordered
+        behind the collective."""
+        if _hip.LAUNCHES[0] == self.mark and maybe_foreign:
+            t = torch.empty(4, dtype=torch.float32, device=torch.device('cuda', torch.cuda.current_device()))
+            self.held.append(t)            # lives as long as the graphs that write it (the plan keeps `held`)
+            _hip.multi([(_hip.MULTI_ZERO, t, None)])
         if _hip.LAUNCHES[0] != self.mark:
             self.graph.capture_end()
             self.ops.append(('graph', self.graph))
@@ -1480,12 +1488,12 @@ class StepPlan(object):
                     join = getattr(state['tape'], 'join', None)
                     if join is not None:
                         join()               # weight gradients still running on the backward's side stream: a graph segment ends with every forked stream joined
-                    seg.cut(('buckets', lo, hi))
+                    seg.cut(('buckets', lo, hi), maybe_foreign=True)
 
         def npos(t):
             if seg is None:
                 return dp._sum_small(t)
-            seg.cut(('npos', t))
+            seg.cut(('npos', t), maybe_foreign=True)
             return True
 
         hooks = (getattr(dnn, 'grad_ready_hook', None), getattr(dnn, 'grad_buffer_hook', None))
@@ -1623,6 +1631,7 @@ class StepPlan(object):
                 gc.enable()
         cur.wait_stream(side)
         self.ops, self.grads = seg.ops, grads
+        self._held = seg.held
         self._baked = self._addresses()
 
     def _addresses(self):

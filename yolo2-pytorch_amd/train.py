@@ -89,7 +89,7 @@ class DataParallelRCCL(nn.Module):
                 m.grad_buffer_hook = self._grad_buffer
 
     tune_synced = None
-    # forward calls (counted per wrapper, identical on every rank) at which the ranks adopt rank 0's measured algorithm choices: after 3 whole
+    # training steps (forward calls in train mode with gradients enabled, or replayed plans; counted per wrapper, identical on every rank) at which the ranks adopt rank 0's measured algorithm choices: after 3 whole
     # steps, then at a thinning schedule that picks up the shapes a multi-scale run visits later, then every 4096 calls.  Rank 0's entries
     # win, entries only this rank has (a shape rank 0 has not met) stay; plans are rebuilt only where something changed.
     SYNC_TUNE_CALLS = (4, 16, 64, 256, 1024, 4096)
@@ -302,17 +302,23 @@ class DataParallelRCCL(nn.Module):
             self._pending = False
             self._reset()
 
-    def _tick(self):
-        """Start of a step (forward() or a StepPlan's graph_begin): clean bookkeeping, the call count, the tune exchange it triggers."""
+    def _tick(self, training=True):
+        """Start of a step (forward() or a StepPlan's graph_begin): clean bookkeeping and - for TRAINING steps only - the step count and the
+        tune exchange it triggers."""
         # a backward that raised leaves the bookkeeping half-filled: start every step from a clean slate
         self._pending = False
         self._reset()
+        if not training:
+            # an evaluation / no_grad call through the wrapper (rank 0 alone summarising, train.py:209; an eval pass between epochs) is
+            # rank-local: it must not advance the schedule below, or that rank would enter the broadcast one step before the others do
+            # while they issue a gradient all-reduce on the same group (ADVICE r4)
+            return
         self._calls += 1
         if self.world > 1 and (self._calls in self.SYNC_TUNE_CALLS or self._calls % self.SYNC_TUNE_CALLS[-1] == 0):
-            # the trigger is the wrapper's call count and nothing else: every rank starts one step per step, so every rank reaches the
-            # broadcast at the same point of its collective sequence - whatever input shapes the ranks' own loaders drew (with one process
-            # per GPU each rank's collate picks its multi-scale size itself, utils/data.py:135-141; a per-shape trigger would put one rank
-            # into the broadcast while the others start a gradient all-reduce)
+            # the trigger is the wrapper's count of TRAINING steps and nothing else: every rank starts one training step per step, so every
+            # rank reaches the broadcast at the same point of its collective sequence - whatever input shapes the ranks' own loaders drew
+            # (with one process per GPU each rank's collate picks its multi-scale size itself, utils/data.py:135-141; a per-shape trigger
+            # would put one rank into the broadcast while the others start a gradient all-reduce)
             self._sync_tune()
 
     # ---- the same protocol for a step that runs as captured hipGraph segments (model.train_graph.StepPlan): no autograd hooks fire, the
@@ -370,7 +376,7 @@ class DataParallelRCCL(nn.Module):
                 self._views[id(p)] = g
 
     def forward(self, *args, **kwargs):
-        self._tick()
+        self._tick(training=self.module.training and torch.is_grad_enabled())
         out = self.module(*args, **kwargs)
         # the region loss sums its positive count over THIS wrapper's group (model/__init__.py:162: mean over the positives of the
         # global batch): the reducer travels with the predictions (model.train_graph.DP_TAG)
@@ -476,8 +482,18 @@ class StepRunner(object):
         if any(k not in data for k in ('yx_min', 'yx_max', 'cls')) or data['yx_min'].dim() != 3 or data['cls'].dim() not in (2, 3):
             return False
         ok = getattr(self, '_params_ok', None)
+        if ok is not None:
+            # a plan snapshots the parameter list and writes EVERY gradient: a parameter frozen after the first step (requires_grad = False:
+            # fine-tuning schedules) or replaced by another tensor must drop the plans, not keep receiving gradients.  requires_grad is one
+            # attribute read per parameter per step; the identity of the list is re-derived every 32 steps (a module-tree walk)
+            self._params_age = getattr(self, '_params_age', 0) + 1
+            ps = self._params_seen
+            if not all(p.requires_grad for p in ps) or (self._params_age % 32 == 0 and [id(p) for p in dnn.parameters()] != [id(p) for p in ps]):
+                self.plans.clear()
+                ok = None
         if ok is None:
-            ps = list(dnn.parameters())
+            ps = self._params_seen = list(dnn.parameters())
+            self._params_age = 0
             ok = all(p.requires_grad and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps)
             if ok and isinstance(dnn, _yolo2.Darknet) and not isinstance(dnn, _yolo2.Tiny):
                 ok = train_graph._pad_layout(dnn) is None           # pruned widths run zero-padded through host-side glue: autograd path
