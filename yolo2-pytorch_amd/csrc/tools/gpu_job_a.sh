@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-5 GPU call 1: new parity tests, the driver's bench command, batch-1 split-K probe
-cd "$(dirname "$0")/../.." || exit 1
-O=gpurun_out/r5a; mkdir -p $O
+cd "$(dirname "$0")/.." || exit 1
+O=gpurun_out/fa; mkdir -p $O
 timeout 1500 python -m pytest tests/test_gpu_b64.py "tests/test_gpu_plan.py::test_full_width_replays_equal_the_autograd_step" "tests/test_gpu_plan.py::test_a_parameter_frozen_after_the_first_steps_drops_the_plans" -x -q -s > $O/tests.log 2>&1
 echo "tests rc=$?" >> $O/tests.log
 tail -30 $O/tests.log
