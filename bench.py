@@ -284,6 +284,18 @@ def static_traffic(tag):
         return None, None
 
 
+def static_extra(tag, key):
+    """Another member of the committed profile record static_traffic() reads (same hash gate)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_%s_traffic.json' % tag)))
+    try:
+        import _hip
+        d = json.load(open(files[-1]))
+        return d.get(key) if d.get('kernels') == _hip.kernel_hash() else None
+    except Exception:
+        return None
+
+
 # ---------------------------------------------------------------------------------------------------- detect leg
 def detect_leg(args, ctx):
     import torch
@@ -315,23 +327,6 @@ def detect_leg(args, ctx):
         table = kernel_table(eager, min(steps, 8)) if want_table else None
         runs = None
         nstreams = max(1, min(args.streams if want_streams is None else want_streams, len(xs))) if (not args.no_graph and args.model == 'darknet') else 1
-        measure.table2 = None
-        if want_table and nstreams > 1:
-            # the same launches issued the way the TIMED region runs them: consecutive batches alternate between two streams (private buffer
-            # slots), so a kernel's launch duration contains what the co-running kernels of the other batch cost it - the figure a rocprofv3
-            # trace of this command shows; the single-stream table above is the uncontended one
-            ss = [torch.cuda.Stream() for _ in range(nstreams)]
-
-            def eager2(i):
-                with torch.cuda.stream(ss[i % nstreams]), torch.no_grad():
-                    return detect.detect_batch(dnn.forward_nhwc(xs[i % len(xs)], i % nstreams), anchors, **kw)
-            try:
-                for i in range(2 * nstreams):
-                    eager2(i)
-                ctx.sync()
-                measure.table2 = kernel_table(eager2, max(nstreams * 4, min(steps, 16)))
-            except Exception as e:
-                print('two-stream kernel table failed (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
         if not args.no_graph:
             try:      # one captured graph per resident batch; graph i runs in buffer slot i % nstreams on stream i % nstreams: graphs of one
                       # slot share intermediate buffers and are serial on their stream, different slots overlap
@@ -358,7 +353,6 @@ def detect_leg(args, ctx):
 
     dt, host, table, graphed = measure(args.steps, args.warmup, ctx.world == 1)
     pipelined = getattr(measure, 'nstreams', 1)
-    table2 = getattr(measure, 'table2', None)
     serial_dt = None
     if pipelined > 1 and ctx.world == 1:          # the same graphs strictly one after the other: the latency of a step, reported beside the throughput
         serial_steps = min(args.steps, 24)
@@ -376,14 +370,6 @@ def detect_leg(args, ctx):
     roof = None
     if table is not None:
         roof = roofline_from(table, 'detect step, batch %d (eager single-stream launches of the same kernels the timed hipGraph replays)' % args.batch)
-        if table2 is not None:
-            # headline `frac`: the dominant kernel's duration UNDER THE TIMED SCHEDULE (two pipelined streams); the uncontended figure beside it
-            r2 = roofline_from(table2, 'detect step, batch %d: launch durations under the timed two-stream schedule (eager launches alternating between the streams)' % args.batch)
-            k2 = next((r for r in r2['top_kernels'] if r['kernel'] == roof['kernel']), None)
-            if k2 is not None and k2['frac'] is not None:
-                roof.update(frac_uncontended=roof['frac'], achieved_uncontended=roof['achieved'], avg_launch_us_uncontended=roof['avg_launch_us'],
-                            frac=k2['frac'], achieved=k2['executed_tflops'], avg_launch_us=k2['avg_launch_us'], what=r2['what'])
-            roof['two_stream_top_kernels'] = r2['top_kernels']
         plan = dnn._plan_cache[1] if dnn._plan_cache else None
         if plan is not None and 'flops_executed' in plan:
             conv_ms = sum(e['ms'] for k, e in table.items() if k.startswith(('conv', 'wino')))
@@ -397,6 +383,16 @@ def detect_leg(args, ctx):
             roof['timed_step_executed_frac'] = round(exe / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
         tr, src = static_traffic('detect_b32') if (args.batch == 32 and args.size == 416 and args.model == 'darknet') else (None, None)
         roof['traffic'], roof['traffic_source'] = tr, src
+        # The per-launch duration above is the UNCONTENDED one (eager single-stream launches under the event hooks).  The timed region replays
+        # the steps pipelined over two streams, where a kernel shares the chip with the other batch's kernels: its launch duration under THAT
+        # schedule cannot be bracketed from inside a hipGraph replay, so it comes from the committed rocprofv3 kernel trace of this command
+        # (profiles/*_detect_b32_traffic.json: `dominant_trace`, same kernel-source hash) and is labelled as such.
+        dt_tr = static_extra('detect_b32', 'dominant_trace') if tr is not None else None
+        dom = table.get(roof['kernel']) if roof.get('kernel') else None
+        if dt_tr and dom and dom['launches'] > 0 and roof['kernel'].split('[')[0] in dt_tr.get('kernel', ''):
+            per_launch = dom['flops'] / dom['launches']
+            roof['frac_timed_schedule_rocprof'] = round(per_launch / (dt_tr['avg_us'] * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+            roof['avg_launch_us_timed_schedule_rocprof'] = dt_tr['avg_us']
         if _hip.WINOGRAD and args.model == 'darknet' and not args.no_direct_leg:
             _hip.WINOGRAD = False
             dnn._plan_cache = None
@@ -632,9 +628,11 @@ def multiscale_leg(args, ctx):
     def step(S):
         last['r'] = y2train.iterate(m, opt, data[S], bench_data.HPARAM, bench_data.THRESHOLD, anchors)
 
-    first_visit = {}
+    import _hip
+    first_visit, first_miss = {}, {}
     for S in sizes:                      # untimed: first visit of every size
         ctx.sync()
+        miss0 = len(_hip.TUNE_MISSES)
         t0 = time.perf_counter()
         for _ in range(max(5, maintain // 2)):
             step(S)
@@ -645,6 +643,7 @@ def multiscale_leg(args, ctx):
         ctx.sync()
         steady = (time.perf_counter() - t1) / 3
         first_visit[S] = max(0.0, (t1 - t0) - max(5, maintain // 2) * steady)
+        first_miss[S] = len(_hip.TUNE_MISSES) - miss0          # problem shapes that had to be MEASURED at this visit (0 with a complete default table)
     schedule = [S for _ in range(max(1, args.ms_cycles)) for S in sizes for _ in range(maintain)]
     dt, host = ctx.timed(lambda i: step(schedule[i]), len(schedule))
     issue = {S: issue_time(ctx, lambda i, S=S: step(S), 4) for S in (sizes[0], sizes[-1])}
@@ -664,7 +663,7 @@ def multiscale_leg(args, ctx):
         med = rest[len(rest) // 2]
         switch.append(max(0.0, per[S][0] - med))
         table.append({'size': S, 'ms_per_step': round(med, 3), 'images_per_sec': round(B * ctx.world / med * 1e3, 1), 'first_step_after_switch_ms': round(per[S][0], 3),
-                      'switch_cost_ms': round(max(0.0, per[S][0] - med), 3), 'first_visit_ms': round(first_visit[S] * 1e3, 1)})
+                      'switch_cost_ms': round(max(0.0, per[S][0] - med), 3), 'first_visit_ms': round(first_visit[S] * 1e3, 1), 'first_visit_shapes_measured': first_miss[S]})
     per_img = FLOPS_TRAIN_PER_IMG * sum((S / 416.0) ** 2 for S in sizes) / len(sizes) if args.model == 'darknet' else None
     out = {'workload': '%s YOLOv2 %d-class multi-scale train, batch-%d/GPU, sizes %s, resize every %d batches: fwd + region loss + bwd + SGD (BASELINE configs[3] per GPU)'
                        % (args.model, C, B, '..'.join(str(v) for v in (sizes[0], sizes[-1])) + ' step %d' % (sizes[1] - sizes[0] if len(sizes) > 1 else 0), maintain),
@@ -673,6 +672,8 @@ def multiscale_leg(args, ctx):
            'switch_cost_ms_mean': round(sum(switch) / len(switch), 3), 'switch_cost_ms_max': round(max(switch), 3),
            'first_visit_ms_mean': round(sum(first_visit.values()) / len(first_visit) * 1e3, 1), 'first_visit_ms_max': round(max(first_visit.values()) * 1e3, 1), 'first_visit_ms_total': round(sum(first_visit.values()) * 1e3, 1),
            'per_gpu_batch': B, 'global_batch': B * ctx.world, 'loss_total': float(last['r']['loss_total'].detach()),
+           'first_visit_shapes_measured': sum(first_miss.values()), 'first_visit_measured_keys': [list(map(str, k)) for k in _hip.TUNE_MISSES[-8:]] if sum(first_miss.values()) else [],
+           'default_tune_table_entries': _hip._DEFAULTS_SEEN.get(str(ctx.dev)),
            'parallelism': 'dp%d' % ctx.world if ctx.world > 1 else 'single GPU', 'per_size': table}
     if per_img is not None:
         out['direct_equiv_tflops_per_gpu'] = round(per_img * B * len(schedule) / dt / 1e12, 2)
@@ -931,8 +932,8 @@ def dry_run(args, ctx):
 
 
 LINE_LIMIT = 6000        # bytes of the final stdout line: the driver parses the LAST line of stdout and keeps a bounded tail of it (round 4's 30 KB line was not parsed)
-ROOF_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'avg_launch_us', 'kernel_share_of_step', 'frac_uncontended', 'avg_launch_us_uncontended',
-             'timed_step_executed_frac', 'kernel_ms_per_step', 'what', 'traffic_source')
+ROOF_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'avg_launch_us', 'kernel_share_of_step', 'frac_timed_schedule_rocprof',
+             'avg_launch_us_timed_schedule_rocprof', 'timed_step_executed_frac', 'kernel_ms_per_step', 'what', 'traffic_source')
 # scalars that go first when the line would exceed LINE_LIMIT (least important first)
 DROP_ORDER = ('split_bf16x6_detect_images_per_sec', 'split_f16x3_detect_images_per_sec', 'latency_b8_launches', 'latency_b1_launches', 'resnet50_608_train_kernel_ms_sum',
               'resnet50_608_train_mfma_ms_per_step', 'train_mfma_ms_per_step', 'train_kernel_ms_sum_single_stream', 'train_dominant_avg_launch_us', 'multiscale_switch_cost_ms_max',
@@ -1126,7 +1127,8 @@ def main():
                              resnet50_608_train_kernel_ms_sum=r['kernel_ms_per_step'])
         if ok(ms):
             extra.update(multiscale_images_per_sec=ms['images_per_sec'], multiscale_ms_per_step_mean=ms['ms_per_step_mean'], multiscale_switch_cost_ms_max=ms['switch_cost_ms_max'],
-                         multiscale_first_visit_ms_mean=ms['first_visit_ms_mean'], multiscale_first_visit_ms_max=ms.get('first_visit_ms_max'))
+                         multiscale_first_visit_ms_mean=ms['first_visit_ms_mean'], multiscale_first_visit_ms_max=ms.get('first_visit_ms_max'),
+                         multiscale_first_visit_shapes_measured=ms.get('first_visit_shapes_measured'))
         if roof is not None:
             for tag in ('split_bf16x6', 'split_f16x3'):
                 sp = roof.get(tag)

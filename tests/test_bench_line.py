@@ -19,8 +19,8 @@ def _worst_case():
             'dtype': 'f32', 'data': 'synthetic', 'headline': 'detect',
             'config': {'workload': 'Darknet-19 YOLOv2 416x416 batch-32/GPU inference: conv stack + decode + filter + NMS (BASELINE configs[1])', 'classes': 20, 'global_batch': 32,
                        'parallelism': 'single GPU', 'weights': 'random-init seed 0 (bench_data.randomize)'}}
-    roof = {'bound': 'mfma', 'peak': 157.3, 'unit': 'TFLOP/s', 'what': 'x' * 400, 'kernel': 'conv_fwd_dma_kernel[grouped]', 'achieved': 111.6, 'frac': 0.7096, 'frac_uncontended': 0.8075,
-            'avg_launch_us': 373.3, 'avg_launch_us_uncontended': 327.9, 'kernel_share_of_step': 0.41, 'traffic': 8.49e9, 'traffic_source': 'static: ' + 'p' * 300,
+    roof = {'bound': 'mfma', 'peak': 157.3, 'unit': 'TFLOP/s', 'what': 'x' * 400, 'kernel': 'conv_fwd_dma_kernel[grouped]', 'achieved': 111.6, 'frac': 0.7096, 'frac_timed_schedule_rocprof': 0.7075,
+            'avg_launch_us': 373.3, 'avg_launch_us_timed_schedule_rocprof': 327.9, 'kernel_share_of_step': 0.41, 'traffic': 8.49e9, 'traffic_source': 'static: ' + 'p' * 300,
             'timed_step_executed_frac': 0.6979, 'kernel_ms_per_step': 4.9, 'top_kernels': [{'kernel': 'k%d' % i, 'frac': 0.5} for i in range(40)], 'conv_chain': {'a': 1},
             'two_stream_top_kernels': [{'kernel': 'k'}] * 30, 'definition': 'd' * 500}
     extra = {}

@@ -36,7 +36,8 @@ def rms_rel(got, ref):
 
 def oracle_step(sd, anchors, x, data, dt):
     """fwd (batch statistics) + region loss + backward of the oracle in dtype `dt`: (loss terms, parameter gradients)."""
-    sdx = {k: (v.to(dt).requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+    # (detach + clone: `.to(float32)` of an fp32 tensor is the tensor itself - requires_grad_ would mark the caller's state dict)
+    sdx = {k: (v.detach().clone().to(dt).requires_grad_('running' not in k) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     f = odark.forward(x.to(dt), sdx, training=True)
     lo, _ = oloss.loss(anchors.to(dt), {k: (v.to(dt) if v.is_floating_point() else v) for k, v in data.items()}, ohead.decode(f, anchors.to(dt)), 0.6)
     oloss.total(lo).backward()
@@ -80,21 +81,33 @@ def test_batch64_replayed_training_step_equals_the_oracle():
     assert sum(1 for v in seen.values() for _, _, m in v if m == 'replay') >= 6
     for p in dnn.parameters():
         assert torch.isfinite(p.grad).all()
+    # the captured step derives only the GEMM-operand forms its layers' chosen algorithms read (one of {packed, Winograd} per pass and layer)
+    plan = next(iter(runner.plans.values()))
+    assert plan.only is not None, 'the pruned capture fell back to preparing every operand form'
+    per_layer = {}
+    for mod, tag in plan.only:
+        per_layer.setdefault(mod, set()).add(tag)
+    assert len(per_layer) == 22 and all(len(v & {'wp', 'uf'}) == 1 and len(v & {'wd', 'ud'}) == 1 for v in per_layer.values()), sorted(map(sorted, per_layer.values()))
+    print('operand forms prepared per step: %s' % {t: sum(1 for _, tag in plan.only if tag == t) for t in ('wp', 'uf', 'wd', 'ud')})
     # ---- replays of the same batch agree with each other (what differs: completion-order atomics of split reductions and BatchNorm sums)
     for b, rows in seen.items():
         for lo, gr, _ in rows[1:]:
             for k in lo:
                 np.testing.assert_allclose(lo[k], rows[0][0][k], rtol=2e-5, err_msg='batch %d loss %s between replays' % (b, k))
     # ---- against the oracle
-    torch.set_num_threads(max(1, min(128, os.cpu_count() or 1)))
+    torch.set_num_threads(max(1, min(96, os.cpu_count() or 1)))
     worst = 0.0
     for b in (0, 1):
         x, nd = host[b]
         t0 = time.time()
         l64, g64 = oracle_step(sd, anchors, x, nd, torch.float64)
         t1 = time.time()
-        l32, g32 = oracle_step(sd, anchors, x, nd, torch.float32)
-        print('oracle batch-%d step: fp64 %.1f s, fp32 %.1f s' % (B, t1 - t0, time.time() - t1))
+        if b == 0:
+            # the fp32 floor is a property of the arithmetic at this shape (the same network, batch size and label statistics): measured on
+            # the first batch, applied to both (one oracle pass less: the fp64 passes are 40 s each on the GPU box's host)
+            l32, g32 = oracle_step(sd, anchors, x, nd, torch.float32)
+            floors = {k: rms_rel(g32[k], g64[k]) for k in g64}
+        print('oracle batch-%d step: fp64 %.1f s%s' % (B, t1 - t0, ', fp32 %.1f s' % (time.time() - t1) if b == 0 else ''))
         lo, gr, mode = seen[b][-1]
         assert mode == 'replay'
         assert set(lo) == set(l64) and len(lo) == 5
@@ -103,7 +116,7 @@ def test_batch64_replayed_training_step_equals_the_oracle():
         assert set(gr) == set(g64)
         rows = []
         for k in g64:
-            floor = rms_rel(g32[k], g64[k])
+            floor = floors[k]
             e = rms_rel(gr[k], g64[k])
             rows.append((e / max(1e-4 / 2.5, floor), k, e, floor))
             # the other replays of this batch are the same step: hold them to the same bound

@@ -474,3 +474,39 @@ def test_a_parameter_frozen_after_the_first_steps_drops_the_plans():
     assert len(runner.plans) == 0                      # no plan holds the stale parameter list
     assert frozen.grad is None and torch.equal(frozen.detach(), before)
     assert other.grad is not None and not torch.equal(other.detach(), moved)
+
+
+def test_capture_falls_back_to_all_operand_forms_when_the_pruned_set_is_short():
+    """A captured step prepares only the operand forms its last eager pass read (train_graph._train_operands(only=...)).  If the algorithm
+    table asks for another form under capture, the capture is repeated with all of them - never a wrong or missing operand."""
+    import train as y2train
+    import utils
+    from model import train_graph
+    sd = odark.init_state_dict(5, 20, seed=0, channels={k: max(v, 32) for k, v in dict(NARROW, **{'layers1.5': 32}).items()}, head_scale=1 / 8.0)     # >= 32 channels: Winograd-eligible layers
+    data = batches(96, 2)
+    outs = {}
+    for mode in ('pruned', 'short', 'off'):
+        inf, anchors = build('darknet', sd={k: v.clone() for k, v in sd.items()})
+        opt = utils.optim.SGD(inf.parameters(), 0.0)
+        train_graph.PRUNE_OPERANDS = mode != 'off'
+        try:
+            for i in range(3):
+                y2train.iterate(inf, opt, data[i % 3], oloss.HPARAM, 0.6, anchors)
+            runner = inf.__dict__['_y2_step_runner']
+            plan = next(iter(runner.plans.values()))
+            assert plan.ops is None and plan.used_last
+            if mode == 'short':
+                keep = sorted(plan.used_last, key=lambda e: (str(id(e[0])), e[1]))[:1]
+                plan.used_last = set(keep)                       # the capture will ask for operands outside this set
+            for i in range(3, 6):
+                r = y2train.iterate(inf, opt, data[i % 3], oloss.HPARAM, 0.6, anchors)
+            torch.cuda.synchronize()
+            assert runner.captures == 1 and not runner.broken and plan.capture_error is None
+            assert (plan.only is not None) == (mode == 'pruned'), (mode, plan.only)
+            outs[mode] = ([float(r['loss'][k].detach()) for k in r['loss']], {k: p.grad.detach().clone() for k, p in inf.dnn.named_parameters()})
+        finally:
+            train_graph.PRUNE_OPERANDS = True
+    for mode in ('short', 'off'):
+        np.testing.assert_allclose(outs[mode][0], outs['pruned'][0], rtol=2e-5)
+        for k in outs['pruned'][1]:
+            assert rel(outs[mode][1][k], outs['pruned'][1][k]) <= 1e-3, (mode, k)

@@ -109,7 +109,7 @@ def test_step_runner_keeps_one_plan_per_shape_and_degrades_per_shape(monkeypatch
     class FakePlan(object):
         WARM = 3
 
-        def __init__(self, inference, anchors, hparam, threshold, dp=None, pool=None):
+        def __init__(self, inference, anchors, hparam, threshold, dp=None, pool=None, shared=None):
             self.ops, self.capture_error, self.calls, self.static, self.params, self.last_grads = None, None, 0, None, [], {}
             self.fail = None
             made.append(self)

@@ -1,16 +1,21 @@
 #!/bin/bash
-# round-5 GPU call 1: new parity tests, the driver's bench command, batch-1 split-K probe
+# round-5 GPU call: parity tests of the benchmarked path, operand-pruning A/B, batch-1 probe
 cd "$(dirname "$0")/.." || exit 1
-O=gpurun_out/fa; mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_b64.py "tests/test_gpu_plan.py::test_full_width_replays_equal_the_autograd_step" "tests/test_gpu_plan.py::test_a_parameter_frozen_after_the_first_steps_drops_the_plans" -x -q -s > $O/tests.log 2>&1
+O=gpurun_out/fb; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_b64.py tests/test_gpu_plan.py -x -q -s > $O/tests.log 2>&1
 echo "tests rc=$?" >> $O/tests.log
-tail -30 $O/tests.log
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_stdout.log 2> $O/bench_stderr.log
-echo "bench rc=$? line bytes: $(tail -1 $O/bench_stdout.log | wc -c)"
-cp gpurun_out/bench_full.json $O/bench_full.json 2>/dev/null
-tail -1 $O/bench_stdout.log
-tail -5 $O/bench_stderr.log
-for s in 256 512 768 1024; do
-  Y2_SPLIT_SLOTS=$s timeout 200 python tools/latency_b1.py 1 2 >> $O/latency.log 2>> $O/latency.err
+grep -v "^WARNING\|amdgpu.ids" $O/tests.log | grep -i "passed\|failed\|error\|worst\|oracle batch\|operand forms\|full-width\|rc=" | tail -30
+export Y2_TUNE_CACHE=/tmp/y2_tune_ab.json
+timeout 300 python tools/train_steady.py 6 > /dev/null 2>&1
+for rep in 1 2; do
+  for pr in 1 0; do
+    echo -n "prune=$pr: " >> $O/train_ab.log; Y2_PRUNE_OPERANDS=$pr timeout 300 python tools/train_steady.py 40 2>/dev/null | tail -1 >> $O/train_ab.log
+  done
 done
-cat $O/latency.log | cut -c1-400
+cat $O/train_ab.log
+unset Y2_TUNE_CACHE
+for cfg in "0 256" "400 256" "400 768" "1400 256"; do
+  set -- $cfg
+  Y2_SMALL_DIRECT=$1 Y2_SPLIT_SLOTS=$2 timeout 200 python tools/latency_b1.py 1 2 2>> $O/latency.err | sed "s/^/small_direct=$1 /" >> $O/latency.log
+done
+cut -c1-330 $O/latency.log

@@ -20,7 +20,7 @@ except Exception:
     KERNELS = None
 
 FAMILY = re.compile(r'conv_fwd_dma_kernel|conv_splitk_fixup_kernel|wino_(input|output|fused\d*|tile_table)_kernel|conv0_kernel|gemm_split_kernel|wino_input_split_kernel')
-TRAIN = len(sys.argv) > 2 and sys.argv[2] == 'train'       # every kernel of the training step; steps = loss_fwd_kernel dispatches
+TRAIN = 'train' in sys.argv[2:]       # every kernel of the training step; steps = loss_fwd_kernel dispatches
 if TRAIN:
     FAMILY = re.compile(r'.')
 rows = []
@@ -37,6 +37,17 @@ for k, c, n, v in rows:
         if c == 'FETCH_SIZE':
             launches += n
 fetch, write = tot['FETCH_SIZE'] / steps, tot['WRITE_SIZE'] / steps
+dominant = None
+by_grid = next((a for a in sys.argv[2:] if a.endswith('by_grid.txt')), None)
+if by_grid and os.path.exists(by_grid):
+    # the kernel with the largest total time in the kernel trace of the same command (tools/rocprof_summary.py by_grid): its average launch
+    # duration under the schedule the command times (detect: graph replays pipelined over two streams)
+    for line in open(by_grid):
+        m = re.match(r'(\S+)\s+(\d+)\s+(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$', line)
+        if m:
+            dominant = {'kernel': m.group(1), 'wgs': int(m.group(2)), 'calls': int(m.group(3)), 'avg_us': float(m.group(5)), 'share_percent': float(m.group(8)),
+                        'source': os.path.basename(by_grid)}
+            break
 print(json.dumps({
     'source': ('rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile_r4.sh) on `tools/train_steady.py` (autotune cache pre-populated): every kernel of the training step' if TRAIN else
                'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile_r4.sh) on `bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3 --no-split-leg --no-multiscale --no-latency --no-resnet` (autotune cache pre-populated); conv0 + conv_fwd_dma_kernel family + split-K fix-up + all Winograd kernels'),
@@ -44,5 +55,6 @@ print(json.dumps({
     'fetch_size_bytes_raw_per_step': fetch, 'write_size_bytes_raw_per_step': write,
     'correction': 'gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE uncorrected; counters are L2 memory-side requests, Infinity-Cache hits included',
     'traffic_bytes_per_step': 2 * fetch + write,
+    'dominant_trace': dominant,
     'kernels': KERNELS,          # hash of the kernel sources the profile was taken on: bench.py reports the figure only for the same sources
 }, indent=1))

@@ -345,6 +345,7 @@ class PlanCache(object):
 
 
 _TUNE = {}
+TUNE_MISSES = []          # keys measured in this process (not served by Y2_TUNE_CACHE / the committed default table)
 AUTOTUNE = os.environ.get('Y2_AUTOTUNE', '1') != '0'
 TUNE_CACHE = os.environ.get('Y2_TUNE_CACHE')      # optional JSON file persisting the measured tile choices across processes
 if TUNE_CACHE and os.path.exists(TUNE_CACHE):
@@ -472,6 +473,7 @@ FORCE_GRAD = os.environ.get('Y2_FORCE_GRAD_ALGO') or None
 FORCE_WGRAD = os.environ.get('Y2_FORCE_WGRAD') or None
 if FORCE_GRAD not in (None, 'f43', 'direct') or FORCE_WGRAD not in (None, 'direct', 'wino', 'f34'):
     raise ValueError('Y2_FORCE_GRAD_ALGO must be f43 or direct, Y2_FORCE_WGRAD direct, wino or f34')
+SMALL_DIRECT = int(os.environ.get('Y2_SMALL_DIRECT', '0'))      # > 0: 3x3 layers with at most this many output pixels (B*H*W) never take a Winograd form (experiment; see autotune_conv)
 PERSIST = os.environ.get('Y2_CONV_PERSIST', '1') != '0'      # 0: never offer the persistent-workgroup tiles (11 / 12 / 13 / 15) of the direct kernel (A/B runs)
 IMPLICIT = os.environ.get('Y2_WINO_IMPLICIT', '1') != '0'  # 0: never offer Y2_ALGO_WINOGRAD_IMPLICIT (A/B runs)
 WINO_MIN_CIN = 32                                        # below this the transforms cost more than the GEMM saves (measured; 32: the 208x208 layer, one K slab per tile of the fused kernels)
@@ -521,6 +523,11 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
     or a callable producing it (called only when that algorithm is timed or chosen)."""
     wino_ok = (wino_w is not None and WINOGRAD and params.ksize == 3 and params.stride in (0, 1) and params.pad_plus1 in (0, 2)
                and not params.transposed and not params.residual and params.out_mode == 0)
+    if wino_ok and SMALL_DIRECT and params.B * params.H * params.W <= SMALL_DIRECT and f43 is None:
+        # single images (detect.py:141-153): a layer with this few output pixels is bound by its FILTER bytes, and the Winograd filter
+        # operand is 16/9 of the direct one (all 13x13 layers: 318 MB against 179 MB - more than the 256 MB Infinity Cache holds across
+        # replays, so the isolated per-layer measurement, which runs hot, misjudges it)
+        wino_ok = False
     split_ok = bool(wino_ok and SPLIT and wino_split is not None and params.Cin % 32 == 0)
     key = (params.B, params.H, params.W, params.Cin, params.ldx, params.Cout, params.ksize, bool(params.y), bool(params.y_pool),
            bool(params.stats), params.out_mode, params.stride, params.pad_plus1, bool(params.residual), params.transposed, params.out_h, params.out_w, str(dev),
@@ -594,6 +601,7 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
         return apply((0, 0))
     L = lib()
     st = stream()
+    TUNE_MISSES.append(key)           # a problem shape neither this process nor the committed table has met: measured now (bench.py reports the count per leg)
     big = params.B * params.H * params.W >= 65536 and params.Cout >= 128 and params.ksize in (1, 3) and params.stride in (0, 1) \
         and params.pad_plus1 in (0, (params.ksize - 1) // 2 + 1) and not params.transposed and not params.residual
     cands = [(0, t) for t in [5, 3, 2, 1] + ([6] if params.Cout <= 32 else []) + ([8, 9] if big else [])]      # 8, 9: 512-thread 256x128 / 128x256 tiles
@@ -760,6 +768,7 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
                     t = min(t, e0.elapsed_time(e1))
                 times.append(t)
             choice = times.index(min(times))
+            TUNE_MISSES.append(key)
             _TUNE[key] = choice
             _tune_save()
             dwp.zero_()          # the timing launches of the direct kernel accumulated into dwp

@@ -79,13 +79,19 @@ def _new(dev, *shape, dtype=torch.float32):
     return torch.empty(*shape, dtype=dtype, device=dev)
 
 
+class OperandPruned(RuntimeError):
+    """A captured step prepares only the GEMM operands its warm-up passes used (StepPlan.used); the algorithm table asked for another one."""
+
+
 def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=None, slope=1.0, stats=None, y_pool=None, ldp=0, coff=0, out_mode=0, keep_v=False, u=False,
-          us=None, us_plane=0, grad=False):
+          us=None, us_plane=0, grad=False, note=None):
     """One y2_conv_fwd.  keep_v: when the Winograd algorithm is chosen, run it in a workspace of its own and return that tensor -
     its head is the transformed input V, which the weight gradient of the same layer reuses (y2_wino_wgrad v_transformed).
-    u: the layer's Winograd filter transform when the caller prepared it (y2_prep_weights), None = not eligible, False = derive it here."""
+    u: the layer's Winograd filter transform when the caller prepared it (y2_prep_weights), None = not eligible, False = derive it here.
+    wp may be None (an operand a captured step did not prepare): choosing an algorithm that reads it raises OperandPruned.
+    note: callable('w' | 'u') told which of the two filter operands the chosen algorithm reads."""
     p = _hip.ConvParams()
-    p.x, p.w = x.data_ptr(), wp.data_ptr()
+    p.x, p.w = x.data_ptr(), (wp.data_ptr() if wp is not None else None)
     p.scale = scale.data_ptr() if scale is not None else None
     p.shift = shift.data_ptr() if shift is not None else None
     p.y = y.data_ptr() if y is not None else None
@@ -101,8 +107,16 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
         u = None
     # us: bf16 plane triple of u (opt-in split-bf16 mode; planes us_plane elements apart), offered as Y2_ALGO_WINOGRAD_SPLIT
     # grad: the output is a data gradient - the deep layers may take the 4x4-tile Winograd form (its filter operand is built on demand)
-    f43 = (lambda: _hip.wino6_weight(wp, cout, cin)) if (grad and GRAD_F43 and u is not None and cin >= 128 and H * W <= 52 * 52) else None      # (offered; the measurement decides: 13x13 ... 26x26 at 416, 19x19 ... 38x38 at 608)
+    def f43_operand():
+        if wp is None:
+            raise OperandPruned('the 4x4-tile data-gradient operand is derived from a packed weight this step did not prepare')
+        return _hip.wino6_weight(wp, cout, cin)
+    f43 = f43_operand if (grad and GRAD_F43 and u is not None and cin >= 128 and H * W <= 52 * 52) else None      # (offered; the measurement decides: 13x13 ... 26x26 at 416, 19x19 ... 38x38 at 608)
     _hip.autotune_conv(p, x.device, wino_w=u, implicit_ok=not keep_v, wino_split=us if u is not None else None, split_plane=us_plane, f43=f43)
+    if p.algo in (0, 6) and wp is None:
+        raise OperandPruned('algorithm %d reads the packed weight, which this step did not prepare' % p.algo)
+    if note is not None:
+        note('w' if p.algo in (0, 6) else 'u')
     kept = None
     if keep_v and p.algo in (1, 2):
         T = B * ((H + 1) // 2) * ((W + 1) // 2)
@@ -122,7 +136,10 @@ class _Block(object):
                  'out_full', 'out_pool', 'out_ld', 'out_off', 'out_mode', 'has_bn', 'slope', 'first', 'wino_v', 'eff')
 
 
-def _train_operands(dnn, dev, scope=None):
+PRUNE_OPERANDS = os.environ.get('Y2_PRUNE_OPERANDS', '1') != '0'      # 0: a captured step derives all four operand forms of every layer (A/B)
+
+
+def _train_operands(dnn, dev, scope=None, only=None, alloc_only=False):
     """GEMM operands of every convolution block for one parameter version, produced by ONE y2_prep_weights launch from the
     state_dict layout: fprop pack, dgrad pack (rotated, in/out swapped) and, where the Winograd algorithm is eligible, both filter
     transforms.  The optimizer rewrites the weights every step, so this runs once per step (it used to be ~90 separate small
@@ -130,8 +147,14 @@ def _train_operands(dnn, dev, scope=None):
     (y2_conv0_fwd reads the state_dict layout) and blocks whose output width is not a multiple of 4 (the 125 / 425-channel head: its
     data gradient runs zero-padded) are left to the per-layer path.
     scope: the buffer dict of a StepPlan - the operands are derived unconditionally (the launch must be part of every replay of the plan's
-    graph) into buffers that plan owns; the per-model cache is neither read nor written."""
+    graph) into buffers that plan owns; the per-model cache is neither read nor written.
+    only: set of (block, 'wp' | 'wd' | 'uf' | 'ud') - derive just these (a StepPlan knows from its warm-up passes which operand each
+    layer's chosen algorithms read: typically ONE of the two forward forms and ONE of the two data-gradient forms, i.e. half of the
+    2.2 GB this launch moves per step); the others stay None.  alloc_only: make sure the buffers exist, launch nothing (a plan allocates
+    shared operand buffers before its capture begins, outside the graph's memory pool)."""
     from model import yolo2 as _yolo2
+    if _hip.split_mode() or scope is None:
+        only = None          # (the split modes derive their planes from the whole arena; the per-model cache serves the autograd path with everything)
     key = (dev, dnn._weight_versions(), _hip.split_mode(), _hip.WINOGRAD)       # the convolution weights only: the BatchNorm buffer updates of a forward pass do not move it
     if scope is not None:
         bufs = (dev, scope)
@@ -146,7 +169,7 @@ def _train_operands(dnn, dev, scope=None):
 
     def buf(tag, n):
         t = bufs[1].get(tag)
-        if t is None or t.numel() != n:
+        if t is None or t.numel() != n or t.device != dev:
             t = torch.empty(n, dtype=torch.float32, device=dev)
             bufs[1][tag] = t
         return t
@@ -163,22 +186,30 @@ def _train_operands(dnn, dev, scope=None):
         if cout % 4 or cin % 4 or not w.is_contiguous() or w.dtype != torch.float32:
             continue
         n = w.numel()
-        d = dict(wp=buf((name, 'wp'), n), wd=buf((name, 'wd'), n), uf=None, ud=None, ufs=None, uds=None, plane=0)
-        items.append((w, d['wp'], cout, cin, k, _hip.PREP_FPROP))
-        items.append((w, d['wd'], cout, cin, k, _hip.PREP_DGRAD))
-        if _hip.wino_eligible(cout, cin, k):
+        want = lambda tag: only is None or (blk, tag) in only
+        d = dict(name=name, wp=buf((name, 'wp'), n) if want('wp') else None, wd=buf((name, 'wd'), n) if want('wd') else None, uf=None, ud=None, ufs=None, uds=None, plane=0)
+        if d['wp'] is not None:
+            items.append((w, d['wp'], cout, cin, k, _hip.PREP_FPROP))
+        if d['wd'] is not None:
+            items.append((w, d['wd'], cout, cin, k, _hip.PREP_DGRAD))
+        if _hip.wino_eligible(cout, cin, k) and want('uf'):
             wino.append((d, 'uf', w, cout, cin, k, _hip.PREP_WINO_FPROP))
-        if _hip.wino_eligible(cin, cout, k):          # the data gradient is a convolution with the roles of Cin and Cout exchanged
+        if _hip.wino_eligible(cin, cout, k) and want('ud'):          # the data gradient is a convolution with the roles of Cin and Cout exchanged
             wino.append((d, 'ud', w, cout, cin, k, _hip.PREP_WINO_DGRAD))
         ops[blk] = d
     usize = sum(16 * cout * cin for _, _, _, cout, cin, _, _ in wino)
     if usize:
-        arena = buf('u_arena', usize)
+        if only is None:
+            arena = buf('u_arena', usize)
         off = 0
         for d, tag, w, cout, cin, k, mode in wino:
-            d[tag] = arena[off:off + 16 * cout * cin]
+            # (a pruned set: one buffer per operand instead of the arena - plans of different input sizes share them by name, and the
+            # split modes, which turn the whole arena into planes with one pass, never prune)
+            d[tag] = arena[off:off + 16 * cout * cin] if only is None else buf((d['name'], tag), 16 * cout * cin)
             items.append((w, d[tag], cout, cin, k, mode))
             off += 16 * cout * cin
+    if alloc_only:
+        return ops
     if items:
         table = (_hip.PrepItem * len(items))()
         for e, (src, dst, cout, cin, k, mode) in zip(table, items):
@@ -307,7 +338,8 @@ def _darknet_fwd(ctx, dnn, x, params, frozen, scope=None):
     dev = x.device
     b1, b2, b3 = dnn._blocks()
     eff = _effective(dnn, dev, frozen)
-    prepared = _train_operands(dnn, dev, scope) if not any(e.padded for e in eff.values()) else {}
+    used = ctx.used = set()          # (block, operand form) pairs this pass's chosen algorithms read: what a captured step has to prepare
+    prepared = _train_operands(dnn, dev, (getattr(ctx, 'ops_scope', None) or scope) if scope is not None else None, only=getattr(ctx, 'only', None)) if not any(e.padded for e in eff.values()) else {}
     det = _hip.ensure_deterministic(dev)      # fixed-order reductions: BN statistics by y2_colstats_det instead of epilogue atomics
     # one zero-filled arena for every layer's replicated BN-statistics accumulators (one launch instead of 22 fills)
     arena = None
@@ -351,7 +383,7 @@ def _darknet_fwd(ctx, dnn, x, params, frozen, scope=None):
                                       B, h, w, cin, cout, cout, 0, 1.0, st), 'y2_conv0_fwd')
         elif mod in prepared:
             blk.wino_v = _conv(L, st, xin, prepared[mod]['wp'], z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=keep_v(h, w, cin, ldx, cout, k), u=prepared[mod]['uf'],
-                               us=prepared[mod]['ufs'], us_plane=prepared[mod]['plane'])
+                               us=prepared[mod]['ufs'], us_plane=prepared[mod]['plane'], note=lambda kind, m=mod: used.add((m, 'wp' if kind == 'w' else 'uf')))
         else:
             wp = _new(dev, e.w.numel())
             _hip.check(L.y2_pack_weight(_hip.ptr(e.w), _hip.ptr(wp), cout, cin, k, 0, st), 'y2_pack_weight')
@@ -652,7 +684,8 @@ def _darknet_bwd(ctx, dout):
                 # (the fp16 split mode is for activations: its fixed operand scales assume O(1) values, and gradients are 1e-5 and smaller -
                 # their fp16 planes would be subnormal; data gradients stay on the fp32 / bf16-split algorithms)
                 dg_split = ready_ops['uds'] if _hip.split_mode() == 'bf16' else None
-                _conv(L, st, dz, ready_ops['wd'], dx, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'], us=dg_split, us_plane=ready_ops['plane'], grad=True)
+                _conv(L, st, dz, ready_ops['wd'], dx, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'], us=dg_split, us_plane=ready_ops['plane'], grad=True,
+                      note=lambda kind, m=blk.mod: ctx.used.add((m, 'wd' if kind == 'w' else 'ud')))
             else:
                 wsrc = e.w
                 if cop != cout:
@@ -1390,7 +1423,10 @@ class StepPlan(object):
     every later one replays.  Results are views of static buffers: valid until the next step."""
     WARM = 3
 
-    def __init__(self, inference, anchors, hparam, threshold, dp=None, pool=None):
+    def __init__(self, inference, anchors, hparam, threshold, dp=None, pool=None, shared=None):
+        """shared: a dict owned by the caller (train.StepRunner) for the prepared GEMM-operand buffers: plans replay strictly one after the
+        other and every replay rewrites the operands it reads at its head, so the plans of all input sizes can use ONE set of buffers
+        (ten multi-scale sizes would otherwise hold ten copies: ~1 GB each)."""
         import model
         from model import yolo2 as _yolo2
         self.inference, self.dnn, self.dp = inference, inference.dnn, dp
@@ -1400,6 +1436,9 @@ class StepPlan(object):
         self.buffers = [b for b in self.dnn.buffers()]
         self.pool = pool if pool is not None else torch.cuda.graph_pool_handle()       # all segments (and, shared by the runner, all shapes) allocate from one pool
         self.scope = {}
+        self.shared = shared if shared is not None else self.scope
+        self.used_last = None       # (block, operand form) pairs the last eager pass read: what the captured step prepares
+        self.only = None
         self.ops = None             # captured op list
         self.last_grads = {}
         self.capture_error = None   # what a failed capture raised (the plan then stays on eager launches)
@@ -1502,6 +1541,7 @@ class StepPlan(object):
             tape = state['tape'] = _Tape()
             tape.fork_ok = GRAPH_FORK
             if self.darknet:
+                tape.ops_scope, tape.only = (self.shared, self.only) if seg is not None else (None, None)
                 head = _darknet_fwd(tape, dnn, st['x'], self.params, False, scope=self.scope if seg is not None else None)
             else:
                 tape.scope = self.scope if seg is not None else None
@@ -1530,6 +1570,8 @@ class StepPlan(object):
         missing = [p for p in self.params if p.requires_grad and id(p) not in grads]
         if missing:
             raise RuntimeError('StepPlan: %d parameters received no gradient' % len(missing))
+        if self.darknet and seg is None:
+            self.used_last = set(getattr(tape, 'used', ()))
         pred = dict(feature=head.permute(0, 3, 1, 2), iou=iou, center_offset=co, size_norm=sn, yx_min=mn, yx_max=mx)
         if logits is not None:
             pred['logits'] = logits
@@ -1611,21 +1653,34 @@ class StepPlan(object):
         gc.disable()
         torch.cuda.synchronize()
         side.wait_stream(cur)
-        seg = _Segments(self.pool, 'capture')
-        grads = {}
+        # first with only the operand forms the last eager pass read (half of y2_prep_weights' traffic); should the algorithm table ask for
+        # another one under capture (a shape it never measured), once more with all of them
+        attempts = ([set(self.used_last)] if (PRUNE_OPERANDS and self.darknet and self.used_last and not _hip.split_mode()) else []) + [None]
         prev_scope = _hip.SCOPE
         try:
-            with torch.cuda.stream(side):
-                _hip.SCOPE = self.scope
-                try:
-                    seg.begin()
-                    self.result, _ = self._chain(seg, grads)
-                    seg.end()
-                except BaseException:
-                    seg.abort()
-                    raise
-                finally:
-                    _hip.SCOPE = prev_scope
+            for only in attempts:
+                self.only = only
+                if self.darknet and self.shared is not self.scope:
+                    # shared operand buffers are ordinary allocations made BEFORE the capture: they outlive this plan's graphs and pool
+                    _train_operands(self.dnn, self.static['x'].device, self.shared, only=only, alloc_only=True)
+                seg = _Segments(self.pool, 'capture')
+                grads = {}
+                with torch.cuda.stream(side):
+                    _hip.SCOPE = self.scope
+                    try:
+                        seg.begin()
+                        self.result, _ = self._chain(seg, grads)
+                        seg.end()
+                        break
+                    except OperandPruned:
+                        seg.abort()
+                        if only is None:
+                            raise
+                    except BaseException:
+                        seg.abort()
+                        raise
+                    finally:
+                        _hip.SCOPE = prev_scope
         finally:
             if gc_was_on:
                 gc.enable()

@@ -459,6 +459,7 @@ class StepRunner(object):
         self.plans = collections.OrderedDict()
         self.warm = {}
         self.pool = None
+        self.shared_ops = {}        # prepared GEMM-operand buffers, one set for the plans of all input shapes (they replay serially; each rewrites what it reads)
         self.broken = None          # a capture failed for a reason other than memory: no more captures (steps keep running as eager plans)
         self.eager_only = set()     # shapes whose capture failed
         self.captures = 0
@@ -533,7 +534,7 @@ class StepRunner(object):
             if self.pool is None or not any(p.ops is not None for p in self.plans.values()):
                 # (a pool lives as long as a graph captured into it: once the last one is gone its handle is dead - torch asserts on reuse)
                 self.pool = torch.cuda.graph_pool_handle()
-            plan = train_graph.StepPlan(self.inference, self.anchors, self.hparam, self.threshold, dp=self.dp, pool=self.pool)
+            plan = train_graph.StepPlan(self.inference, self.anchors, self.hparam, self.threshold, dp=self.dp, pool=self.pool, shared=self.shared_ops)
             plan._alloc(data, npad)
             plan.calls = self.warm.get(shape, 0)      # the per-layer measurements depend on the shape, not on the box count
             self.plans[key] = plan
