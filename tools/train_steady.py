@@ -11,6 +11,7 @@ import torch
 import bench_data, train as y2train, utils
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 3          # 3: what the rocprofv3 profiles use (Y2_TRAIN_GRAPH=0); 6 puts the capture of the step in front of the timed region
 dev = torch.device('cuda:0')
 inf, anchors = bench_data.build_model(20, dev, 'darknet')
 inf.train()
@@ -20,7 +21,7 @@ for i in range(2):
     d = {k: v.to(dev) for k, v in bench_data.labels(64, 416, 20, seed=2 + i).items()}
     d['tensor'] = bench_data.images(64, 416, seed=11 + i).to(dev)
     data.append(d)
-for i in range(3):
+for i in range(warm):
     y2train.iterate(inf, opt, data[i % 2], bench_data.HPARAM, bench_data.THRESHOLD, anchors)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -28,4 +29,8 @@ for i in range(steps):
     y2train.iterate(inf, opt, data[i % 2], bench_data.HPARAM, bench_data.THRESHOLD, anchors)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(json.dumps({'steps_total': steps + 3, 'steps_timed': steps, 'ms_per_step': round(dt / steps * 1e3, 3), 'images_per_sec': round(64 * steps / dt, 1)}))
+runner = inf.__dict__.get('_y2_step_runner')
+plan = next(iter(runner.plans.values())) if (runner is not None and runner.plans) else None
+info = {'captures': getattr(runner, 'captures', None), 'graph_ops': None if plan is None or plan.ops is None else len(plan.ops),
+        'operand_forms_prepared': None if plan is None or plan.only is None else len(plan.only), 'capture_error': None if plan is None or plan.capture_error is None else str(plan.capture_error)[:200]}
+print(json.dumps({'plan': info, 'steps_total': steps + warm, 'steps_timed': steps, 'ms_per_step': round(dt / steps * 1e3, 3), 'images_per_sec': round(64 * steps / dt, 1)}))
