@@ -429,7 +429,7 @@ def test_full_width_replays_equal_the_autograd_step():
         x = data[b]['tensor'].cpu()
         nd = synth.norm_data({k: v.cpu() for k, v in data[b].items() if k != 'tensor'}, 416, 416, 13, 13)
         for name, dt in (('fp64', torch.float64), ('fp32', torch.float32)):
-            sdx = {k: (v.to(dt).requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+            sdx = {k: (v.detach().clone().to(dt).requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}      # (clone: `.to(float32)` of an fp32 tensor is the tensor itself)
             f = odark.forward(x.to(dt), sdx, training=True)
             lo, _ = oloss.loss(anchors.to(dt), {k: (v.to(dt) if v.is_floating_point() else v) for k, v in nd.items()}, ohead.decode(f, anchors.to(dt)), 0.6)
             oloss.total(lo).backward()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-5 GPU call: operand-pruning A/B (steady state), parity tests of the benchmarked path
 cd "$(dirname "$0")/.." || exit 1
-O=gpurun_out/fc; mkdir -p $O
+O=gpurun_out/fd; mkdir -p $O
 export Y2_TUNE_CACHE=/tmp/y2_tune_ab.json
 timeout 300 python tools/train_steady.py 6 6 > /dev/null 2>&1
 for rep in 1 2; do

@@ -473,7 +473,6 @@ FORCE_GRAD = os.environ.get('Y2_FORCE_GRAD_ALGO') or None
 FORCE_WGRAD = os.environ.get('Y2_FORCE_WGRAD') or None
 if FORCE_GRAD not in (None, 'f43', 'direct') or FORCE_WGRAD not in (None, 'direct', 'wino', 'f34'):
     raise ValueError('Y2_FORCE_GRAD_ALGO must be f43 or direct, Y2_FORCE_WGRAD direct, wino or f34')
-SMALL_DIRECT = int(os.environ.get('Y2_SMALL_DIRECT', '0'))      # > 0: 3x3 layers with at most this many output pixels (B*H*W) never take a Winograd form (experiment; see autotune_conv)
 PERSIST = os.environ.get('Y2_CONV_PERSIST', '1') != '0'      # 0: never offer the persistent-workgroup tiles (11 / 12 / 13 / 15) of the direct kernel (A/B runs)
 IMPLICIT = os.environ.get('Y2_WINO_IMPLICIT', '1') != '0'  # 0: never offer Y2_ALGO_WINOGRAD_IMPLICIT (A/B runs)
 WINO_MIN_CIN = 32                                        # below this the transforms cost more than the GEMM saves (measured; 32: the 208x208 layer, one K slab per tile of the fused kernels)
@@ -511,7 +510,12 @@ def _time_conv(L, params, st):
     return t
 
 
-def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, split_plane=0, f43=None):
+class OperandMissing(RuntimeError):
+    """The chosen algorithm reads a filter operand the caller did not prepare (a captured training step derives only the forms its
+    warm-up passes used: model.train_graph)."""
+
+
+def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, split_plane=0, f43=None, wino_eligible=None):
     """Measure-don't-guess algorithm + tile selection for one y2_conv_fwd problem: the first time a problem shape is seen,
     every tile configuration of the direct kernel - and, when `wino_w` (y2_wino_weight output) is given, of the Winograd
     path - is timed (HIP events, best of 2 x 3 launches) and the fastest is cached for the process; later calls only
@@ -521,13 +525,10 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
     so the algorithm that never materialises it (3) is not offered.
     f43: the result is a GRADIENT and may take Winograd F(4x4,3x3) (Y2_ALGO_WINOGRAD_F43, 8-9e-6 x rms per layer): the y2_wino6_weight operand
     or a callable producing it (called only when that algorithm is timed or chosen)."""
-    wino_ok = (wino_w is not None and WINOGRAD and params.ksize == 3 and params.stride in (0, 1) and params.pad_plus1 in (0, 2)
-               and not params.transposed and not params.residual and params.out_mode == 0)
-    if wino_ok and SMALL_DIRECT and params.B * params.H * params.W <= SMALL_DIRECT and f43 is None:
-        # single images (detect.py:141-153): a layer with this few output pixels is bound by its FILTER bytes, and the Winograd filter
-        # operand is 16/9 of the direct one (all 13x13 layers: 318 MB against 179 MB - more than the 256 MB Infinity Cache holds across
-        # replays, so the isolated per-layer measurement, which runs hot, misjudges it)
-        wino_ok = False
+    # wino_eligible: the layer IS Winograd-eligible although `wino_w` is not at hand (None) - the problem keeps its identity (the key below),
+    # and an algorithm that reads the missing operand raises OperandMissing instead of being silently replaced by another one
+    wino_ok = (((wino_w is not None) if wino_eligible is None else bool(wino_eligible)) and WINOGRAD and params.ksize == 3 and params.stride in (0, 1)
+               and params.pad_plus1 in (0, 2) and not params.transposed and not params.residual and params.out_mode == 0)
     split_ok = bool(wino_ok and SPLIT and wino_split is not None and params.Cin % 32 == 0)
     key = (params.B, params.H, params.W, params.Cin, params.ldx, params.Cout, params.ksize, bool(params.y), bool(params.y_pool),
            bool(params.stats), params.out_mode, params.stride, params.pad_plus1, bool(params.residual), params.transposed, params.out_h, params.out_w, str(dev),
@@ -544,6 +545,8 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
 
     def apply(choice):
         algo, tile = choice
+        if algo in (1, 2, 3) and wino_w is None:
+            raise OperandMissing('algorithm %d reads the Winograd filter transform, which the caller did not prepare' % algo)
         params.algo, params.tile = algo, tile
         params.w = wino_split.data_ptr() if algo in (4, 5) else wino_w.data_ptr() if algo in (1, 2, 3) else f43_w().data_ptr() if algo == 6 else w_direct
         params.w_plane = split_plane if algo in (4, 5) else 0

@@ -79,16 +79,17 @@ def _new(dev, *shape, dtype=torch.float32):
     return torch.empty(*shape, dtype=dtype, device=dev)
 
 
-class OperandPruned(RuntimeError):
-    """A captured step prepares only the GEMM operands its warm-up passes used (StepPlan.used); the algorithm table asked for another one."""
+OperandPruned = _hip.OperandMissing      # a captured step prepares only the GEMM operands its warm-up passes used (StepPlan.used_last); the algorithm table asked for another one
 
 
 def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=None, slope=1.0, stats=None, y_pool=None, ldp=0, coff=0, out_mode=0, keep_v=False, u=False,
-          us=None, us_plane=0, grad=False, note=None):
+          us=None, us_plane=0, grad=False, note=None, u_eligible=None):
     """One y2_conv_fwd.  keep_v: when the Winograd algorithm is chosen, run it in a workspace of its own and return that tensor -
     its head is the transformed input V, which the weight gradient of the same layer reuses (y2_wino_wgrad v_transformed).
     u: the layer's Winograd filter transform when the caller prepared it (y2_prep_weights), None = not eligible, False = derive it here.
-    wp may be None (an operand a captured step did not prepare): choosing an algorithm that reads it raises OperandPruned.
+    wp may be None (an operand a captured step did not prepare): choosing an algorithm that reads it raises OperandPruned; likewise
+    u = None with u_eligible = True (the layer is Winograd-eligible, its transform was not prepared: the problem keeps its identity in the
+    algorithm table - same key, same offer of the 4x4-tile gradient form - and only a choice that READS u fails).
     note: callable('w' | 'u') told which of the two filter operands the chosen algorithm reads."""
     p = _hip.ConvParams()
     p.x, p.w = x.data_ptr(), (wp.data_ptr() if wp is not None else None)
@@ -111,8 +112,9 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
         if wp is None:
             raise OperandPruned('the 4x4-tile data-gradient operand is derived from a packed weight this step did not prepare')
         return _hip.wino6_weight(wp, cout, cin)
-    f43 = f43_operand if (grad and GRAD_F43 and u is not None and cin >= 128 and H * W <= 52 * 52) else None      # (offered; the measurement decides: 13x13 ... 26x26 at 416, 19x19 ... 38x38 at 608)
-    _hip.autotune_conv(p, x.device, wino_w=u, implicit_ok=not keep_v, wino_split=us if u is not None else None, split_plane=us_plane, f43=f43)
+    eligible = (u is not None) if u_eligible is None else (bool(u_eligible) and out_mode == 0)
+    f43 = f43_operand if (grad and GRAD_F43 and eligible and cin >= 128 and H * W <= 52 * 52) else None      # (offered; the measurement decides: 13x13 ... 26x26 at 416, 19x19 ... 38x38 at 608)
+    _hip.autotune_conv(p, x.device, wino_w=u, implicit_ok=not keep_v, wino_split=us if u is not None else None, split_plane=us_plane, f43=f43, wino_eligible=eligible)
     if p.algo in (0, 6) and wp is None:
         raise OperandPruned('algorithm %d reads the packed weight, which this step did not prepare' % p.algo)
     if note is not None:
@@ -187,7 +189,8 @@ def _train_operands(dnn, dev, scope=None, only=None, alloc_only=False):
             continue
         n = w.numel()
         want = lambda tag: only is None or (blk, tag) in only
-        d = dict(name=name, wp=buf((name, 'wp'), n) if want('wp') else None, wd=buf((name, 'wd'), n) if want('wd') else None, uf=None, ud=None, ufs=None, uds=None, plane=0)
+        d = dict(name=name, wp=buf((name, 'wp'), n) if want('wp') else None, wd=buf((name, 'wd'), n) if want('wd') else None, uf=None, ud=None, ufs=None, uds=None, plane=0,
+                 uf_ok=bool(_hip.wino_eligible(cout, cin, k)), ud_ok=bool(_hip.wino_eligible(cin, cout, k)))      # eligibility does not depend on what `only` leaves out
         if d['wp'] is not None:
             items.append((w, d['wp'], cout, cin, k, _hip.PREP_FPROP))
         if d['wd'] is not None:
@@ -383,7 +386,7 @@ def _darknet_fwd(ctx, dnn, x, params, frozen, scope=None):
                                       B, h, w, cin, cout, cout, 0, 1.0, st), 'y2_conv0_fwd')
         elif mod in prepared:
             blk.wino_v = _conv(L, st, xin, prepared[mod]['wp'], z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=keep_v(h, w, cin, ldx, cout, k), u=prepared[mod]['uf'],
-                               us=prepared[mod]['ufs'], us_plane=prepared[mod]['plane'], note=lambda kind, m=mod: used.add((m, 'wp' if kind == 'w' else 'uf')))
+                               us=prepared[mod]['ufs'], us_plane=prepared[mod]['plane'], note=lambda kind, m=mod: used.add((m, 'wp' if kind == 'w' else 'uf')), u_eligible=prepared[mod]['uf_ok'])
         else:
             wp = _new(dev, e.w.numel())
             _hip.check(L.y2_pack_weight(_hip.ptr(e.w), _hip.ptr(wp), cout, cin, k, 0, st), 'y2_pack_weight')
@@ -685,7 +688,7 @@ def _darknet_bwd(ctx, dout):
                 # their fp16 planes would be subnormal; data gradients stay on the fp32 / bf16-split algorithms)
                 dg_split = ready_ops['uds'] if _hip.split_mode() == 'bf16' else None
                 _conv(L, st, dz, ready_ops['wd'], dx, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'], us=dg_split, us_plane=ready_ops['plane'], grad=True,
-                      note=lambda kind, m=blk.mod: ctx.used.add((m, 'wd' if kind == 'w' else 'ud')))
+                      note=lambda kind, m=blk.mod: ctx.used.add((m, 'wd' if kind == 'w' else 'ud')), u_eligible=ready_ops['ud_ok'])
             else:
                 wsrc = e.w
                 if cop != cout:
