@@ -509,6 +509,43 @@ def conv3x3_leg(args, ctx):
     return out
 
 
+def contended_step_ms(ctx, step, k=8, reps=6, hold_ms=60.0):
+    """Rehearsal of the data-parallel step on ONE GPU (tools/contention.py): RCCL's all-reduce kernels hold CUs while backward
+    runs and the persistent fused Winograd kernels want whole CUs.  A background stream holds k workgroup slots (256 threads + 32 KB LDS
+    each, tools/probes/spin.hip) for the duration of a step; returns the median step time under that load beside the same measurement
+    with nothing held.  A PREDICTION for the first 8-GPU run to be checked against, not a measurement of it."""
+    import ctypes
+    path = os.path.join(ROOT, 'tools', 'probes', 'libspin.so')
+    if not os.path.exists(path):
+        return None
+    try:
+        import torch
+        spin = ctypes.CDLL(path)
+        spin.spin_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
+        side = torch.cuda.Stream()
+        res = {}
+        for held in (0, k):
+            ts = []
+            for i in range(reps):
+                ctx.sync()
+                if held and spin.spin_launch(held, 256, hold_ms, ctypes.c_void_p(side.cuda_stream)) != 0:
+                    return None
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                step(i)
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            ctx.sync()
+            res[held] = sorted(ts)[len(ts) // 2]
+        return {'ms_per_step_contended': round(res[k], 3), 'ms_per_step_uncontended_same_protocol': round(res[0], 3),
+                'contended_note': 'single GPU rehearsal: %d workgroup slots (256 threads, 32 KB LDS) held by a background kernel during the step (what RCCL channels look like to the '
+                                  'persistent kernels); a prediction for the data-parallel step, unmeasured on 8-GPU hardware' % k}
+    except Exception as e:
+        print('contention rehearsal skipped (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
+        return None
+
+
 # ---------------------------------------------------------------------------------------------------- train leg
 def train_leg(args, ctx):
     import torch
@@ -569,6 +606,10 @@ def train_leg(args, ctx):
     out.update({'images_per_sec': round(B * steps * ctx.world / dt, 2), 'ms_per_step': round(dt / steps * 1e3, 3), 'host_ms_per_step': round(host / steps * 1e3, 3),
                 'loss_total': float(last['r']['loss_total'].detach())})
     out['host_issue_ms_per_step'] = issue_time(ctx, step)
+    if ctx.world == 1:
+        c = contended_step_ms(ctx, step)
+        if c is not None:
+            out.update(c)
     runner = keep[0].__dict__.get('_y2_step_runner')
     out['launch'] = ('hipGraph replay of the captured step (%d graph segment(s)) + eager optimizer' % sum(1 for p in runner.plans.values() for op in (p.ops or []) if op[0] == 'graph')
                      if (runner is not None and runner.captures) else 'eager launches')

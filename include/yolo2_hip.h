@@ -58,11 +58,14 @@ int y2_pack_weight(const float* w, float* dst, int Cout, int Cin, int ksize, int
  * (a training step re-derives ~90 operands from the freshly updated weights; as separate launches they are launch-latency bound).
  * Modes: Y2_PREP_FPROP / Y2_PREP_DGRAD = y2_pack_weight modes 0 / 1;  Y2_PREP_WINO_FPROP / Y2_PREP_WINO_DGRAD = the Winograd
  * filter transform U[16][Cout][Cin] resp. U[16][Cin][Cout] (rotated, in/out swapped) of a 3x3 filter, bit-identical to
- * y2_pack_weight + y2_wino_weight.  dst sizes: Cout*Cin*k*k floats (packs), 16*Cout*Cin floats (transforms). */
+ * y2_pack_weight + y2_wino_weight;  Y2_PREP_WINO6_DGRAD = the F(4x4,3x3) data-gradient operand U6[36][Cin][Cout] (rotated, in/out
+ * swapped), bit-identical to y2_pack_weight(mode 1) + y2_wino6_weight.
+ * dst sizes: Cout*Cin*k*k floats (packs), 16*Cout*Cin floats (2x2-tile transforms), 36*Cout*Cin floats (4x4-tile transform). */
 #define Y2_PREP_FPROP 0
 #define Y2_PREP_DGRAD 1
 #define Y2_PREP_WINO_FPROP 2
 #define Y2_PREP_WINO_DGRAD 3
+#define Y2_PREP_WINO6_DGRAD 4
 #define Y2_PREP_MAX_ITEMS 96
 typedef struct {
     const float* src;

@@ -408,7 +408,8 @@ def test_multi_tensor_weight_preparation_equals_the_single_tensor_kernels(cout, 
             want[(name, mode)] = t
     want[('3', 2)] = _hip.wino_weight(want[('3', 0)], cout, cin)
     want[('3', 3)] = _hip.wino_weight(want[('3', 1)], cin, cout)
-    specs = [('3', 0, w3, 3, 1), ('3', 1, w3, 3, 1), ('1', 0, w1, 1, 1), ('1', 1, w1, 1, 1), ('3', 2, w3, 3, 16.0 / 9), ('3', 3, w3, 3, 16.0 / 9)]
+    want[('3', 4)] = _hip.wino6_weight(want[('3', 1)], cin, cout)          # F(4x4,3x3) operand of the data gradient (Y2_PREP_WINO6_DGRAD, round 5)
+    specs = [('3', 0, w3, 3, 1), ('3', 1, w3, 3, 1), ('1', 0, w1, 1, 1), ('1', 1, w1, 1, 1), ('3', 2, w3, 3, 16.0 / 9), ('3', 3, w3, 3, 16.0 / 9), ('3', 4, w3, 3, 4.0)]
     outs = [torch.full((int(round(w.numel() * f)),), float('nan'), device=d) for _, _, w, _, f in specs]
     table = (_hip.PrepItem * len(specs))()
     for i, (name, mode, w, k, f) in enumerate(specs):

@@ -46,7 +46,7 @@ class PrepItem(ctypes.Structure):
     _fields_ = [('src', c_void_p), ('dst', c_void_p), ('Cout', ctypes.c_int32), ('Cin', ctypes.c_int32), ('ksize', ctypes.c_int32), ('mode', ctypes.c_int32)]
 
 
-PREP_FPROP, PREP_DGRAD, PREP_WINO_FPROP, PREP_WINO_DGRAD = 0, 1, 2, 3
+PREP_FPROP, PREP_DGRAD, PREP_WINO_FPROP, PREP_WINO_DGRAD, PREP_WINO6_DGRAD = 0, 1, 2, 3, 4
 
 
 class MultiItem(ctypes.Structure):

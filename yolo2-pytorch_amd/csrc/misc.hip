@@ -77,9 +77,58 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepTable tb) {
     // Winograd F(2x2,3x3) filter transform straight from the state_dict layout: U[p][n][k] = (G g G^T)[p].
     //   WINO_FPROP: n = co, k = ci, g[t] = w[co][ci][t];   WINO_DGRAD: n = ci, k = co, g[t] = w[co][ci][8 - t] (rotated, in/out swapped)
     // Same arithmetic as wino_weight_kernel on the packed operand: bit-identical U.
-    const bool dg = q.mode == Y2_PREP_WINO_DGRAD;
+    const bool dg = q.mode == Y2_PREP_WINO_DGRAD || q.mode == Y2_PREP_WINO6_DGRAD;
     const int N = dg ? Cin : Cout, K = dg ? Cout : Cin;
     const long long total = (long long)N * K;
+    if (q.mode == Y2_PREP_WINO6_DGRAD) {
+        // F(4x4,3x3) filter operand of the data gradient, U6[p][n = ci][k = co] = (G6 g G6^T)[p] with g[t] = w[co][ci][8 - t]: the same
+        // staging as the 2x2-tile item below, the arithmetic of wino6_weight_kernel (csrc/wino.hip) in its order: bit-identical to
+        // y2_pack_weight(mode 1) + y2_wino6_weight, without the packed intermediate and without a launch per layer.
+        constexpr float GM[6][3] = {{1.f, 0.f, 0.f}, {-1.f / 3, -1.f / 3, -1.f / 3}, {1.f / 3, -1.f / 3, 1.f / 3},
+                                    {1.f / 15, 2.f / 15, 4.f / 15}, {-16.f / 15, 8.f / 15, -4.f / 15}, {0.f, 0.f, 1.f}};
+        __shared__ float tile6[32][73];
+        const int t = threadIdx.x;
+        const int tiles_k = (Cout + 31) / 32, tiles_n = (Cin + 7) / 8;
+        for (int tl = blk; tl < tiles_k * tiles_n; tl += nblk) {
+            const int c0 = (tl % tiles_k) * 32, n0 = (tl / tiles_k) * 8;
+            const int nn = min(8, Cin - n0);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int e = t + 256 * j, row = e / 72, col = e % 72;
+                if (c0 + row < Cout && col < nn * 9) tile6[row][col] = w[((long long)(c0 + row) * Cin + n0) * 9 + col];
+            }
+            __syncthreads();
+            const int k = c0 + (t & 31), n = n0 + (t >> 5);
+            if (k >= Cout || n >= Cin) continue;
+            float g[3][3];
+#pragma unroll
+            for (int x = 0; x < 9; ++x) g[x / 3][x % 3] = tile6[t & 31][(t >> 5) * 9 + 8 - x];
+            float sm[6][3];
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (GM[a][i] != 0.f) v += GM[a][i] * g[i][j];
+                    sm[a][j] = v;
+                }
+            float* d = dst + (long long)n * K + k;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (GM[b][j] != 0.f) v += GM[b][j] * sm[a][j];
+                    d[(long long)(6 * a + b) * total] = v;
+                }
+        }
+        return;
+    }
     if (dg) {
         // the data-gradient operand is the transpose (n = ci, k = co): with one thread per (ci, co) pair and co fastest the stores are
         // coalesced, but every lane's 36-byte load sits Cin * 36 bytes from its neighbour's (28 % of every line used; this item type was
@@ -307,8 +356,8 @@ extern "C" int y2_prep_weights(const y2_prep_item* items, int32_t count, y2_stre
         int blocks = 0;
         for (int i = 0; i < tb.count; ++i) {
             const y2_prep_item& q = items[lo + i];
-            if (q.src == nullptr || q.dst == nullptr || q.Cout <= 0 || q.Cin <= 0 || q.ksize <= 0 || q.mode < Y2_PREP_FPROP || q.mode > Y2_PREP_WINO_DGRAD) return Y2_EINVAL;
-            if ((q.mode == Y2_PREP_WINO_FPROP || q.mode == Y2_PREP_WINO_DGRAD) && q.ksize != 3) return Y2_ENOSUP;
+            if (q.src == nullptr || q.dst == nullptr || q.Cout <= 0 || q.Cin <= 0 || q.ksize <= 0 || q.mode < Y2_PREP_FPROP || q.mode > Y2_PREP_WINO6_DGRAD) return Y2_EINVAL;
+            if ((q.mode == Y2_PREP_WINO_FPROP || q.mode == Y2_PREP_WINO_DGRAD || q.mode == Y2_PREP_WINO6_DGRAD) && q.ksize != 3) return Y2_ENOSUP;
             const long long n = (long long)q.Cout * q.Cin;          // one thread per (co, ci) pair in every mode
             long long nb = (n + 511) / 512;            // ~2 pairs per thread
             if (nb < 1) nb = 1;

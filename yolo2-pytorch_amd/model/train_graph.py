@@ -83,14 +83,15 @@ OperandPruned = _hip.OperandMissing      # a captured step prepares only the GEM
 
 
 def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=None, slope=1.0, stats=None, y_pool=None, ldp=0, coff=0, out_mode=0, keep_v=False, u=False,
-          us=None, us_plane=0, grad=False, note=None, u_eligible=None):
+          us=None, us_plane=0, grad=False, note=None, u_eligible=None, u6=None):
     """One y2_conv_fwd.  keep_v: when the Winograd algorithm is chosen, run it in a workspace of its own and return that tensor -
     its head is the transformed input V, which the weight gradient of the same layer reuses (y2_wino_wgrad v_transformed).
     u: the layer's Winograd filter transform when the caller prepared it (y2_prep_weights), None = not eligible, False = derive it here.
     wp may be None (an operand a captured step did not prepare): choosing an algorithm that reads it raises OperandPruned; likewise
     u = None with u_eligible = True (the layer is Winograd-eligible, its transform was not prepared: the problem keeps its identity in the
     algorithm table - same key, same offer of the 4x4-tile gradient form - and only a choice that READS u fails).
-    note: callable('w' | 'u') told which of the two filter operands the chosen algorithm reads."""
+    note: callable('w' | 'u' | '6') told which filter operand the chosen algorithm reads (packed, 2x2-tile transform, 4x4-tile transform).
+    u6: the 4x4-tile transform when the caller prepared it; else it is derived from wp when that algorithm is timed or chosen."""
     p = _hip.ConvParams()
     p.x, p.w = x.data_ptr(), (wp.data_ptr() if wp is not None else None)
     p.scale = scale.data_ptr() if scale is not None else None
@@ -109,16 +110,18 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
     # us: bf16 plane triple of u (opt-in split-bf16 mode; planes us_plane elements apart), offered as Y2_ALGO_WINOGRAD_SPLIT
     # grad: the output is a data gradient - the deep layers may take the 4x4-tile Winograd form (its filter operand is built on demand)
     def f43_operand():
+        if u6 is not None:
+            return u6          # prepared with the step's other operands (y2_prep_weights, Y2_PREP_WINO6_DGRAD)
         if wp is None:
             raise OperandPruned('the 4x4-tile data-gradient operand is derived from a packed weight this step did not prepare')
         return _hip.wino6_weight(wp, cout, cin)
     eligible = (u is not None) if u_eligible is None else (bool(u_eligible) and out_mode == 0)
     f43 = f43_operand if (grad and GRAD_F43 and eligible and cin >= 128 and H * W <= 52 * 52) else None      # (offered; the measurement decides: 13x13 ... 26x26 at 416, 19x19 ... 38x38 at 608)
     _hip.autotune_conv(p, x.device, wino_w=u, implicit_ok=not keep_v, wino_split=us if u is not None else None, split_plane=us_plane, f43=f43, wino_eligible=eligible)
-    if p.algo in (0, 6) and wp is None:
+    if wp is None and (p.algo == 0 or (p.algo == 6 and u6 is None)):
         raise OperandPruned('algorithm %d reads the packed weight, which this step did not prepare' % p.algo)
     if note is not None:
-        note('w' if p.algo in (0, 6) else 'u')
+        note('w' if p.algo == 0 else '6' if p.algo == 6 else 'u')
     kept = None
     if keep_v and p.algo in (1, 2):
         T = B * ((H + 1) // 2) * ((W + 1) // 2)
@@ -150,7 +153,8 @@ def _train_operands(dnn, dev, scope=None, only=None, alloc_only=False):
     data gradient runs zero-padded) are left to the per-layer path.
     scope: the buffer dict of a StepPlan - the operands are derived unconditionally (the launch must be part of every replay of the plan's
     graph) into buffers that plan owns; the per-model cache is neither read nor written.
-    only: set of (block, 'wp' | 'wd' | 'uf' | 'ud') - derive just these (a StepPlan knows from its warm-up passes which operand each
+    only: set of (block, 'wp' | 'wd' | 'uf' | 'ud' | 'u6d') - derive just these ('u6d': the 4x4-tile data-gradient operand, prepared here
+    only on request: the eager passes derive it on demand from 'wd') (a StepPlan knows from its warm-up passes which operand each
     layer's chosen algorithms read: typically ONE of the two forward forms and ONE of the two data-gradient forms, i.e. half of the
     2.2 GB this launch moves per step); the others stay None.  alloc_only: make sure the buffers exist, launch nothing (a plan allocates
     shared operand buffers before its capture begins, outside the graph's memory pool)."""
@@ -199,6 +203,10 @@ def _train_operands(dnn, dev, scope=None, only=None, alloc_only=False):
             wino.append((d, 'uf', w, cout, cin, k, _hip.PREP_WINO_FPROP))
         if _hip.wino_eligible(cin, cout, k) and want('ud'):          # the data gradient is a convolution with the roles of Cin and Cout exchanged
             wino.append((d, 'ud', w, cout, cin, k, _hip.PREP_WINO_DGRAD))
+        d['u6d'] = None
+        if only is not None and (blk, 'u6d') in only and d['ud_ok']:
+            d['u6d'] = buf((name, 'u6d'), 36 * cout * cin)
+            items.append((w, d['u6d'], cout, cin, k, _hip.PREP_WINO6_DGRAD))
         ops[blk] = d
     usize = sum(16 * cout * cin for _, _, _, cout, cin, _, _ in wino)
     if usize:
@@ -386,7 +394,7 @@ def _darknet_fwd(ctx, dnn, x, params, frozen, scope=None):
                                       B, h, w, cin, cout, cout, 0, 1.0, st), 'y2_conv0_fwd')
         elif mod in prepared:
             blk.wino_v = _conv(L, st, xin, prepared[mod]['wp'], z, B, h, w, cin, ldx, cout, k, cout, stats=estats, keep_v=keep_v(h, w, cin, ldx, cout, k), u=prepared[mod]['uf'],
-                               us=prepared[mod]['ufs'], us_plane=prepared[mod]['plane'], note=lambda kind, m=mod: used.add((m, 'wp' if kind == 'w' else 'uf')), u_eligible=prepared[mod]['uf_ok'])
+                               us=prepared[mod]['ufs'], us_plane=prepared[mod]['plane'], note=lambda kind, m=mod: used.add((m, 'uf' if kind == 'u' else 'wp')), u_eligible=prepared[mod]['uf_ok'])
         else:
             wp = _new(dev, e.w.numel())
             _hip.check(L.y2_pack_weight(_hip.ptr(e.w), _hip.ptr(wp), cout, cin, k, 0, st), 'y2_pack_weight')
@@ -688,7 +696,7 @@ def _darknet_bwd(ctx, dout):
                 # their fp16 planes would be subnormal; data gradients stay on the fp32 / bf16-split algorithms)
                 dg_split = ready_ops['uds'] if _hip.split_mode() == 'bf16' else None
                 _conv(L, st, dz, ready_ops['wd'], dx, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'], us=dg_split, us_plane=ready_ops['plane'], grad=True,
-                      note=lambda kind, m=blk.mod: ctx.used.add((m, 'wd' if kind == 'w' else 'ud')), u_eligible=ready_ops['ud_ok'])
+                      note=lambda kind, m=blk.mod: ctx.used.add((m, 'wd' if kind == 'w' else 'u6d' if kind == '6' else 'ud')), u_eligible=ready_ops['ud_ok'], u6=ready_ops.get('u6d'))
             else:
                 wsrc = e.w
                 if cop != cout:
