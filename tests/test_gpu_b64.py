@@ -89,7 +89,7 @@ def test_batch64_replayed_training_step_equals_the_oracle():
         per_layer.setdefault(mod, set()).add(tag)
     assert len(per_layer) >= 21 and all(          # (every block but the first; the 125-channel head's data gradient runs zero-padded outside the prepared set)
         len(v & {'wp', 'uf'}) == 1 and len(v & {'wd', 'ud', 'u6d'}) == 1 for v in per_layer.values()), sorted(map(sorted, per_layer.values()))
-    print('operand forms prepared per step: %s' % {t: sum(1 for _, tag in plan.only if tag == t) for t in ('wp', 'uf', 'wd', 'ud')})
+    print('operand forms prepared per step: %s' % {t: sum(1 for _, tag in plan.only if tag == t) for t in ('wp', 'uf', 'wd', 'ud', 'u6d')})
     # ---- replays of the same batch agree with each other (what differs: completion-order atomics of split reductions and BatchNorm sums)
     for b, rows in seen.items():
         for lo, gr, _ in rows[1:]:
