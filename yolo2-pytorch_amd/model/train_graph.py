@@ -37,10 +37,13 @@ def _side_stream(dev):
 
 
 # A captured StepPlan may fork the weight gradients onto the side stream like the eager backward does (joined before every segment end).
-# Measured at batch 64: the step gains 0.75 ms of GPU time (31.8 -> 31.05 ms at 416x416, 19.8 -> 18.9 at 320x320) and hipGraphLaunch of the
-# multi-branch graph costs 11.2 / 6.8 ms of HOST time per step against 0.27 ms for the linear graph - with eight ranks on one host the
-# linear graph is the safe choice; 1 = fork (A/B runs).
-GRAPH_FORK = os.environ.get('Y2_GRAPH_FORK', '0') == '1'
+# Measured at batch 64: the step gains 0.75 ms of GPU time (31.8 -> 31.05 ms at 416x416, 19.8 -> 18.9 at 320x320).  The price is on the host:
+# the runtime issues a non-linear graph node by node and hipGraphLaunch returns only when most of the graph has EXECUTED (tools/probes/
+# graph_fork_cost.py: 270 small kernels, host time of a launch 0.16 ms linear, 0.84 ms = the graph's GPU time with one fork or with 22;
+# 11 ms of a 31 ms training step) - the issuing thread is blocked, not busy.  Y2_GRAPH_FORK: '1' fork, '0' never, 'auto' (default): fork in
+# single-process training (the host thread has nothing else to issue during a step), linear under the data-parallel wrapper, where the
+# same thread issues the RCCL collectives between graph segments and eight ranks share one host - unmeasured on 8-GPU hardware.
+GRAPH_FORK = {'1': True, '0': False}.get(os.environ.get('Y2_GRAPH_FORK', 'auto'), 'auto')
 GRAD_F43 = os.environ.get('Y2_GRAD_F43', '1') != '0'        # offer Winograd F(4x4,3x3) to the data gradients of the deep layers (A/B)
 FUSE_CONV0 = os.environ.get('Y2_FUSE_CONV0', '1') != '0'      # 0: materialise the first layer's dz and run the two-kernel form (A/B runs)
 DEBUG_TAP = None        # tools/debug: callable(block name, dz, dx) invoked per block of the Darknet backward
@@ -1550,7 +1553,7 @@ class StepPlan(object):
         dnn.grad_ready_hook, dnn.grad_buffer_hook = ready, dest
         try:
             tape = state['tape'] = _Tape()
-            tape.fork_ok = GRAPH_FORK
+            tape.fork_ok = (dp is None) if GRAPH_FORK == 'auto' else bool(GRAPH_FORK)
             if self.darknet:
                 tape.ops_scope, tape.only = (self.shared, self.only) if seg is not None else (None, None)
                 head = _darknet_fwd(tape, dnn, st['x'], self.params, False, scope=self.scope if seg is not None else None)
