@@ -1419,9 +1419,17 @@ class _Segments(object):
             self.ops.append(('graph', self.graph))
         self.graph = None
 
-    def abort(self):
+    def abort(self, fork=None):
+        """End a capture that failed half-way.  fork: the stream the backward forks weight gradients onto - when the failure came between a
+        fork and its join that stream is part of this capture, and a capture cannot end with an unjoined branch (it would stay in capture
+        mode and poison the next attempt): join it first."""
         if self.graph is not None:
             try:
+                if fork is not None:
+                    with torch.cuda.stream(fork):
+                        forked = torch.cuda.is_current_stream_capturing()
+                    if forked:
+                        torch.cuda.current_stream().wait_stream(fork)
                 self.graph.capture_end()
             except Exception:
                 pass
@@ -1687,11 +1695,11 @@ class StepPlan(object):
                         seg.end()
                         break
                     except OperandPruned:
-                        seg.abort()
+                        seg.abort(_side_stream(self.static['x'].device))
                         if only is None:
                             raise
                     except BaseException:
-                        seg.abort()
+                        seg.abort(_side_stream(self.static['x'].device))
                         raise
                     finally:
                         _hip.SCOPE = prev_scope
