@@ -1679,6 +1679,7 @@ class StepPlan(object):
         # another one under capture (a shape it never measured), once more with all of them
         attempts = ([set(self.used_last)] if (PRUNE_OPERANDS and self.darknet and self.used_last and not _hip.split_mode()) else []) + [None]
         prev_scope = _hip.SCOPE
+        aborted = []          # a pool handle dies with its last graph (torch asserts on reuse): the aborted attempt's graph lives until the next one exists
         try:
             for only in attempts:
                 self.only = only
@@ -1695,6 +1696,7 @@ class StepPlan(object):
                         seg.end()
                         break
                     except OperandPruned:
+                        aborted.append((seg, seg.graph))
                         seg.abort(_side_stream(self.static['x'].device))
                         if only is None:
                             raise
@@ -1708,6 +1710,7 @@ class StepPlan(object):
                 gc.enable()
         cur.wait_stream(side)
         self.ops, self.grads = seg.ops, grads
+        del aborted[:]
         self._held = seg.held
         self._baked = self._addresses()
 
