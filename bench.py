@@ -278,7 +278,7 @@ def static_traffic(tag):
         rel = os.path.relpath(files[-1], ROOT)
         if d.get('kernels') != _hip.kernel_hash():
             # a PMC profile of OTHER kernels says nothing about this build: no number rather than a stale one
-            return None, 'stale: %s was taken on kernel sources %s, this build is %s (regenerate with tools/gpu_profile_r4.sh)' % (rel, d.get('kernels'), _hip.kernel_hash())
+            return None, 'stale: %s was taken on kernel sources %s, this build is %s (regenerate with tools/gpu_profile_r5.sh)' % (rel, d.get('kernels'), _hip.kernel_hash())
         return d['traffic_bytes_per_step'], 'static: %s (same kernel sources %s)' % (rel, d.get('kernels'))
     except Exception:
         return None, None

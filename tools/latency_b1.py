@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Single-image detect latency (BASELINE configs[0] on the GPU, detect.py:141-153): the bench.py latency leg alone, with a FRESH per-layer
-measurement (Y2_TUNE_DEFAULTS=0 by default here) so that kernel-side knobs (Y2_SPLIT_SLOTS ...) are seen by the algorithm selection.
+measurement (Y2_TUNE_DEFAULTS=0 by default here) so that kernel-side experiments are seen by the algorithm selection.
 
-    Y2_SPLIT_SLOTS=768 python tools/latency_b1.py [batch ...]      # one JSON line per batch size"""
+    python tools/latency_b1.py [batch ...]      # one JSON line per batch size"""
 import json
 import os
 import sys
@@ -46,7 +46,7 @@ def main():
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 300 * 1e3
         rows = bench.top_kernels(table, 0.02)[0]
-        print(json.dumps({'batch': B, 'split_slots': os.environ.get('Y2_SPLIT_SLOTS'), 'ms_per_step': round(ms, 4), 'launches': round(sum(e['launches'] for e in table.values()), 1),
+        print(json.dumps({'batch': B, 'ms_per_step': round(ms, 4), 'launches': round(sum(e['launches'] for e in table.values()), 1),
                           'kernel_ms_sum_eager': round(sum(e['ms'] for e in table.values()), 4), 'algos': algos,
                           'top': [(r['kernel'], r['launches_per_step'], r['ms_per_step']) for r in rows]}))
         del g

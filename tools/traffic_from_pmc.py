@@ -49,8 +49,8 @@ if by_grid and os.path.exists(by_grid):
                         'source': os.path.basename(by_grid)}
             break
 print(json.dumps({
-    'source': ('rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile_r4.sh) on `tools/train_steady.py` (autotune cache pre-populated): every kernel of the training step' if TRAIN else
-               'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile_r4.sh) on `bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3 --no-split-leg --no-multiscale --no-latency --no-resnet` (autotune cache pre-populated); conv0 + conv_fwd_dma_kernel family + split-K fix-up + all Winograd kernels'),
+    'source': ('rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile_r5.sh) on `tools/train_steady.py` (autotune cache pre-populated): every kernel of the training step' if TRAIN else
+               'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile_r5.sh) on `bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3 --no-split-leg --no-multiscale --no-latency --no-resnet` (autotune cache pre-populated); conv0 + conv_fwd_dma_kernel family + split-K fix-up + all Winograd kernels'),
     'kernel_launches_profiled': launches, 'steps_profiled': steps,
     'fetch_size_bytes_raw_per_step': fetch, 'write_size_bytes_raw_per_step': write,
     'correction': 'gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE uncorrected; counters are L2 memory-side requests, Infinity-Cache hits included',

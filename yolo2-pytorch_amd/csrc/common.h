@@ -81,7 +81,6 @@ struct Y2ProfScope {
 
 constexpr int Y2_NUM_CU = 256;   // MI355X: 8 XCD x 32 CU
 constexpr int Y2_NUM_XCD = 8;
-constexpr int Y2_SMALL_SPLIT_SLOTS = 256;   // split-K slot target of launches smaller than one round (csrc/conv_fwd.hip: plan_split); Y2_SPLIT_SLOTS overrides
 
 // Bijective XCD-aware remap of a 1-D grid: hardware places block b on XCD b % 8, so give every XCD a
 // contiguous chunk of the logical tile list (neighbouring tiles share operand panels -> L2 hits).

@@ -882,24 +882,15 @@ int launch(const ConvArgs& a0, hipStream_t stream) {
 // Remainder split: T tiles on P CUs run floor(T/P) full rounds; the last T mod P tiles would occupy only part of the chip
 // for a whole tile time.  They are cut into s K-slices each (s chosen to minimise ceil(rem*s/P)/s) and a tiny fixup kernel
 // adds the slices.  Needs caller workspace; without it (or when nothing is gained) tiles run whole.
-// Launches smaller than ONE round (single images, batch <= 2: BASELINE configs[0], detect.py:141-153) are latency-bound, not slot-bound: with
-// one workgroup per CU a K loop waits a full HBM round trip per slab and nothing else is resident to cover it.  For those the slot count the
-// split aims at is `small_slots()` (several workgroups per CU, up to 32 K-slices), so that 3-4 slabs per CU are in flight.
-inline int small_slots() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("Y2_SPLIT_SLOTS"); v = (e != nullptr && atoi(e) >= Y2_NUM_CU) ? atoi(e) : Y2_SMALL_SPLIT_SLOTS; }
-    return v;
-}
-
 inline void plan_split(long long tiles, int nk, long long tile_elems, size_t ws_bytes, int& full_tiles, int& ksplit, int P = Y2_NUM_CU) {
     full_tiles = (int)tiles; ksplit = 1;
-    const bool small = tiles < P && small_slots() > P;
-    const int smax = small ? 32 : 16;
-    if (small) P = small_slots();
     const long long rem = tiles % P;
     if (rem == 0 || nk < 8) return;
     double best = 1.0; int bs = 1;
-    for (int s = 2; s <= smax && nk / s >= 4; ++s) {
+    // (round 5, measured and not kept: aiming the split of launches smaller than one round - single images - at 512 / 768 / 1024 slots with up
+    // to 32 K-slices, so that several workgroups per CU cover each other's HBM round trips: batch-1 detect 0.621 -> 0.621 / 0.621 / 0.623 ms,
+    // the same plan chosen; these launches are bound by the filter bytes they stream)
+    for (int s = 2; s <= 16 && nk / s >= 4; ++s) {
         const double t = (double)y2_cdiv(rem * s, P) / s * 1.02 + 0.01;   // small penalty for the extra prologue/epilogue + fixup
         if (t < best - 1e-9) { best = t; bs = s; }
     }
