@@ -39,7 +39,7 @@ def main():
         for B, S in shapes:
             x = bench_data.images(B, S, seed=1).to(dev)
             with torch.no_grad():
-                for _ in range(2):
+                for _ in range(3):
                     detect.detect_batch(inf.dnn.forward_nhwc(x), anchors, **kw)
             torch.cuda.synchronize()
 
@@ -49,10 +49,17 @@ def main():
         for B, S in shapes:
             d = {k: v.to(dev) for k, v in bench_data.labels(B, S, C, seed=2).items()}
             d['tensor'] = bench_data.images(B, S, seed=11).to(dev)
-            for _ in range(3):
+            # the choices of a shape settle over several steps (the weight gradient is measured in the first backward with the forward's transformed
+            # input at hand; where it then runs a form that does not read it the next forward is a NEW problem - no transformed input to keep -
+            # and so is that layer's next weight gradient): iterate until two consecutive steps measured nothing
+            quiet, steps = 0, 0
+            while quiet < 2 and steps < 10:
+                before = len(_hip.TUNE_MISSES)
                 y2train.iterate(inf, opt, d, bench_data.HPARAM, bench_data.THRESHOLD, anchors)
-            torch.cuda.synchronize()
-            print('  train B=%d S=%d C=%d: %d entries, %.0f s' % (B, S, C, len(_hip._TUNE), time.time() - t0), flush=True)
+                torch.cuda.synchronize()
+                steps += 1
+                quiet = quiet + 1 if len(_hip.TUNE_MISSES) == before else 0
+            print('  train B=%d S=%d C=%d: %d entries after %d steps, %.0f s' % (B, S, C, len(_hip._TUNE), steps, time.time() - t0), flush=True)
 
     for C in [int(v) for v in args.classes.split(',')]:
         inf, anchors = bench_data.build_model(C, dev, 'darknet')
