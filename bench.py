@@ -1008,6 +1008,9 @@ def compact_line(head, roof, extra, cb, tables_at=None, limit=LINE_LIMIT):
                 r[k] = r[k][:157] + '...'
         r.update({k: v for k, v in extra.items() if not isinstance(v, (dict, list))})
         out['roofline'] = r
+    else:
+        # N > 1: no per-kernel table is taken (the roofline and the CPU baseline are the N = 1 run's); the legs' scalars still belong in the line
+        out['summary'] = {k: v for k, v in extra.items() if not isinstance(v, (dict, list))}
     if cb is not None:
         keep = ('value', 'unit', 'cores', 'kind', 'sample', 'cpu_model', 'cpu_count', 'b1_ms_per_image', 'train_b8_images_per_sec', 'nms_n200_ms', 'error')
         c = {k: cb[k] for k in keep if k in cb}
@@ -1018,11 +1021,12 @@ def compact_line(head, roof, extra, cb, tables_at=None, limit=LINE_LIMIT):
         out['tables'] = tables_at
     line = json.dumps(out, separators=(',', ':'))
     drop = list(DROP_ORDER)
-    while len(line) > limit and 'roofline' in out:
-        k = drop.pop(0) if drop else next((k for k in reversed(list(out['roofline'])) if k not in ROOF_KEYS[:6]), None)
+    box = out.get('roofline', out.get('summary'))
+    while len(line) > limit and box:
+        k = drop.pop(0) if drop else next((k for k in reversed(list(box)) if k not in ROOF_KEYS[:6]), None)
         if k is None:
             break
-        out['roofline'].pop(k, None)
+        box.pop(k, None)
         line = json.dumps(out, separators=(',', ':'))
     return line
 
