@@ -770,6 +770,13 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
                     e1.synchronize()
                     t = min(t, e0.elapsed_time(e1))
                 times.append(t)
+            if v is not None and H * W >= 52 * 52 and len(times) > 1:
+                # The 2x2-tile reduction reads the forward's transformed input V: choosing it makes the FORWARD of this layer keep V, i.e. run
+                # the input-transform kernel (|x| read + 4|x| written at ~5.5 TB/s) in front of a V-reading algorithm instead of the implicit
+                # one the large maps otherwise take.  That cost belongs to this choice (round 5: on the 208x208 layer the reduction measured
+                # 0.93 ms against 0.98 ms for the direct kernel and made the forward 0.32 ms slower - the per-kernel comparison cannot see it;
+                # on the 104x104 layers it wins even so).  times are for two launches.
+                times[1] += 2.0 * 5.0 * B * H * W * cin * 4 / 5.5e9
             choice = times.index(min(times))
             TUNE_MISSES.append(key)
             _TUNE[key] = choice
