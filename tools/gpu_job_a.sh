@@ -1,6 +1,9 @@
 #!/bin/bash
+# same-box A/B of two algorithm tables (tools/probes/tune_old.json / tune_new.json as Y2_TUNE_CACHE, default table off)
 cd "$(dirname "$0")/.." || exit 1
-O=gpurun_out/fg; mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_plan.py -x -q -s -k "capture_falls or frozen or darknet_step_plan or dp_world2" > $O/tests.log 2>&1
-echo "tests rc=$?" >> $O/tests.log
-grep -v "^WARNING\|amdgpu.ids" $O/tests.log | grep -i "passed\|failed\|error\|rc=" | tail -30
+O=gpurun_out/fi; mkdir -p $O
+for rep in 1 2 3; do for t in old new; do
+  cp tools/probes/tune_$t.json /tmp/tc_$t.json
+  echo -n "$t: " >> $O/ab.log; Y2_TUNE_DEFAULTS=0 Y2_TUNE_CACHE=/tmp/tc_$t.json timeout 300 python tools/train_steady.py 40 8 2>/dev/null | tail -1 >> $O/ab.log
+done; done
+cat $O/ab.log | cut -c1-6,130-
