@@ -1733,7 +1733,7 @@ _CAPTURE_STREAMS = {}
 def _capture_stream(dev):
     s = _CAPTURE_STREAMS.get(str(dev))
     if s is None:
-        s = _CAPTURE_STREAMS[str(dev)] = torch.cuda.Stream(device=dev, priority=-1 if os.environ.get('Y2_CAPTURE_PRIO', '0') == '1' else 0)
+        s = _CAPTURE_STREAMS[str(dev)] = torch.cuda.Stream(device=dev)      # (round 5, measured: a HIGH-priority capture stream for the main chain, so that the forked weight gradients only fill gaps: 35.0 instead of 30.7 ms per step)
     return s
 
 
