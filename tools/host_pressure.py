@@ -4,7 +4,7 @@
 With one process per GPU the eight ranks of a node share its cores; what the GPU-bound single-rank run hides (the launch queue absorbs
 the host's lead) shows when a rank owns an eighth of the cores and seven other interpreters are busy beside it.  For each input size
 this tool runs the batch-64 training step (train.iterate: forward + region loss + backward + fused SGD) in its three launch modes -
-autograd (one ctypes launch per kernel under torch.autograd), plan (same launches, no autograd), graph (captured hipGraph replay) - in
+autograd (one ctypes launch per kernel under torch.autograd), plan (same launches, no autograd), graph (captured hipGraph replay, linear), graph+fork (weight gradients on a second branch) - in
 three host settings:
 
   free        all cores, nobody else
@@ -59,8 +59,10 @@ def main():
     for S in [int(v) for v in args.sizes.split(',')]:
         d = {k: v.to(dev) for k, v in bench_data.labels(args.batch, S, 20, seed=2).items()}
         d['tensor'] = bench_data.images(args.batch, S, seed=11).to(dev)
-        for mode, (plan, graph) in (('autograd', (False, False)), ('plan', (True, False)), ('graph', (True, True))):
-            y2train.PLAN, y2train.GRAPH = plan, graph
+        from model import train_graph
+        for mode, (plan, graph, fork) in (('autograd', (False, False, False)), ('plan', (True, False, False)), ('graph', (True, True, False)), ('graph+fork', (True, True, True))):
+            # graph = ONE linear hipGraph per step (what the data-parallel wrapper replays); graph+fork = the weight gradients on a second branch (single-process default, round 5)
+            y2train.PLAN, y2train.GRAPH, train_graph.GRAPH_FORK = plan, graph, fork
             inf, anchors = bench_data.build_model(20, dev, 'darknet')
             inf.train()
             opt = utils.optim.SGD(inf.parameters(), 1e-3, momentum=0.9)
@@ -110,6 +112,7 @@ def main():
             del inf, opt
             torch.cuda.empty_cache()
     y2train.PLAN = y2train.GRAPH = True
+    train_graph.GRAPH_FORK = 'auto'
 
 
 if __name__ == '__main__':
