@@ -44,7 +44,6 @@ def _side_stream(dev):
 # single-process training (the host thread has nothing else to issue during a step), linear under the data-parallel wrapper, where the
 # same thread issues the RCCL collectives between graph segments and eight ranks share one host - unmeasured on 8-GPU hardware.
 GRAPH_FORK = {'1': True, '0': False}.get(os.environ.get('Y2_GRAPH_FORK', 'auto'), 'auto')
-RESNET_BWD_FORK = os.environ.get('Y2_RESNET_BWD_FORK', '1') != '0'      # 0: the op-list backward (ResNets, Tiny) keeps its weight gradients on the main stream (A/B)
 GRAD_F43 = os.environ.get('Y2_GRAD_F43', '1') != '0'        # offer Winograd F(4x4,3x3) to the data gradients of the deep layers (A/B)
 FUSE_CONV0 = os.environ.get('Y2_FUSE_CONV0', '1') != '0'      # 0: materialise the first layer's dz and run the two-kernel form (A/B runs)
 DEBUG_TAP = None        # tools/debug: callable(block name, dz, dx) invoked per block of the Darknet backward
@@ -1281,25 +1280,6 @@ class ResNetTrainFn(torch.autograd.Function):
                 zero.append(e['dwp'])
         _hip.multi([(_hip.MULTI_ZERO, t, None) for t in zero], st)
         affine = []
-        # weight gradients off the critical path, like the Darknet backward: on a side stream behind an event (eager), on a forked branch of the
-        # graph (a StepPlan in single-process training); handed to autograd / the data-parallel hook one layer later
-        main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if (RESNET_BWD_FORK and BWD_STREAMS > 1 and not _hip.DETERMINISTIC and (not torch.cuda.is_current_stream_capturing() or getattr(ctx, 'fork_ok', False))) else None
-        late = []
-
-        def join():
-            for item in late:
-                if item[2] is not None:
-                    main.wait_event(item[2])
-                    item[2] = None
-        ctx.join = join
-
-        def flush_weight_grads(keep=0):
-            while len(late) > keep:
-                prm, g, evt = late.pop(0)
-                if evt is not None:
-                    main.wait_event(evt)
-                ready(prm, g)
         G = {id(ops[-1].y): [_hip.f32c(dout)]}      # gradient sources per activation tensor
         for op in reversed(ops):
             srcs = G.pop(id(op.y), [])
@@ -1332,33 +1312,17 @@ class ResNetTrainFn(torch.autograd.Function):
             elif op.conv.bias is not None:
                 affine.append((op.conv.bias, e['off'], cout))
             # ---- weight gradient
-            def weight_grad(st_w, op=op, e=e, dz=dz, cout=cout, cin=cin, k=k, cop=cop):
-                if e['wino']:
-                    dwp = _hip.conv_wgrad(op.x, dz, B, op.h, op.w, cin, cin, cop, cop, k)     # direct or Winograd, by measurement
-                else:
-                    dwp = e['dwp']
-                    _hip.check(L.y2_conv_wgrad_ex(_hip.ptr(op.x), _hip.ptr(dz), _hip.ptr(dwp), B, op.h, op.w, cin, cin, cop, cop, k, op.stride, op.pad, st_w), 'y2_conv_wgrad_ex')
-                if not e['wino'] and e['final']:
-                    return dwp.view(cout, cin, 1, 1)
-                dw = dest(op.conv.weight) if (cop == cout and cin == op.cin) else _new(dev, cop, cin, k, k)
-                _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cop, cin, k, st_w), 'y2_unpack_weight_grad')
-                return dw if (cop == cout and cin == op.cin) else dw[:cout, :op.cin].contiguous()
-            if side is not None:
-                ev = torch.cuda.Event()
-                ev.record(main)                           # dz (and the zero fill of the accumulation targets) is complete on the main stream
-                with torch.cuda.stream(side):
-                    side.wait_event(ev)
-                    gw = weight_grad(_hip.stream())
-                    for tns in (dz, op.x):                # read on the side stream: the allocator must not recycle them under it
-                        if tns is not None:
-                            tns.record_stream(side)
-                    done = torch.cuda.Event()
-                    done.record(side)
-                gw.record_stream(main)
-                flush_weight_grads(keep=1)
-                late.append([op.conv.weight, gw, done])
+            if e['wino']:
+                dwp = _hip.conv_wgrad(op.x, dz, B, op.h, op.w, cin, cin, cop, cop, k)     # direct or Winograd, by measurement
             else:
-                ready(op.conv.weight, weight_grad(st))
+                dwp = e['dwp']
+                _hip.check(L.y2_conv_wgrad_ex(_hip.ptr(op.x), _hip.ptr(dz), _hip.ptr(dwp), B, op.h, op.w, cin, cin, cop, cop, k, op.stride, op.pad, st), 'y2_conv_wgrad_ex')
+            if not e['wino'] and e['final']:
+                ready(op.conv.weight, dwp.view(cout, cin, 1, 1))
+            else:
+                dw = dest(op.conv.weight) if (cop == cout and cin == op.cin) else _new(dev, cop, cin, k, k)
+                _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw), cop, cin, k, st), 'y2_unpack_weight_grad')
+                ready(op.conv.weight, dw if (cop == cout and cin == op.cin) else dw[:cout, :op.cin].contiguous())
             op.z = None
             if op.first and not ctx.need_dx:
                 continue
@@ -1395,8 +1359,6 @@ class ResNetTrainFn(torch.autograd.Function):
         _hip.multi(items, st)
         for prm, t in handed:
             ready(prm, t)
-        flush_weight_grads()
-        ctx.join = None
         dx_img = None
         if ctx.need_dx:
             gx = G.pop(id(ctx.x4), None)
