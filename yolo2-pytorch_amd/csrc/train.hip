@@ -639,10 +639,8 @@ inline int act_grid(long long total, int Cg) {
     int g = 256, r = Cg;
     while (r) { const int t = g % r; g = r; r = t; }
     const int unit = Cg / g;
-    static int per_thread = 0, per_cu = 0;          // experiment knobs (A/B runs): items per thread the grid aims at, workgroups per CU it is capped at
-    if (per_thread == 0) { const char* e = getenv("Y2_ACT_ITEMS"); per_thread = (e && atoi(e) > 0) ? atoi(e) : 8; e = getenv("Y2_ACT_WG_PER_CU"); per_cu = (e && atoi(e) > 0) ? atoi(e) : 8; }
-    long long want = (total + 256LL * per_thread - 1) / (256LL * per_thread);
-    const long long cap = (long long)Y2_NUM_CU * per_cu;
+    long long want = (total + 256 * 8 - 1) / (256 * 8);
+    const long long cap = (long long)Y2_NUM_CU * 8;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     return (int)(((want + unit - 1) / unit) * unit);
