@@ -884,9 +884,6 @@ int launch(const ConvArgs& a0, hipStream_t stream) {
 // adds the slices.  Needs caller workspace; without it (or when nothing is gained) tiles run whole.
 inline void plan_split(long long tiles, int nk, long long tile_elems, size_t ws_bytes, int& full_tiles, int& ksplit, int P = Y2_NUM_CU) {
     full_tiles = (int)tiles; ksplit = 1;
-    static int split_on = -1;
-    if (split_on < 0) { const char* e = getenv("Y2_SPLITK"); split_on = (e != nullptr && atoi(e) == 0) ? 0 : 1; }
-    if (!split_on) return;
     const long long rem = tiles % P;
     if (rem == 0 || nk < 8) return;
     double best = 1.0; int bs = 1;
