@@ -1087,6 +1087,20 @@ def main():
             import traceback
             traceback.print_exc()
             tr = {'error': '%s: %s' % (type(e).__name__, e)}
+    # (the multi-scale leg runs BEFORE the latency / ResNet legs: its first-visit figures are capture + graph-pool growth, and growing the pool by tens of GB right after
+    #  another leg has handed ~100 GB back to the driver measured 0.6-0.9 s per size on some boxes, 11-35 ms on others - the driver reclaims freed memory lazily)
+    ms = None
+    if args.multiscale or (not args.no_multiscale and not args.no_train and args.model == 'darknet'):
+        ctx.sync()
+        time.sleep(args.settle)
+        try:
+            ms = multiscale_leg(args, ctx)
+        except Exception as e:
+            if args.multiscale:
+                raise
+            import traceback
+            traceback.print_exc()
+            ms = {'error': '%s: %s' % (type(e).__name__, e)}
     lat = rn = None
     if ctx.world == 1 and args.model == 'darknet' and not args.no_latency and not args.no_detect:
         try:
@@ -1103,18 +1117,6 @@ def main():
             import traceback
             traceback.print_exc()
             rn = {'error': '%s: %s' % (type(e).__name__, e)}
-    ms = None
-    if args.multiscale or (not args.no_multiscale and not args.no_train and args.model == 'darknet'):
-        ctx.sync()
-        time.sleep(args.settle)
-        try:
-            ms = multiscale_leg(args, ctx)
-        except Exception as e:
-            if args.multiscale:
-                raise
-            import traceback
-            traceback.print_exc()
-            ms = {'error': '%s: %s' % (type(e).__name__, e)}
     if ctx.rank == 0:
         ref = {'darknet': (' (BASELINE configs[1])', ' (BASELINE configs[2])')}.get(args.model, (' (plugin swap: forward of BASELINE configs[4])', ' (plugin swap, BASELINE configs[4] per GPU)') if args.model.startswith('resnet') else ('', ''))
         det_workload = '%s YOLOv2 %dx%d batch-%d/GPU inference: conv stack + decode + filter + NMS%s' % (label, args.size, args.size, args.batch, ref[0])
