@@ -186,6 +186,19 @@ class Ctx(object):
         return self.max_over_ranks(time.perf_counter() - t0), host
 
 
+KEEP_CACHED = [False]
+
+
+def release_memory():
+    """End of a leg: hand the allocator's cached blocks back to the driver - unless a multi-scale leg is still to come.  Its first-visit figures are
+    capture + growth of the graph pool by tens of GB per size, and on this driver an allocation that lands on memory the process freed moments ago
+    waits for the lazy reclaim (0.5-0.9 s per size measured at 544 ... 608 in runs where the preceding legs had released their memory; 11-35 ms in a
+    process that had not).  A training job never does that; the measurement should not either."""
+    import torch
+    if not KEEP_CACHED[0]:
+        torch.cuda.empty_cache()
+
+
 def kernel_table(fn, steps):
     """Run fn(i) `steps` times with the library's per-kernel event hooks on (include/yolo2_hip.h: y2_prof_*): every kernel launch
     is bracketed by a HIP event pair on its launch stream.  Returns {kernel: dict(launches, ms, flops)} per STEP (averages)."""
@@ -442,7 +455,7 @@ def detect_leg(args, ctx):
                     dnn._plan_cache = None
     state = {k: v.detach().cpu() for k, v in dnn.state_dict().items()} if (ctx.world == 1 and args.cpu_sample > 0 and args.model == 'darknet') else None
     del inf, dnn
-    torch.cuda.empty_cache()
+    release_memory()
     return out, roof, state, anchors
 
 
@@ -505,7 +518,7 @@ def conv3x3_leg(args, ctx):
             _hip.WINOGRAD = True
             dnn._plan_cache = None
     del inf, dnn
-    torch.cuda.empty_cache()
+    release_memory()
     return out
 
 
@@ -590,7 +603,7 @@ def train_leg(args, ctx):
         out['single_gpu_images_per_sec'] = round(single, 2)
         out['single_gpu_note'] = 'same step, no DP wrapper, all ranks running concurrently, MAX over ranks: per-GPU rate with zero communication'
         del step, last, keep
-        torch.cuda.empty_cache()
+        release_memory()
     step, last, keep = make(True)
     for i in range(5):          # untimed: autotune, allocator, and (N > 1) the wrapper's one-time adoption of rank 0's algorithm choices at its 4th call
         step(i)
@@ -635,7 +648,7 @@ def train_leg(args, ctx):
         if B == 64 and S == 416 and args.model == 'darknet' and args.classes == 20:
             out['roofline']['traffic'], out['roofline']['traffic_source'] = static_traffic('train_b64')
     del step, last, keep
-    torch.cuda.empty_cache()
+    release_memory()
     return out
 
 
@@ -1061,6 +1074,7 @@ def main():
         return
     assert ctx.gpu, 'bench.py needs an MI355X (use --dry-run to exercise the launch path without one)'
 
+    KEEP_CACHED[0] = ctx.world == 1 and (args.multiscale or (not args.no_multiscale and not args.no_train and args.model == 'darknet'))
     det = roof = state = anchors = None
     if args.multiscale:
         args.no_detect = args.no_train = args.no_conv3 = args.no_latency = args.no_resnet = True
@@ -1101,6 +1115,9 @@ def main():
             import traceback
             traceback.print_exc()
             ms = {'error': '%s: %s' % (type(e).__name__, e)}
+    KEEP_CACHED[0] = False
+    if ctx.gpu:
+        torch.cuda.empty_cache()
     lat = rn = None
     if ctx.world == 1 and args.model == 'darknet' and not args.no_latency and not args.no_detect:
         try:
