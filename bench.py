@@ -194,7 +194,10 @@ def release_memory():
     capture + growth of the graph pool by tens of GB per size, and on this driver an allocation that lands on memory the process freed moments ago
     waits for the lazy reclaim (0.5-0.9 s per size measured at 544 ... 608 in runs where the preceding legs had released their memory; 11-35 ms in a
     process that had not).  A training job never does that; the measurement should not either."""
+    import gc
+
     import torch
+    gc.collect()          # captured graphs sit in reference cycles (plan <-> tape <-> closures): their pools stay reserved until the collector has run
     if not KEEP_CACHED[0]:
         torch.cuda.empty_cache()
 
@@ -684,6 +687,7 @@ def multiscale_leg(args, ctx):
 
     import _hip
     first_visit, first_miss = {}, {}
+    reserved0 = torch.cuda.memory_reserved() / 2.0 ** 30 if ctx.gpu else None
     for S in sizes:                      # untimed: first visit of every size
         ctx.sync()
         miss0 = len(_hip.TUNE_MISSES)
@@ -728,6 +732,7 @@ def multiscale_leg(args, ctx):
            'per_gpu_batch': B, 'global_batch': B * ctx.world, 'loss_total': float(last['r']['loss_total'].detach()),
            'first_visit_shapes_measured': sum(first_miss.values()), 'first_visit_measured_keys': [list(map(str, k)) for k in _hip.TUNE_MISSES[-8:]] if sum(first_miss.values()) else [],
            'default_tune_table_entries': _hip._DEFAULTS_SEEN.get(str(ctx.dev)),
+           'reserved_gib_before_after': [None if reserved0 is None else round(reserved0, 1), round(torch.cuda.memory_reserved() / 2.0 ** 30, 1) if ctx.gpu else None],
            'parallelism': 'dp%d' % ctx.world if ctx.world > 1 else 'single GPU', 'per_size': table}
     if per_img is not None:
         out['direct_equiv_tflops_per_gpu'] = round(per_img * B * len(schedule) / dt / 1e12, 2)

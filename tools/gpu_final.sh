@@ -18,7 +18,7 @@ bench) echo "=== bench"; timeout 1500 python bench.py --tables gpurun_out/bench_
 driver) echo "=== driver command"; timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --tables gpurun_out/bench_r05_driver_full.json 2>/dev/null | tail -1 > gpurun_out/bench_r05_driver.json; echo "line bytes: $(wc -c < gpurun_out/bench_r05_driver.json)"
   python -c "
 import json; r = json.load(open('gpurun_out/bench_r05_driver.json'))['roofline']; print({k: r[k] for k in r if k.startswith(('multiscale', 'train_ms', 'train_images', 'detect_images', 'frac', 'traffic'))})
-f = json.load(open('gpurun_out/bench_r05_driver_full.json'))['multiscale']; print([(p['size'], p['first_visit_ms'], p['first_visit_shapes_measured']) for p in f['per_size']], f.get('first_visit_measured_keys'))";;
+f = json.load(open('gpurun_out/bench_r05_driver_full.json'))['multiscale']; print([(p['size'], p['first_visit_ms'], p['first_visit_shapes_measured']) for p in f['per_size']], f.get('first_visit_measured_keys'), f.get('reserved_gib_before_after'))";;
 profiles) echo "=== profiles"; bash tools/gpu_profile_r5.sh 2>&1 | tail -40
   for f in detect_b32_traffic.json train_b64_traffic.json; do cp gpurun_out/prof5/$f profiles/r05_$f; done;;      # a bench stage that follows reports this build's traffic
 contention) echo "=== contention"; timeout 600 python tools/contention.py 2>/dev/null | tee gpurun_out/r05_contention.txt | head -3;;
