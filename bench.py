@@ -186,16 +186,24 @@ class Ctx(object):
         return self.max_over_ranks(time.perf_counter() - t0), host
 
 
+KEEP_CACHED = [False]
+
+
 def release_memory():
     """End of a leg: collect (captured graphs sit in reference cycles - plan <-> tape <-> closures - and their pools stay reserved until the
-    collector has run), then hand the allocator's cached blocks back to the driver.  It matters for what the NEXT leg measures: with ~45 GiB of
-    earlier legs' pools still reserved the multi-scale leg crosses ~220 GiB at its largest sizes, and beyond that every growth of the graph pool
-    costs 0.4-0.9 s on this driver (first-visit figures of 11 ms became 860 ms; `reserved_gib_before_after` in the tables shows where a run stood)."""
+    collector has run) and, unless a multi-scale leg is still to come, hand the allocator's cached blocks back to the driver.
+    The multi-scale leg's first-visit figures are capture + growth of the graph pool by ~15 GB per size, and on this driver an allocation that lands
+    on memory the process released moments ago is slow (lazy reclaim).  Measured with the driver's command, per size 320 ... 608, 0 shapes measured in
+    every run: release before the leg: 350-890 ms at EVERY size; no release, no collect (round-5 default until the last day): 11-35 ms up to 480-544,
+    0.4-0.9 s above; no release + collect (shipped): 9-90 ms up to 576, 850 ms at 608 (the process then holds ~240 GiB, `reserved_gib_before_after`);
+    a process that runs ONLY this leg: 10-12 ms at every size after the first (200 ms: one-time initialisation).  A training job never releases
+    memory between steps; the last figure is the one that describes it."""
     import gc
 
     import torch
     gc.collect()
-    torch.cuda.empty_cache()
+    if not KEEP_CACHED[0]:
+        torch.cuda.empty_cache()
 
 
 def kernel_table(fn, steps):
@@ -735,7 +743,7 @@ def multiscale_leg(args, ctx):
     if ctx.world > 1:
         out['autotune_choices_synced'] = getattr(m, 'tune_synced', None)
     del m, inf, opt, data
-    release_memory()
+    torch.cuda.empty_cache()
     return out
 
 
@@ -800,7 +808,7 @@ def latency_leg(args, ctx):
                           'top_kernels': top_kernels(table, 0.03)[0]}
         del g
     del inf, dnn
-    release_memory()
+    torch.cuda.empty_cache()
     return out
 
 
@@ -865,7 +873,7 @@ def resnet_leg(args, ctx):
         roof = roofline_from(table, 'ResNet-50 608x608 COCO-80 training step, batch %d (same launch sequence issued eagerly under the event hooks)' % B)
         out['train']['roofline'] = roof
     del m, inf, dnn, opt
-    release_memory()
+    torch.cuda.empty_cache()
     return out
 
 # ---------------------------------------------------------------------------------------------------- CPU baseline
@@ -1075,6 +1083,7 @@ def main():
         return
     assert ctx.gpu, 'bench.py needs an MI355X (use --dry-run to exercise the launch path without one)'
 
+    KEEP_CACHED[0] = ctx.world == 1 and (args.multiscale or (not args.no_multiscale and not args.no_train and args.model == 'darknet'))
     det = roof = state = anchors = None
     if args.multiscale:
         args.no_detect = args.no_train = args.no_conv3 = args.no_latency = args.no_resnet = True
@@ -1101,8 +1110,8 @@ def main():
             import traceback
             traceback.print_exc()
             tr = {'error': '%s: %s' % (type(e).__name__, e)}
-    # (the multi-scale leg runs before the latency / ResNet legs and after release_memory() of the training leg: its first-visit figures are capture + graph-pool growth,
-    #  which turns slow once the process holds more than ~220 GiB)
+    # (the multi-scale leg runs BEFORE the latency / ResNet legs: its first-visit figures are capture + graph-pool growth, and growing the pool by tens of GB right after
+    #  another leg has handed ~100 GB back to the driver measured 0.6-0.9 s per size on some boxes, 11-35 ms on others - the driver reclaims freed memory lazily)
     ms = None
     if args.multiscale or (not args.no_multiscale and not args.no_train and args.model == 'darknet'):
         ctx.sync()
@@ -1115,6 +1124,9 @@ def main():
             import traceback
             traceback.print_exc()
             ms = {'error': '%s: %s' % (type(e).__name__, e)}
+    KEEP_CACHED[0] = False
+    if ctx.gpu:
+        torch.cuda.empty_cache()
     lat = rn = None
     if ctx.world == 1 and args.model == 'darknet' and not args.no_latency and not args.no_detect:
         try:
