@@ -186,23 +186,14 @@ class Ctx(object):
         return self.max_over_ranks(time.perf_counter() - t0), host
 
 
-KEEP_CACHED = [False]
-
-
 def release_memory():
     """End of a leg: collect (captured graphs sit in reference cycles - plan <-> tape <-> closures - and their pools stay reserved until the
-    collector has run) and, unless a multi-scale leg is still to come, hand the allocator's cached blocks back to the driver.
-    The multi-scale leg's first-visit figures are capture + growth of the graph pool by ~15 GB per size, and on this driver an allocation that lands
-    on memory the process released moments ago is slow (lazy reclaim).  Measured with the driver's command, per size 320 ... 608, 0 shapes measured in
-    every run: release before the leg: 350-890 ms at EVERY size; no release, no collect (round-5 default until the last day): 11-35 ms up to 480-544,
-    0.4-0.9 s above; no release + collect (shipped): 9-90 ms up to 576, 850 ms at 608 (the process then holds ~240 GiB, `reserved_gib_before_after`);
-    a process that runs ONLY this leg: 10-12 ms at every size after the first (200 ms: one-time initialisation).  A training job never releases
-    memory between steps; the last figure is the one that describes it."""
+    collector has run), then hand the allocator's cached blocks back to the driver."""
     import gc
 
     import torch
     gc.collect()
-    if not KEEP_CACHED[0]:
+    if torch.cuda.is_available():
         torch.cuda.empty_cache()
 
 
@@ -1083,11 +1074,26 @@ def main():
         return
     assert ctx.gpu, 'bench.py needs an MI355X (use --dry-run to exercise the launch path without one)'
 
-    KEEP_CACHED[0] = ctx.world == 1 and (args.multiscale or (not args.no_multiscale and not args.no_train and args.model == 'darknet'))
     det = roof = state = anchors = None
     if args.multiscale:
         args.no_detect = args.no_train = args.no_conv3 = args.no_latency = args.no_resnet = True
         args.cpu_sample = 0
+    # The multi-scale leg runs FIRST, in a process that has not released memory yet: its first-visit figures are capture + growth of the graph pool by ~15 GB per
+    # size, and hipMalloc on this driver is 50x slower once the process has been through a few alloc / free cycles of tens of GB (release_memory).  A training job is
+    # in exactly that pristine state when it meets a new size.
+    ms = None
+    if args.multiscale or (not args.no_multiscale and not args.no_train and args.model == 'darknet'):
+        ctx.sync()
+        time.sleep(args.settle)
+        try:
+            ms = multiscale_leg(args, ctx)
+        except Exception as e:
+            if args.multiscale:
+                raise
+            import traceback
+            traceback.print_exc()
+            ms = {'error': '%s: %s' % (type(e).__name__, e)}
+    release_memory()
     if not args.no_detect:
         det, roof, state, anchors = detect_leg(args, ctx)
     conv3 = None
@@ -1110,23 +1116,6 @@ def main():
             import traceback
             traceback.print_exc()
             tr = {'error': '%s: %s' % (type(e).__name__, e)}
-    # (the multi-scale leg runs BEFORE the latency / ResNet legs: its first-visit figures are capture + graph-pool growth, and growing the pool by tens of GB right after
-    #  another leg has handed ~100 GB back to the driver measured 0.6-0.9 s per size on some boxes, 11-35 ms on others - the driver reclaims freed memory lazily)
-    ms = None
-    if args.multiscale or (not args.no_multiscale and not args.no_train and args.model == 'darknet'):
-        ctx.sync()
-        time.sleep(args.settle)
-        try:
-            ms = multiscale_leg(args, ctx)
-        except Exception as e:
-            if args.multiscale:
-                raise
-            import traceback
-            traceback.print_exc()
-            ms = {'error': '%s: %s' % (type(e).__name__, e)}
-    KEEP_CACHED[0] = False
-    if ctx.gpu:
-        torch.cuda.empty_cache()
     lat = rn = None
     if ctx.world == 1 and args.model == 'darknet' and not args.no_latency and not args.no_detect:
         try:
