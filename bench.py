@@ -1078,9 +1078,9 @@ def main():
     if args.multiscale:
         args.no_detect = args.no_train = args.no_conv3 = args.no_latency = args.no_resnet = True
         args.cpu_sample = 0
-    # The multi-scale leg runs FIRST, in a process that has not released memory yet: its first-visit figures are capture + growth of the graph pool by ~15 GB per
-    # size, and hipMalloc on this driver is 50x slower once the process has been through a few alloc / free cycles of tens of GB (release_memory).  A training job is
-    # in exactly that pristine state when it meets a new size.
+    # The multi-scale leg runs FIRST, in a process that has not allocated anything yet - the state of a training job that meets a new size.  Its first-visit figures
+    # are capture + growth of the graph pool by ~15 GB per size; what a hipMalloc of that size costs depends on the BOX (10-12 ms at every size in four consecutive
+    # processes on one, 0.5-0.9 s from 480-544 upwards on others - whatever this bench did before the leg: DESIGN.md 3.7).
     ms = None
     if args.multiscale or (not args.no_multiscale and not args.no_train and args.model == 'darknet'):
         ctx.sync()
@@ -1094,6 +1094,9 @@ def main():
             traceback.print_exc()
             ms = {'error': '%s: %s' % (type(e).__name__, e)}
     release_memory()
+    if ms is not None and ctx.gpu and not args.multiscale:
+        ctx.sync()
+        time.sleep(args.settle)          # (a leg measures lower right behind seconds of full load: DESIGN.md 5)
     if not args.no_detect:
         det, roof, state, anchors = detect_leg(args, ctx)
     conv3 = None
