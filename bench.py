@@ -65,8 +65,8 @@ def parse_args():
     ap.add_argument('--size', type=int, default=416)
     ap.add_argument('--classes', type=int, default=20)
     ap.add_argument('--model', default='darknet', help='darknet (BASELINE configs[1-3]), tiny, or a model.resnet plugin name (configs[4]: --model resnet50 --size 608 --classes 80)')
-    ap.add_argument('--headline', default='auto', choices=['auto', 'detect', 'train'], help='auto: detect at N = 1, data-parallel train at N > 1')
-    ap.add_argument('--train-steps', type=int, default=0, help='timed training steps (0 = min(--steps, 12))')
+    ap.add_argument('--headline', default='auto', choices=['auto', 'detect', 'train'], help='auto: the batch-64 training step (BASELINE configs[2]) at EVERY N - one workload for the whole scaling curve; detect beside it')
+    ap.add_argument('--train-steps', type=int, default=0, help='timed training steps (0 = --steps)')
     ap.add_argument('--train-batch', type=int, default=64, help='per-GPU batch of the train leg (BASELINE configs[2])')
     ap.add_argument('--rotate', type=int, default=4, help='number of different resident input batches the timed steps rotate over')
     ap.add_argument('--no-graph', action='store_true', help='launch the detect step eagerly instead of replaying captured hipGraphs')
@@ -257,22 +257,54 @@ def top_kernels(table, min_share=0.01):
     return rows, total
 
 
-def roofline_from(table, what):
-    """`roofline` object for the dominant MFMA kernel of `table` + the per-kernel list."""
+def family(name):
+    """'conv_fwd_dma_kernel[grouped]' -> 'conv_fwd_dma_kernel': the __global__ template a hook name belongs to (the names rocprofv3 prints)."""
+    return name.split('[')[0]
+
+
+def families(table):
+    """Hook table grouped by kernel template: {family: dict(launches, ms, flops)} per step."""
+    fam = {}
+    for k, e in table.items():
+        f = fam.setdefault(family(k), dict(launches=0.0, ms=0.0, flops=0.0))
+        for key in ('launches', 'ms', 'flops'):
+            f[key] += e[key]
+    return fam
+
+
+def roofline_from(table, what, trace_tag=None):
+    """`roofline` object for the dominant MFMA kernel of `table` + the per-kernel list.  The dominant kernel is a kernel TEMPLATE (all its launches of a
+    step, whatever job each does: the names a rocprofv3 trace prints).  `frac` is what the committed rocprofv3 trace of the timed schedule supports
+    (profiles/*_traffic.json: `trace`, same kernel sources, same launches per step) when there is one - this run's executed FLOPs per step of the
+    kernel / the trace's time per step of the kernel; `frac_uncontended` is this run's event-hook figure (eager single-stream launches)."""
     rows, total_ms = top_kernels(table)
-    mfma = [r for r in rows if r['executed_tflops'] is not None]
-    dom = max(mfma, key=lambda r: r['ms_per_step']) if mfma else None
+    fam = families(table)
+    mf = {k: e for k, e in fam.items() if e['flops'] > 0 and e['ms'] > 0}
+    dom = max(mf, key=lambda k: mf[k]['ms']) if mf else None
     gemm_ms = sum(e['ms'] for e in table.values() if e['flops'] > 0)
     gemm_fl = sum(e['flops'] for e in table.values())
     out = {'bound': 'mfma', 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'what': what,
-           'definition': 'executed multiply-add FLOPs of the kernel (2*M*N*K of the GEMM each launch runs; Winograd layers execute 16/36 of the direct count) / its '
-                         'launch durations, HIP event pair per launch on the launch stream, measured in this run',
-           'kernel': dom['kernel'] if dom else None, 'achieved': dom['executed_tflops'] if dom else None, 'frac': dom['frac'] if dom else None,
-           'kernel_share_of_step': dom['share'] if dom else None, 'avg_launch_us': dom['avg_launch_us'] if dom else None,
+           'definition': 'executed multiply-add FLOPs of the kernel template per step (2*M*N*K of the GEMM each launch runs; Winograd layers execute 16/36 of the direct count) / its '
+                         'time per step: `frac` from the committed rocprofv3 kernel trace of the timed schedule when it matches this build, `frac_uncontended` from HIP event pairs '
+                         'per launch on the launch stream in this run',
+           'kernel': dom, 'achieved': None, 'frac': None, 'frac_uncontended': None, 'frac_source': None,
            'all_mfma_kernels': {'executed_tflops': round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else None,
                                 'frac': round(gemm_fl / (gemm_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if gemm_ms > 0 else None,
                                 'ms_per_step': round(gemm_ms, 4), 'executed_flops_per_step': gemm_fl},
-           'kernel_ms_per_step': round(total_ms, 4), 'top_kernels': rows}
+           'kernel_ms_per_step': round(total_ms, 4), 'top_kernels': rows,
+           'families': {k: {'launches_per_step': round(e['launches'], 2), 'ms_per_step': round(e['ms'], 4), 'executed_flops_per_step': e['flops']} for k, e in fam.items() if e['ms'] / (total_ms or 1.0) >= 0.01}}
+    if dom:
+        e = mf[dom]
+        live = e['flops'] / (e['ms'] * 1e-3) / 1e12
+        out.update(kernel_share_of_step=round(e['ms'] / (total_ms or 1.0), 4), launches_per_step=round(e['launches'], 2),
+                   frac_uncontended=round(live / kernel_peak(dom), 4), avg_launch_us_uncontended=round(e['ms'] / e['launches'] * 1e3, 2))
+        tr, why = trace_family(trace_tag, dom, e['launches']) if trace_tag else (None, 'no committed trace for this workload')
+        if tr is not None:
+            tf = e['flops'] / (tr['us_per_step'] * 1e-6) / 1e12
+            out.update(achieved=round(tf, 2), frac=round(tf / kernel_peak(dom), 4), avg_launch_us=round(tr['us_per_step'] / e['launches'], 2), frac_source=tr['source'])
+        else:
+            out.update(achieved=round(live, 2), frac=out['frac_uncontended'], avg_launch_us=out['avg_launch_us_uncontended'],
+                       frac_source='event hooks of this run, eager single-stream launches (%s)' % why)
     return out
 
 
@@ -289,7 +321,7 @@ def static_traffic(tag):
         rel = os.path.relpath(files[-1], ROOT)
         if d.get('kernels') != _hip.kernel_hash():
             # a PMC profile of OTHER kernels says nothing about this build: no number rather than a stale one
-            return None, 'stale: %s was taken on kernel sources %s, this build is %s (regenerate with tools/gpu_profile_r5.sh)' % (rel, d.get('kernels'), _hip.kernel_hash())
+            return None, 'stale: %s was taken on kernel sources %s, this build is %s (regenerate with tools/gpu_profile.sh)' % (rel, d.get('kernels'), _hip.kernel_hash())
         return d['traffic_bytes_per_step'], 'static: %s (same kernel sources %s)' % (rel, d.get('kernels'))
     except Exception:
         return None, None
@@ -305,6 +337,32 @@ def static_extra(tag, key):
         return d.get(key) if d.get('kernels') == _hip.kernel_hash() else None
     except Exception:
         return None
+
+
+def trace_family(tag, fam, live_launches_per_step):
+    """Time per step of one kernel template in the committed rocprofv3 kernel trace of the timed schedule (profiles/*_<tag>_traffic.json: `trace`,
+    tools/trace_families.py).  Accepted only for the same kernel sources AND the same number of launches of that template per step as this run
+    (a changed algorithm table or grouping makes the two describe different launch sets).  Returns (dict(us_per_step, source) | None, why not)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_%s_traffic.json' % tag)))
+    if not files:
+        return None, 'no committed trace'
+    try:
+        import _hip
+        d = json.load(open(files[-1]))
+        rel = os.path.relpath(files[-1], ROOT)
+        if d.get('kernels') != _hip.kernel_hash():
+            return None, 'committed trace %s is of other kernel sources' % rel
+        t = d.get('trace') or {}
+        f = (t.get('families') or {}).get(fam)
+        if not f or not t.get('steps'):
+            return None, '%s has no trace row for %s' % (rel, fam)
+        lps = f['calls'] / float(t['steps'])
+        if abs(lps - live_launches_per_step) > 0.02 * max(live_launches_per_step, 1.0):
+            return None, '%s: %s is launched %.2f x per step in the trace, %.2f x in this run' % (rel, fam, lps, live_launches_per_step)
+        return {'us_per_step': f['total_us'] / float(t['steps']), 'source': 'rocprofv3 kernel trace of the timed schedule: %s (same kernel sources %s, %.0f launches per step)' % (rel, d.get('kernels'), lps)}, None
+    except Exception as e:
+        return None, '%s: %s' % (type(e).__name__, e)
 
 
 # ---------------------------------------------------------------------------------------------------- detect leg
@@ -356,7 +414,7 @@ def detect_leg(args, ctx):
                 with torch.cuda.stream(streams[g % nstreams]):
                     runs[g].run()
         fn = replay if runs is not None else eager
-        measure.nstreams = nstreams
+        measure.nstreams, measure.runs = nstreams, runs
         for i in range(2 * len(xs)):
             fn(i)
         dt, host = ctx.timed(fn, steps)
@@ -369,18 +427,31 @@ def detect_leg(args, ctx):
         serial_steps = min(args.steps, 24)
         serial_dt = measure(serial_steps, 0, False, want_streams=1)[0] / serial_steps
         measure.nstreams = pipelined
+    d2h_dt = None
+    if ctx.world == 1 and getattr(measure, 'runs', None):
+        # the reference hands the survivors to the host (utils/postprocess.py:34-49 returns a Python list; detect.py:69-79 indexes with it): the same replays, each
+        # followed by the per-class expansion (y2_expand_classes), the host round trip for the counts and the copy of every image's detections to host memory
+        runs, nd = measure.runs, min(args.steps, 24)
+
+        def to_host(i):
+            res = detect.postprocess_batch(runs[i % len(runs)].run(), fix=True, threshold_cls=kw['threshold_cls'])
+            return [None if r is None else tuple(t.cpu() for t in r) for r in res]
+        to_host(0)
+        d2h_dt = ctx.timed(to_host, nd)[0] / nd
     images = args.batch * args.steps * ctx.world
     out = {'images_per_sec': round(images / dt, 2), 'ms_per_step': round(dt / args.steps * 1e3, 4), 'steps': args.steps,
            'host_ms_per_step': round(host / args.steps * 1e3, 4),
            'launch': ('hipGraph replay, steps pipelined over %d streams (private buffers per stream)' % measure.nstreams if getattr(measure, 'nstreams', 1) > 1 else 'hipGraph replay') if graphed else 'eager',
            'resident_batches_rotated': len(xs), 'per_gpu_batch': args.batch, 'streams': pipelined,
            'serial_ms_per_step': None if serial_dt is None else round(serial_dt * 1e3, 4), 'serial_images_per_sec': None if serial_dt is None else round(args.batch / serial_dt, 2),
+           'to_host_ms_per_step': None if d2h_dt is None else round(d2h_dt * 1e3, 4), 'to_host_images_per_sec': None if d2h_dt is None else round(args.batch / d2h_dt, 2),
            'parallelism': 'replicas x%d (no collective)' % ctx.world if ctx.world > 1 else 'single GPU'}
     if ctx.world > 1:
         out['autotune_choices_synced'] = getattr(measure, 'tune_synced', None)
     roof = None
     if table is not None:
-        roof = roofline_from(table, 'detect step, batch %d (eager single-stream launches of the same kernels the timed hipGraph replays)' % args.batch)
+        std = args.batch == 32 and args.size == 416 and args.model == 'darknet'
+        roof = roofline_from(table, 'detect step, batch %d (the timed step = hipGraph replays of these kernels pipelined over %d streams)' % (args.batch, pipelined), trace_tag='detect_b32' if std else None)
         plan = dnn._plan_cache[1] if dnn._plan_cache else None
         if plan is not None and 'flops_executed' in plan:
             conv_ms = sum(e['ms'] for k, e in table.items() if k.startswith(('conv', 'wino')))
@@ -390,20 +461,12 @@ def detect_leg(args, ctx):
                                   'direct_equiv_tflops': round(alg / conv_ms / 1e9, 2),
                                   'direct_equiv_note': 'ALGORITHMIC conv FLOPs (SURVEY.md 8d, 2*Cin*Cout*k*k*H*W) / kernel time: what a direct convolution would have to sustain; not a roofline fraction',
                                   'winograd_layers': int(sum(plan['algos'])), 'flops_per_step': alg, 'executed_flops_per_step': exe}
-            # the whole TIMED step (conv chain + decode + filter + NMS, pipelined) against the fp32-MFMA peak, in executed multiply-adds
-            roof['timed_step_executed_frac'] = round(exe / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
-        tr, src = static_traffic('detect_b32') if (args.batch == 32 and args.size == 416 and args.model == 'darknet') else (None, None)
+            # the whole TIMED step (conv chain + decode + filter + NMS, pipelined) against the fp32-MFMA peak: executed multiply-adds, and SURVEY.md 8d's
+            # algorithmic (direct-convolution) FLOPs - the latter exceeds 1 where Winograd layers execute 16/36 of the direct count
+            roof['step_frac_executed'] = round(exe / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+            roof['step_frac_direct_equiv'] = round(alg / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+        tr, src = static_traffic('detect_b32') if std else (None, None)
         roof['traffic'], roof['traffic_source'] = tr, src
-        # The per-launch duration above is the UNCONTENDED one (eager single-stream launches under the event hooks).  The timed region replays
-        # the steps pipelined over two streams, where a kernel shares the chip with the other batch's kernels: its launch duration under THAT
-        # schedule cannot be bracketed from inside a hipGraph replay, so it comes from the committed rocprofv3 kernel trace of this command
-        # (profiles/*_detect_b32_traffic.json: `dominant_trace`, same kernel-source hash) and is labelled as such.
-        dt_tr = static_extra('detect_b32', 'dominant_trace') if tr is not None else None
-        dom = table.get(roof['kernel']) if roof.get('kernel') else None
-        if dt_tr and dom and dom['launches'] > 0 and roof['kernel'].split('[')[0] in dt_tr.get('kernel', ''):
-            per_launch = dom['flops'] / dom['launches']
-            roof['frac_timed_schedule_rocprof'] = round(per_launch / (dt_tr['avg_us'] * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
-            roof['avg_launch_us_timed_schedule_rocprof'] = dt_tr['avg_us']
         if _hip.WINOGRAD and args.model == 'darknet' and not args.no_direct_leg:
             _hip.WINOGRAD = False
             dnn._plan_cache = None
@@ -564,7 +627,7 @@ def train_leg(args, ctx):
     import bench_data
     import train as y2train
     import utils
-    steps = args.train_steps or min(args.steps, 12)
+    steps = args.train_steps or args.steps          # EXACTLY K timed steps, like every leg (this is the headline leg at every N)
     B, S = args.train_batch, args.size
     nbatch = max(1, min(args.rotate, 2))
     data = []
@@ -624,6 +687,9 @@ def train_leg(args, ctx):
     runner = keep[0].__dict__.get('_y2_step_runner')
     out['launch'] = ('hipGraph replay of the captured step (%d graph segment(s)) + eager optimizer' % sum(1 for p in runner.plans.values() for op in (p.ops or []) if op[0] == 'graph')
                      if (runner is not None and runner.captures) else 'eager launches')
+    if runner is not None and runner.plans:
+        pl = next(iter(runner.plans.values()))
+        out['operand_forms_prepared'] = None if pl.only is None else len(pl.only)      # None: the captured step derives every operand form (not the pruned step)
     if single:
         out['dp_speedup_vs_single_gpu'] = round(out['images_per_sec'] / single, 3)
     if per_img is not None:
@@ -640,11 +706,15 @@ def train_leg(args, ctx):
         finally:
             train_graph.BWD_STREAMS = streams
             y2train.GRAPH = graph
-        out['roofline'] = roofline_from(table, 'training step, batch %d: fprop / dgrad / wgrad kernels with their executed FLOPs; per-kernel durations measured single-stream '
-                                               '(the timed step runs the weight gradients on a side stream, Y2_BWD_STREAMS=%d)' % (B, streams))
-        out['roofline']['kernel_ms_sum_single_stream'] = round(sum(e['ms'] for e in table.values()), 3)
-        if B == 64 and S == 416 and args.model == 'darknet' and args.classes == 20:
-            out['roofline']['traffic'], out['roofline']['traffic_source'] = static_traffic('train_b64')
+        std = B == 64 and S == 416 and args.model == 'darknet' and args.classes == 20
+        out['roofline'] = r = roofline_from(table, 'training step, batch %d: fprop / dgrad / wgrad kernels with their executed FLOPs (the timed step = one hipGraph replay, weight gradients '
+                                                   'forked onto a side stream, + the fused optimizer)' % B, trace_tag='train_b64' if std else None)
+        r['kernel_ms_sum_single_stream'] = round(sum(e['ms'] for e in table.values()), 3)
+        # the whole TIMED step against the fp32-MFMA peak: executed multiply-adds of all its MFMA kernels, and SURVEY.md 8d's algorithmic FLOPs (87.78 GFLOP per image)
+        r['step_frac_executed'] = round(r['all_mfma_kernels']['executed_flops_per_step'] / (dt / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+        if per_img is not None:
+            r['step_frac_direct_equiv'] = round(per_img * B / (dt / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+        r['traffic'], r['traffic_source'] = static_traffic('train_b64') if std else (None, None)
     del step, last, keep
     release_memory()
     return out
@@ -986,8 +1056,8 @@ def dry_run(args, ctx):
 
 
 LINE_LIMIT = 6000        # bytes of the final stdout line: the driver parses the LAST line of stdout and keeps a bounded tail of it (round 4's 30 KB line was not parsed)
-ROOF_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'avg_launch_us', 'kernel_share_of_step', 'frac_timed_schedule_rocprof',
-             'avg_launch_us_timed_schedule_rocprof', 'timed_step_executed_frac', 'kernel_ms_per_step', 'what', 'traffic_source')
+ROOF_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'avg_launch_us', 'frac_uncontended', 'step_frac_executed', 'step_frac_direct_equiv',
+             'kernel_share_of_step', 'launches_per_step', 'kernel_ms_per_step', 'frac_source', 'what', 'traffic_source')
 # scalars that go first when the line would exceed LINE_LIMIT (least important first)
 DROP_ORDER = ('split_bf16x6_detect_images_per_sec', 'split_f16x3_detect_images_per_sec', 'latency_b8_launches', 'latency_b1_launches', 'resnet50_608_train_kernel_ms_sum',
               'resnet50_608_train_mfma_ms_per_step', 'train_mfma_ms_per_step', 'train_kernel_ms_sum_single_stream', 'train_dominant_avg_launch_us', 'multiscale_switch_cost_ms_max',
@@ -1016,7 +1086,7 @@ def compact_line(head, roof, extra, cb, tables_at=None, limit=LINE_LIMIT):
     out = dict(head)
     if roof is not None:
         r = {k: roof[k] for k in ROOF_KEYS if k in roof and not isinstance(roof[k], (dict, list))}
-        for k in ('what', 'traffic_source'):
+        for k in ('what', 'traffic_source', 'frac_source'):
             if isinstance(r.get(k), str) and len(r[k]) > 160:
                 r[k] = r[k][:157] + '...'
         r.update({k: v for k, v in extra.items() if not isinstance(v, (dict, list))})
@@ -1036,12 +1106,26 @@ def compact_line(head, roof, extra, cb, tables_at=None, limit=LINE_LIMIT):
     drop = list(DROP_ORDER)
     box = out.get('roofline', out.get('summary'))
     while len(line) > limit and box:
-        k = drop.pop(0) if drop else next((k for k in reversed(list(box)) if k not in ROOF_KEYS[:6]), None)
+        k = drop.pop(0) if drop else next((k for k in reversed(list(box)) if k not in ROOF_KEYS[:11]), None)
         if k is None:
             break
         box.pop(k, None)
         line = json.dumps(out, separators=(',', ':'))
     return line
+
+
+def naming(args, headline):
+    """(metric, workload of the detect leg, workload of the train leg) - functions of the arguments only, never of the world size: the line of an
+    N-GPU run names the same workload as the line of the 1-GPU run it is compared with."""
+    label = {'darknet': 'Darknet-19', 'tiny': 'tiny-yolo'}.get(args.model, args.model)
+    ref = {'darknet': (' (BASELINE configs[1])', ' (BASELINE configs[2])')}.get(args.model, (' (plugin swap: forward of BASELINE configs[4])', ' (plugin swap, BASELINE configs[4] per GPU)') if args.model.startswith('resnet') else ('', ''))
+    det_workload = '%s YOLOv2 %dx%d batch-%d/GPU inference: conv stack + decode + filter + NMS%s' % (label, args.size, args.size, args.batch, ref[0])
+    tr_workload = '%s YOLOv2 %d-class train %dx%d batch-%d/GPU: fwd + region loss + bwd + SGD%s' % (label, args.classes, args.size, args.size, args.train_batch, ref[1])
+    if headline == 'train':
+        metric = 'images/sec (%dx%d) train+detect, %s YOLOv2: value = TRAIN step, batch %d per GPU (configs[2]) at every N; detect (configs[1]) = roofline.detect_images_per_sec' % (args.size, args.size, label, args.train_batch)
+    else:
+        metric = 'images/sec (%dx%d) train+detect, %s YOLOv2: value = DETECT (configs[1]); train (configs[2]) = roofline.train_images_per_sec' % (args.size, args.size, label)
+    return metric, det_workload, tr_workload
 
 
 def main():
@@ -1054,7 +1138,9 @@ def main():
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or let bench.py launch the ranks itself)' % (args.gpus, ctx.world, args.gpus))
     if ctx.ranks_seen != ctx.world:
         raise SystemExit('bench.py: all-reduce of ones saw %d ranks, expected %d' % (ctx.ranks_seen, ctx.world))
-    headline = args.headline if args.headline != 'auto' else ('detect' if ctx.world == 1 else 'train')
+    # ONE headline workload at every N (value(8) / value(1) must compare like with like): the batch-64 training step, the leg with a collective and the
+    # configuration north_star's targets are quoted on; detect (configs[1], replicas) is reported beside it
+    headline = args.headline if args.headline != 'auto' else 'train'
     if args.no_detect and headline == 'detect':
         headline = 'train'
     if args.no_train and headline == 'train':
@@ -1065,10 +1151,12 @@ def main():
         tr, de = dry_run(args, ctx)
         if ctx.rank == 0:
             src = tr if headline == 'train' else de
-            print(json.dumps({'metric': 'DRY RUN (stand-in CPU workload, launch/rendezvous/DP-wrapper/timing protocol only)', 'value': src['images_per_sec'], 'unit': 'images/sec',
+            metric, det_workload, tr_workload = naming(args, headline)
+            print(json.dumps({'metric': 'DRY RUN (stand-in CPU workload, launch/rendezvous/DP-wrapper/timing protocol only) of: ' + metric, 'value': src['images_per_sec'], 'unit': 'images/sec',
                               'n_gpus': ctx.world, 'ranks_seen': ctx.ranks_seen, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': src['ms_per_step'],
                               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'dry_run': True, 'valid': False,
-                              'headline': headline, 'config': {'workload': 'none: 2-layer CPU MLP stand-in'}, 'train': tr, 'detect': de}))
+                              'headline': headline, 'config': {'workload': tr_workload if headline == 'train' else det_workload, 'executed': 'none of it: 2-layer CPU MLP stand-in',
+                                                               'global_batch': (args.train_batch if headline == 'train' else args.batch) * ctx.world}, 'train': tr, 'detect': de}))
         if ctx.world > 1:
             ctx.dist.destroy_process_group()
         return
@@ -1136,31 +1224,29 @@ def main():
             traceback.print_exc()
             rn = {'error': '%s: %s' % (type(e).__name__, e)}
     if ctx.rank == 0:
-        ref = {'darknet': (' (BASELINE configs[1])', ' (BASELINE configs[2])')}.get(args.model, (' (plugin swap: forward of BASELINE configs[4])', ' (plugin swap, BASELINE configs[4] per GPU)') if args.model.startswith('resnet') else ('', ''))
-        det_workload = '%s YOLOv2 %dx%d batch-%d/GPU inference: conv stack + decode + filter + NMS%s' % (label, args.size, args.size, args.batch, ref[0])
-        tr_workload = '%s YOLOv2 %d-class train %dx%d batch-%d/GPU: fwd + region loss + bwd + SGD%s' % (label, args.classes, args.size, args.size, args.train_batch, ref[1])
+        metric, det_workload, tr_workload = naming(args, headline)
         if args.multiscale:
             value, msps, steps, workload = ms['images_per_sec'], ms['ms_per_step_mean'], ms['steps'], ms['workload']
             metric = 'images/sec (320..608 multi-scale) train, %s YOLOv2 (BASELINE configs[3] per GPU)' % label
             headline = 'multiscale'
         elif headline == 'train':
             value, msps, steps, workload = tr['images_per_sec'], tr['ms_per_step'], tr['steps'], tr_workload
-            metric = 'images/sec (%dx%d) train+detect, %s YOLOv2: value = data-parallel TRAIN step; detect beside it in summary' % (args.size, args.size, label)
         else:
             value, msps, steps, workload = det['images_per_sec'], det['ms_per_step'], det['steps'], det_workload
-            metric = 'images/sec (%dx%d) train+detect, %s YOLOv2: value = DETECT (configs[1]); train (configs[2]) = roofline.train_images_per_sec' % (args.size, args.size, label)
         ok = lambda d: d is not None and 'error' not in d
         # ---- scalars of the ONE line the driver parses (it keeps `roofline`, `config`, `cpu_baseline`): every leg's headline numbers, once
         extra = {}
+        droof, troof = roof, (tr.get('roofline') if ok(tr) else None)
         if ok(det):
             extra.update(detect_images_per_sec=det['images_per_sec'], detect_ms_per_step=det['ms_per_step'], detect_streams=det.get('streams'),
-                         detect_serial_images_per_sec=det.get('serial_images_per_sec'), detect_serial_ms_per_step=det.get('serial_ms_per_step'))
-        if roof is not None:
-            if 'conv_chain' in roof:
-                extra.update(conv_chain_ms_per_step=roof['conv_chain']['ms_per_step'], conv_chain_frac=roof['conv_chain']['frac'])
-            if isinstance(roof.get('direct_only'), dict) and 'frac' in roof['direct_only']:
-                extra['detect_direct_only_frac'] = roof['direct_only']['all_mfma_kernels']['frac']
-            for r in roof.get('top_kernels', []):
+                         detect_serial_images_per_sec=det.get('serial_images_per_sec'), detect_serial_ms_per_step=det.get('serial_ms_per_step'),
+                         detect_to_host_images_per_sec=det.get('to_host_images_per_sec'))
+        if droof is not None:
+            if 'conv_chain' in droof:
+                extra.update(conv_chain_ms_per_step=droof['conv_chain']['ms_per_step'], conv_chain_frac=droof['conv_chain']['frac'])
+            if isinstance(droof.get('direct_only'), dict) and 'frac' in droof['direct_only']:
+                extra['detect_direct_only_frac'] = droof['direct_only']['all_mfma_kernels']['frac']
+            for r in droof.get('top_kernels', []):
                 if r['frac'] is not None:       # one scalar per MFMA kernel of the detect step (uncontended single-stream launches): frac_<kernel>
                     extra['frac_' + scalar_name(r['kernel'])] = r['frac']
         if ok(tr):
@@ -1168,11 +1254,17 @@ def main():
             for k in ('dp_exposed_comm_ms_per_step', 'ms_per_step_contended', 'single_gpu_images_per_sec'):
                 if k in tr:
                     extra['train_' + k] = tr[k]
-            r = tr.get('roofline')
-            if r:
-                extra.update(train_traffic_bytes_per_step=r.get('traffic'), train_mfma_frac=r['all_mfma_kernels']['frac'], train_mfma_ms_per_step=r['all_mfma_kernels']['ms_per_step'],
-                             train_kernel_ms_sum_single_stream=r.get('kernel_ms_sum_single_stream'), train_dominant_kernel=r['kernel'], train_dominant_frac=r['frac'],
-                             train_dominant_avg_launch_us=r['avg_launch_us'])
+        # the leg that is NOT the headline hands its roofline scalars over with a prefix; the headline leg's ARE the `roofline` object
+        side, prefix = (droof, 'detect_') if headline == 'train' else (troof, 'train_')
+        if side:
+            for k in ('kernel', 'frac', 'frac_uncontended', 'avg_launch_us', 'step_frac_executed', 'step_frac_direct_equiv', 'traffic', 'kernel_ms_per_step'):
+                if side.get(k) is not None:
+                    extra[prefix + ('dominant_' if k in ('kernel', 'frac', 'frac_uncontended', 'avg_launch_us') else '') + k] = side[k]
+        if troof:
+            extra.update(train_mfma_frac=troof['all_mfma_kernels']['frac'], train_mfma_ms_per_step=troof['all_mfma_kernels']['ms_per_step'],
+                         train_kernel_ms_sum_single_stream=troof.get('kernel_ms_sum_single_stream'))
+        if headline == 'train' and troof:
+            roof = dict(troof)
         if ok(conv3):
             extra['conv3x3_b64_mfma_util'] = conv3['autotuned']['mfma_utilisation']
             if 'direct_only' in conv3:
@@ -1194,15 +1286,13 @@ def main():
             extra.update(multiscale_images_per_sec=ms['images_per_sec'], multiscale_ms_per_step_mean=ms['ms_per_step_mean'], multiscale_switch_cost_ms_max=ms['switch_cost_ms_max'],
                          multiscale_first_visit_ms_mean=ms['first_visit_ms_mean'], multiscale_first_visit_ms_max=ms.get('first_visit_ms_max'),
                          multiscale_first_visit_shapes_measured=ms.get('first_visit_shapes_measured'))
-        if roof is not None:
+        if droof is not None:
             for tag in ('split_bf16x6', 'split_f16x3'):
-                sp = roof.get(tag)
+                sp = droof.get(tag)
                 if isinstance(sp, dict) and 'images_per_sec' in sp:
                     extra[tag + '_detect_images_per_sec'] = sp['images_per_sec']
-        if roof is None and ok(tr) and tr.get('roofline'):
-            r = tr['roofline']
-            roof = {'bound': 'mfma', 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'what': r['what'], 'kernel': r['kernel'], 'achieved': r['achieved'], 'frac': r['frac'],
-                    'avg_launch_us': r['avg_launch_us'], 'traffic': r.get('traffic'), 'traffic_source': r.get('traffic_source')}
+        if roof is None and troof:
+            roof = dict(troof)
         head = {'metric': metric, 'value': value, 'unit': 'images/sec', 'n_gpus': ctx.world, 'ranks_seen': ctx.ranks_seen, 'steps': steps, 'warmup': args.warmup,
                 'ms_per_step': msps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'headline': headline,
                 'config': {'workload': workload, 'classes': args.classes, 'global_batch': (args.batch if headline == 'detect' else args.train_batch) * ctx.world,

@@ -14,20 +14,21 @@ sys.path.insert(0, ROOT)
 
 def _worst_case():
     """A result with MORE scalars than any real run produces (every leg present, long kernel names, long strings)."""
-    head = {'metric': 'images/sec (416x416) train+detect, Darknet-19 YOLOv2: value = DETECT (configs[1]); train (configs[2]) = roofline.train_images_per_sec', 'value': 7351.87,
-            'unit': 'images/sec', 'n_gpus': 1, 'ranks_seen': 1, 'steps': 20, 'warmup': 5, 'ms_per_step': 4.3526, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic', 'headline': 'detect',
-            'config': {'workload': 'Darknet-19 YOLOv2 416x416 batch-32/GPU inference: conv stack + decode + filter + NMS (BASELINE configs[1])', 'classes': 20, 'global_batch': 32,
+    head = {'metric': 'images/sec (416x416) train+detect, Darknet-19 YOLOv2: value = TRAIN step, batch 64 per GPU (configs[2]) at every N; detect (configs[1]) = roofline.detect_images_per_sec', 'value': 2051.87,
+            'unit': 'images/sec', 'n_gpus': 1, 'ranks_seen': 1, 'steps': 20, 'warmup': 5, 'ms_per_step': 31.3526, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic', 'headline': 'train',
+            'config': {'workload': 'Darknet-19 YOLOv2 20-class train 416x416 batch-64/GPU: fwd + region loss + bwd + SGD (BASELINE configs[2])', 'classes': 20, 'global_batch': 64,
                        'parallelism': 'single GPU', 'weights': 'random-init seed 0 (bench_data.randomize)'}}
-    roof = {'bound': 'mfma', 'peak': 157.3, 'unit': 'TFLOP/s', 'what': 'x' * 400, 'kernel': 'conv_fwd_dma_kernel[grouped]', 'achieved': 111.6, 'frac': 0.7096, 'frac_timed_schedule_rocprof': 0.7075,
-            'avg_launch_us': 373.3, 'avg_launch_us_timed_schedule_rocprof': 327.9, 'kernel_share_of_step': 0.41, 'traffic': 8.49e9, 'traffic_source': 'static: ' + 'p' * 300,
-            'timed_step_executed_frac': 0.6979, 'kernel_ms_per_step': 4.9, 'top_kernels': [{'kernel': 'k%d' % i, 'frac': 0.5} for i in range(40)], 'conv_chain': {'a': 1},
-            'two_stream_top_kernels': [{'kernel': 'k'}] * 30, 'definition': 'd' * 500}
+    roof = {'bound': 'mfma', 'peak': 157.3, 'unit': 'TFLOP/s', 'what': 'x' * 400, 'kernel': 'conv_fwd_dma_kernel', 'achieved': 111.6, 'frac': 0.7096, 'frac_uncontended': 0.8075,
+            'avg_launch_us': 373.3, 'avg_launch_us_uncontended': 327.9, 'kernel_share_of_step': 0.41, 'launches_per_step': 29.0, 'traffic': 8.49e9, 'traffic_source': 'static: ' + 'p' * 300,
+            'frac_source': 'f' * 300, 'step_frac_executed': 0.5179, 'step_frac_direct_equiv': 1.14, 'kernel_ms_per_step': 4.9, 'top_kernels': [{'kernel': 'k%d' % i, 'frac': 0.5} for i in range(40)],
+            'conv_chain': {'a': 1}, 'families': {'k': {'a': 1}}, 'definition': 'd' * 500}
     extra = {}
     for i in range(12):
         extra['frac_some_quite_long_kernel_name_%d_implicit' % i] = 0.61234
     for k in ('detect_images_per_sec', 'detect_ms_per_step', 'detect_streams', 'detect_serial_images_per_sec', 'detect_serial_ms_per_step', 'conv_chain_ms_per_step', 'conv_chain_frac',
-              'detect_direct_only_frac', 'train_images_per_sec', 'train_ms_per_step', 'train_host_issue_ms_per_step', 'train_dp_exposed_comm_ms_per_step', 'train_ms_per_step_contended',
+              'detect_direct_only_frac', 'detect_to_host_images_per_sec', 'detect_dominant_frac', 'detect_dominant_frac_uncontended', 'detect_step_frac_executed',
+              'detect_step_frac_direct_equiv', 'detect_traffic', 'train_images_per_sec', 'train_ms_per_step', 'train_host_issue_ms_per_step', 'train_dp_exposed_comm_ms_per_step', 'train_ms_per_step_contended',
               'train_single_gpu_images_per_sec', 'train_traffic_bytes_per_step', 'train_mfma_frac', 'train_mfma_ms_per_step', 'train_kernel_ms_sum_single_stream', 'train_dominant_frac',
               'train_dominant_avg_launch_us', 'conv3x3_b64_mfma_util', 'conv3x3_b64_direct_only_util', 'latency_b1_ms', 'latency_b1_launches', 'latency_b1_executed_mfma_frac',
               'latency_b1_direct_equiv_frac', 'latency_b8_ms', 'latency_b8_launches', 'latency_b8_executed_mfma_frac', 'latency_b8_direct_equiv_frac', 'latency_b1_weight_tbs',
@@ -52,12 +53,12 @@ def test_final_line_is_small_flat_and_complete():
         assert k in d, k
     assert 'workload' in d['config'] and 'model' not in d['config']
     r = d['roofline']
-    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'frac_uncontended', 'step_frac_executed', 'step_frac_direct_equiv', 'frac_source'):
         assert k in r, k
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     assert all(not isinstance(v, (dict, list)) for v in r.values())           # scalars only: tables live in the file `tables` names
     for k in ('train_images_per_sec', 'train_ms_per_step', 'train_traffic_bytes_per_step', 'conv3x3_b64_mfma_util', 'latency_b1_ms', 'multiscale_first_visit_ms_mean',
-              'resnet50_608_train_direct_equiv_frac', 'detect_serial_ms_per_step'):
+ 'resnet50_608_train_direct_equiv_frac', 'detect_serial_ms_per_step', 'detect_images_per_sec', 'detect_step_frac_executed', 'detect_to_host_images_per_sec'):
         assert k in r, k                                                     # the figures a reviewer looks for survive the trimming
     c = d['cpu_baseline']
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
@@ -69,7 +70,37 @@ def test_final_line_is_small_flat_and_complete():
     line = bench.compact_line(head, roof, extra, cb, 'x.json')
     assert len(line) <= bench.LINE_LIMIT
     r = json.loads(line)['roofline']
-    assert all(k in r for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'))
+    assert all(k in r for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'frac_uncontended', 'step_frac_executed', 'step_frac_direct_equiv'))
+
+
+def test_roofline_frac_follows_the_committed_trace_only_when_it_describes_the_same_launches(tmp_path, monkeypatch):
+    """`roofline.frac` is the figure profiles/ reproduces: this run's executed FLOPs per step of the dominant kernel TEMPLATE over the committed trace's time per
+    step of that template - taken only for the same kernel sources and the same launches per step; otherwise the event-hook figure, labelled as such."""
+    import bench
+    import _hip
+    table = {'conv_fwd_dma_kernel[grouped]': dict(launches=14.0, ms=6.0, flops=14 * 55e9), 'conv_fwd_dma_kernel[persistent]': dict(launches=15.0, ms=1.5, flops=15 * 10e9),
+             'conv_wgrad_kernel[grouped]': dict(launches=13.0, ms=5.3, flops=13 * 50e9), 'bn_act_bwd_kernel': dict(launches=45.0, ms=3.0, flops=0.0)}
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    rec = {'kernels': _hip.kernel_hash(), 'trace': {'steps': 10, 'families': {'conv_fwd_dma_kernel': {'calls': 290, 'total_us': 82000.0}}}}
+    (prof / 'r99_train_b64_traffic.json').write_text(json.dumps(rec))
+    r = bench.roofline_from(table, 'x', trace_tag='train_b64')
+    flops = 14 * 55e9 + 15 * 10e9
+    assert r['kernel'] == 'conv_fwd_dma_kernel' and r['launches_per_step'] == 29.0
+    assert abs(r['frac'] - flops / 8.2e-3 / 1e12 / 157.3) < 1e-3 and 'r99_train_b64_traffic.json' in r['frac_source']
+    assert abs(r['frac_uncontended'] - flops / 7.5e-3 / 1e12 / 157.3) < 1e-3 and r['frac'] < r['frac_uncontended']
+    # another launch count per step (a changed algorithm table): the trace no longer describes this run
+    rec['trace']['families']['conv_fwd_dma_kernel']['calls'] = 250
+    (prof / 'r99_train_b64_traffic.json').write_text(json.dumps(rec))
+    r = bench.roofline_from(table, 'x', trace_tag='train_b64')
+    assert r['frac'] == r['frac_uncontended'] and 'event hooks' in r['frac_source'] and '25.00 x per step in the trace' in r['frac_source']
+    # other kernel sources
+    rec['kernels'] = 'deadbeef'
+    rec['trace']['families']['conv_fwd_dma_kernel']['calls'] = 290
+    (prof / 'r99_train_b64_traffic.json').write_text(json.dumps(rec))
+    r = bench.roofline_from(table, 'x', trace_tag='train_b64')
+    assert r['frac'] == r['frac_uncontended'] and 'other kernel sources' in r['frac_source']
 
 
 def test_tables_go_to_a_file(tmp_path):

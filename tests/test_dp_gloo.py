@@ -188,7 +188,7 @@ def worker(rank, world, port, tmp):
     _hip._TUNE[('mine', rank, 'cpu')] = [2, 0]
     dp2 = train.DataParallelRCCL(nn.Linear(3, 3))
     for call in range(1, 5):
-        dp2(torch.randn(2 + rank * call, 3))                    # a different input shape per rank and call
+        dp2(torch.randn(2 + rank * call, 3)).sum().backward()   # a different input shape per rank and call; a step is a BACKWARD that all-reduces
         assert (dp2.tune_synced is not None) == (call >= 4)
     assert _hip._TUNE[(64, 10, 10, 512, 'cpu')] == [1, 0] and _hip._TUNE[('mine', rank, 'cpu')] == [2, 0]
     assert (('mine', 0, 'cpu') in _hip._TUNE) and len(_hip._TUNE) == (2 if rank == 0 else 3)
@@ -207,15 +207,18 @@ def worker(rank, world, port, tmp):
             lin.train()
         for p in lin.parameters():
             p.grad = None
+        if call == 3:
+            lin.eval()                                          # a differentiable eval()-mode step on EVERY rank (frozen-BatchNorm fine-tuning) is a training step
         dp3(xs[rank * 2:rank * 2 + 2]).pow(2).mean().backward()
+        lin.train()
         assert dp3._calls == call, (rank, dp3._calls, call)
         assert (dp3.tune_synced is not None) == (call >= 4), (rank, call)
         red = [p.grad.clone() for p in lin.parameters()]
-        for p in lin.parameters():
-            p.grad = None
-        lin(xs).pow(2).mean().backward()
-        for a, p in zip(red, lin.parameters()):
-            assert torch.allclose(a, p.grad, rtol=1e-5, atol=1e-6), ('eval calls between training steps', rank, call)
+        # witness on private copies of the weights (a backward through `lin` itself would fire the wrapper's hooks: that IS a step of the wrapper)
+        wit = [p.detach().clone().requires_grad_() for p in lin.parameters()]
+        torch.nn.functional.linear(xs, wit[0], wit[1]).pow(2).mean().backward()
+        for a, w in zip(red, wit):
+            assert torch.allclose(a, w.grad, rtol=1e-5, atol=1e-6), ('eval calls between training steps', rank, call)
     if rank == 0:
         open(os.path.join(tmp, 'ok'), 'w').write('ok')
     dist.barrier()
@@ -341,6 +344,13 @@ def test_bench_self_launches_ranks_dry_run():
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['ranks_seen'] == 2 and rec['dry_run'] is True and rec['valid'] is False
     assert rec['headline'] == 'train' and rec['train']['wrapper'] == 'DataParallelRCCL' and rec['steps'] == 3
+    # the line of the 1-GPU run names the SAME workload (the driver divides value(N) by value(1)): the batch-64 training step at every N
+    one = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--dry-run', '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=120, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    rec1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][0])
+    assert rec1['n_gpus'] == 1 and rec1['headline'] == rec['headline'] == 'train' and rec1['metric'] == rec['metric']
+    assert rec1['config']['workload'] == rec['config']['workload'] and 'configs[2]' in rec['config']['workload'] and 'batch-64/GPU' in rec['config']['workload']
+    assert rec['config']['global_batch'] == 2 * rec1['config']['global_batch'] == 128
     # a world size that contradicts --gpus is refused, not silently accepted
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '1'],
                          capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'))

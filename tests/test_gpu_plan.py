@@ -253,7 +253,7 @@ def _dp_rank(rank, world, port, tmp, modes, kind='darknet'):
     if runner is not None and runner.plans:
         plan = next(iter(runner.plans.values()))
         ops = None if plan.ops is None else [op[0] for op in plan.ops]
-    torch.save({'losses': losses, 'params': {k: v.cpu() for k, v in inf.dnn.state_dict().items()}, 'grads': {k: p.grad.cpu() for k, p in inf.dnn.named_parameters()},
+    torch.save({'backend': dist.get_backend(), 'device': torch.cuda.current_device(), 'losses': losses, 'params': {k: v.cpu() for k, v in inf.dnn.state_dict().items()}, 'grads': {k: p.grad.cpu() for k, p in inf.dnn.named_parameters()},
                 'ops': ops, 'captures': None if runner is None else runner.captures}, os.path.join(tmp, 'rank%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -305,6 +305,37 @@ def test_dp_world2_graph_segments_interoperate_with_the_hook_path(tmp_path):
         for k, v in out[name][0]['grads'].items():
             assert torch.equal(v, out[name][1]['grads'][k]), (name, k)
             assert rel(v, out['hooks'][0]['grads'][k]) <= 50 * STEP_TOL, (name, 'grad', k)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='real RCCL between two ranks needs two visible GPUs (the 1-GPU lease runs the gloo / shared-GPU variants above)')
+def test_real_rccl_world2_captured_steps_equal_the_host_staged_run(tmp_path):
+    """train.ensure_model across GPUs (/root/reference/train.py:65-71, loader scaling :296-309) on the transport it ships with: two ranks, one GPU each,
+    backend nccl (= RCCL), eight steps of train.iterate - eager plans, the capture, replays of hipGraph segments with RCCL bucket all-reduces and the
+    positive-count all-reduce BETWEEN them on the same stream - against the same two ranks sharing cuda:0 over gloo with host-staged buffers (the variant
+    every 1-GPU run exercises) and against the hook path on RCCL.  Same collectives in the same order: same losses, same averaged gradients, no hang."""
+    import torch.multiprocessing as mp
+    world = 2
+    out = {}
+    for name, modes, backend in (('rccl_graphs', [(True, True)] * 2, 'auto'), ('rccl_hooks', [(False, False)] * 2, 'auto'), ('gloo_graphs', [(True, True)] * 2, 'gloo')):
+        d = tmp_path / name
+        d.mkdir()
+        os.environ['Y2_TEST_DP_BACKEND'] = backend
+        try:
+            mp.spawn(_dp_rank, args=(world, _free_port(), str(d), modes), nprocs=world, join=True)
+        finally:
+            os.environ.pop('Y2_TEST_DP_BACKEND', None)
+        out[name] = [torch.load(str(d / ('rank%d.pt' % r)), weights_only=False) for r in range(world)]
+    g = out['rccl_graphs']
+    assert [r['backend'] for r in g] == ['nccl', 'nccl'] and sorted(r['device'] for r in g) == [0, 1]
+    assert [r['backend'] for r in out['gloo_graphs']] == ['gloo', 'gloo']
+    assert g[0]['captures'] == 1 and g[0]['ops'].count('graph') >= 3 and 'npos' in g[0]['ops'] and 'buckets' in g[0]['ops'], g[0]['ops']
+    for other in ('rccl_hooks', 'gloo_graphs'):
+        for r in range(world):
+            np.testing.assert_allclose(np.array(g[r]['losses']), np.array(out[other][r]['losses']), rtol=2e-5, err_msg='%s rank %d' % (other, r))
+        for k, v in g[0]['grads'].items():
+            assert torch.equal(v, g[1]['grads'][k]), k                          # replicas hold the same averaged gradient, bit for bit
+            assert rel(v, out[other][0]['grads'][k]) <= 50 * STEP_TOL, (other, k)
 
 
 def test_plans_are_recaptured_after_the_model_moved_to_the_cpu_and_back():

@@ -2,7 +2,7 @@
 # Round-5 artefacts.  Stages (all by default, or name them): tune tests smoke profiles bench driver contention
 #   tune        tools/make_tune_table.py -> yolo2-pytorch_amd/tune/default_gfx950.json (copied to gpurun_out/ for committing)
 #   tests       full GPU test suite            smoke   __graft_entry__.smoke()
-#   profiles    rocprofv3 stats + PMC passes (tools/gpu_profile_r5.sh) -> gpurun_out/prof5/
+#   profiles    rocprofv3 stats + PMC passes (tools/gpu_profile.sh) -> gpurun_out/prof/
 #   bench       the default bench line -> gpurun_out/bench_r05.json (+ the long form gpurun_out/bench_r05_full.json)
 #   driver      the driver's own command (`bench.py --gpus 1 --steps 20 --warmup 5`) -> gpurun_out/bench_r05_driver.json
 #   contention  tools/contention.py -> gpurun_out/r05_contention.txt
@@ -19,7 +19,7 @@ driver) echo "=== driver command"; timeout 900 python bench.py --gpus 1 --steps 
   python -c "
 import json; r = json.load(open('gpurun_out/bench_r05_driver.json'))['roofline']; print({k: r[k] for k in r if k.startswith(('multiscale', 'train_ms', 'train_images', 'detect_images', 'frac', 'traffic'))})
 f = json.load(open('gpurun_out/bench_r05_driver_full.json'))['multiscale']; print([(p['size'], p['first_visit_ms'], p['first_visit_shapes_measured']) for p in f['per_size']], f.get('first_visit_measured_keys'), f.get('reserved_gib_before_after'))";;
-profiles) echo "=== profiles"; bash tools/gpu_profile_r5.sh 2>&1 | tail -40
-  for f in detect_b32_traffic.json train_b64_traffic.json; do cp gpurun_out/prof5/$f profiles/r05_$f; done;;      # a bench stage that follows reports this build's traffic
+profiles) echo "=== profiles"; bash tools/gpu_profile.sh 2>&1 | tail -40
+  for f in detect_b32_traffic.json train_b64_traffic.json; do cp gpurun_out/prof/$f profiles/r05_$f; done;;      # a bench stage that follows reports this build's traffic
 contention) echo "=== contention"; timeout 600 python tools/contention.py 2>/dev/null | tee gpurun_out/r05_contention.txt | head -3;;
 esac; done

@@ -48,13 +48,19 @@ if by_grid and os.path.exists(by_grid):
             dominant = {'kernel': m.group(1), 'wgs': int(m.group(2)), 'calls': int(m.group(3)), 'avg_us': float(m.group(5)), 'share_percent': float(m.group(8)),
                         'source': os.path.basename(by_grid)}
             break
+trace = None
+trace_file = next((a for a in sys.argv[2:] if a.endswith('trace.json')), None)
+if trace_file and os.path.exists(trace_file):
+    # per kernel-template time of the steady part of the kernel trace of the same command (tools/trace_families.py): what bench.py's roofline.frac divides by
+    trace = json.load(open(trace_file))
 print(json.dumps({
-    'source': ('rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile_r5.sh) on `tools/train_steady.py` (autotune cache pre-populated): every kernel of the training step' if TRAIN else
-               'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile_r5.sh) on `bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3 --no-split-leg --no-multiscale --no-latency --no-resnet` (autotune cache pre-populated); conv0 + conv_fwd_dma_kernel family + split-K fix-up + all Winograd kernels'),
+    'source': ('rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile.sh) on `tools/train_steady.py` (autotune cache pre-populated): every kernel of the training step' if TRAIN else
+               'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profile.sh) on `bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-train --no-direct-leg --no-conv3 --no-split-leg --no-multiscale --no-latency --no-resnet` (autotune cache pre-populated); conv0 + conv_fwd_dma_kernel family + split-K fix-up + all Winograd kernels'),
     'kernel_launches_profiled': launches, 'steps_profiled': steps,
     'fetch_size_bytes_raw_per_step': fetch, 'write_size_bytes_raw_per_step': write,
     'correction': 'gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE uncorrected; counters are L2 memory-side requests, Infinity-Cache hits included',
     'traffic_bytes_per_step': 2 * fetch + write,
     'dominant_trace': dominant,
+    'trace': trace,
     'kernels': KERNELS,          # hash of the kernel sources the profile was taken on: bench.py reports the figure only for the same sources
 }, indent=1))

@@ -199,6 +199,7 @@ class DataParallelRCCL(nn.Module):
         retain_graph) becomes a private copy before this pass's _fill rewrites the bucket."""
         if not self._pending:
             self._pending = True
+            self._count_step()          # (before this backward's first all-reduce: every rank's collective sequence is [tune broadcast,] bucket 0, bucket 1, ...)
             had = set()
             for q in self._params:
                 if q.grad is not None:
@@ -308,11 +309,14 @@ class DataParallelRCCL(nn.Module):
         # a backward that raised leaves the bookkeeping half-filled: start every step from a clean slate
         self._pending = False
         self._reset()
-        if not training:
-            # an evaluation / no_grad call through the wrapper (rank 0 alone summarising, train.py:209; an eval pass between epochs) is
-            # rank-local: it must not advance the schedule below, or that rank would enter the broadcast one step before the others do
-            # while they issue a gradient all-reduce on the same group
-            return
+        if training:
+            self._count_step()
+
+    def _count_step(self):
+        """One training step begins its collective sequence here (the first gradient event of a hook-path backward, or a StepPlan's graph_begin).  A forward
+        call is NOT a step: an evaluation / no_grad call through the wrapper (rank 0 alone summarising, train.py:209; an eval pass between epochs) is
+        rank-local and must not advance the schedule below, or that rank would enter the broadcast one step before the others do while they issue a gradient
+        all-reduce on the same group; an eval()-mode step that DOES back-propagate must advance it on every rank."""
         self._calls += 1
         if self.world > 1 and (self._calls in self.SYNC_TUNE_CALLS or self._calls % self.SYNC_TUNE_CALLS[-1] == 0):
             # the trigger is the wrapper's count of TRAINING steps and nothing else: every rank starts one training step per step, so every
@@ -376,7 +380,10 @@ class DataParallelRCCL(nn.Module):
                 self._views[id(p)] = g
 
     def forward(self, *args, **kwargs):
-        self._tick(training=self.module.training and torch.is_grad_enabled())
+        # forward() only cleans the bookkeeping.  What counts as a TRAINING step (and drives the tune exchange) is a BACKWARD that all-reduces - counted in
+        # _start(): an evaluation / no_grad / summary forward of one rank alone never reaches it, a differentiable eval()-mode step (frozen-BatchNorm
+        # fine-tuning, model.train_graph.darknet_forward_eval_grad) does, and every rank runs one such backward per step
+        self._tick(training=False)
         out = self.module(*args, **kwargs)
         # the region loss sums its positive count over THIS wrapper's group (model/__init__.py:162: mean over the positives of the
         # global batch): the reducer travels with the predictions (model.train_graph.DP_TAG)
@@ -458,11 +465,20 @@ class StepRunner(object):
         self.anchors, self.hparam, self.threshold = anchors, dict(hparam), float(threshold)
         self.plans = collections.OrderedDict()
         self.warm = {}
+        self.used = {}              # input shape -> (block, operand form) pairs the last eager pass of that shape read (StepPlan.used_last)
         self.pool = None
         self.shared_ops = {}        # prepared GEMM-operand buffers, one set for the plans of all input shapes (they replay serially; each rewrites what it reads)
         self.broken = None          # a capture failed for a reason other than memory: no more captures (steps keep running as eager plans)
         self.eager_only = set()     # shapes whose capture failed
         self.captures = 0
+
+    def _param_ids(self, dnn):
+        """ids of every parameter slot of the module tree as it was when the plans were made (a module ADDED later has no plan-side gradient either way:
+        the periodic full walk below catches it)."""
+        self._walks = getattr(self, '_walks', 0) + 1
+        if self._walks % 64 == 0 or getattr(self, '_mods_seen', None) is None:
+            self._mods_seen = [m for m in dnn.modules() if m._parameters]
+        return [id(p) for m in self._mods_seen for p in m._parameters.values()]
 
     def same(self, anchors, hparam, threshold):
         return anchors is self.anchors and dict(hparam) == self.hparam and float(threshold) == self.threshold
@@ -487,14 +503,16 @@ class StepRunner(object):
             # a plan snapshots the parameter list and writes EVERY gradient: a parameter frozen after the first step (requires_grad = False:
             # fine-tuning schedules) or replaced by another tensor must drop the plans, not keep receiving gradients.  requires_grad is one
             # attribute read per parameter per step; the identity of the list is re-derived every 32 steps (a module-tree walk)
-            self._params_age = getattr(self, '_params_age', 0) + 1
+            # attribute read per parameter per step; the identity of the list is re-derived every step from the modules' own _parameters dicts (no generator
+            # chain through named_modules: ~25 us for Darknet-19) - a replaced nn.Parameter must not leave even one step without its gradient
             ps = self._params_seen
-            if not all(p.requires_grad for p in ps) or (self._params_age % 32 == 0 and [id(p) for p in dnn.parameters()] != [id(p) for p in ps]):
+            if not all(p.requires_grad for p in ps) or self._param_ids(dnn) != self._params_ids_seen:
                 self.plans.clear()
                 ok = None
         if ok is None:
             ps = self._params_seen = list(dnn.parameters())
-            self._params_age = 0
+            self._mods_seen = [m for m in dnn.modules() if m._parameters]
+            self._params_ids_seen = self._param_ids(dnn)
             ok = all(p.requires_grad and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps)
             if ok and isinstance(dnn, _yolo2.Darknet) and not isinstance(dnn, _yolo2.Tiny):
                 ok = train_graph._pad_layout(dnn) is None           # pruned widths run zero-padded through host-side glue: autograd path
@@ -537,6 +555,7 @@ class StepRunner(object):
             plan = train_graph.StepPlan(self.inference, self.anchors, self.hparam, self.threshold, dp=self.dp, pool=self.pool, shared=self.shared_ops)
             plan._alloc(data, npad)
             plan.calls = self.warm.get(shape, 0)      # the per-layer measurements depend on the shape, not on the box count
+            plan.used_last = self.used.get(shape)     # ... and so do the operand forms the chosen algorithms read: a successor plan (more boxes, a new tune epoch) captures the pruned step too
             self.plans[key] = plan
             while len(self.plans) > self.MAX:
                 self.plans.popitem(last=False)
@@ -544,6 +563,8 @@ class StepRunner(object):
         self.warm[shape] = self.warm.get(shape, 0) + 1
         had_graph = plan.ops is not None
         out = plan.run(data, capture=GRAPH and not self.broken and shape not in self.eager_only)
+        if plan.used_last:
+            self.used[shape] = plan.used_last
         self.last = (npad, 'replay' if had_graph else ('capture' if plan.ops is not None else 'eager'))      # (tools/soak_multiscale.py reads it)
         if plan.capture_error is not None and shape not in self.eager_only:
             # the capture failed; the step itself ran (eagerly).  Out of memory: every captured step is dropped (their shared pool goes back to
