@@ -753,6 +753,16 @@ def multiscale_leg(args, ctx):
     import _hip
     first_visit, first_miss = {}, {}
     reserved0 = torch.cuda.memory_reserved() / 2.0 ** 30 if ctx.gpu else None
+    # the sizes are known up front (config.ini:39 `[data] sizes`): the training steps' activation arena is sized ONCE for the largest (nothing executes:
+    # train.reserve captures that size's step into the arena and drops it); reported, not part of any first visit
+    reserve_ms = None
+    if ctx.gpu and y2train.ARENA:
+        ctx.sync()
+        t0 = time.perf_counter()
+        y2train.reserve(m, data[max(sizes)], bench_data.HPARAM, bench_data.THRESHOLD, anchors)
+        ctx.sync()
+        reserve_ms = round((time.perf_counter() - t0) * 1e3, 1)
+    reserved1 = torch.cuda.memory_reserved() / 2.0 ** 30 if ctx.gpu else None
     for S in sizes:                      # untimed: first visit of every size
         ctx.sync()
         miss0 = len(_hip.TUNE_MISSES)
@@ -798,6 +808,7 @@ def multiscale_leg(args, ctx):
            'first_visit_shapes_measured': sum(first_miss.values()), 'first_visit_measured_keys': [list(map(str, k)) for k in _hip.TUNE_MISSES[-8:]] if sum(first_miss.values()) else [],
            'default_tune_table_entries': _hip._DEFAULTS_SEEN.get(str(ctx.dev)),
            'reserved_gib_before_after': [None if reserved0 is None else round(reserved0, 1), round(torch.cuda.memory_reserved() / 2.0 ** 30, 1) if ctx.gpu else None],
+           'arena_reserve_ms': reserve_ms, 'reserved_gib_after_reserve': None if reserved1 is None else round(reserved1, 1),
            'parallelism': 'dp%d' % ctx.world if ctx.world > 1 else 'single GPU', 'per_size': table}
     if per_img is not None:
         out['direct_equiv_tflops_per_gpu'] = round(per_img * B * len(schedule) / dt / 1e12, 2)
@@ -1285,7 +1296,8 @@ def main():
         if ok(ms):
             extra.update(multiscale_images_per_sec=ms['images_per_sec'], multiscale_ms_per_step_mean=ms['ms_per_step_mean'], multiscale_switch_cost_ms_max=ms['switch_cost_ms_max'],
                          multiscale_first_visit_ms_mean=ms['first_visit_ms_mean'], multiscale_first_visit_ms_max=ms.get('first_visit_ms_max'),
-                         multiscale_first_visit_shapes_measured=ms.get('first_visit_shapes_measured'))
+                         multiscale_first_visit_shapes_measured=ms.get('first_visit_shapes_measured'), multiscale_reserved_gib=(ms.get('reserved_gib_before_after') or [None, None])[1],
+                         multiscale_arena_reserve_ms=ms.get('arena_reserve_ms'))
         if droof is not None:
             for tag in ('split_bf16x6', 'split_f16x3'):
                 sp = droof.get(tag)

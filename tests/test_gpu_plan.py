@@ -182,6 +182,60 @@ def test_step_plans_per_input_size_and_box_count_share_one_pool():
             assert rel(a.grad, b.grad) <= 1e-3, (key, k, rel(a.grad, b.grad))
 
 
+def test_plans_of_all_sizes_live_in_one_activation_arena_sized_for_the_largest():
+    """configs[3] (utils/data.py:135-141 changes the size every `maintain` batches; config.ini:39 lists the sizes up front): train.reserve sizes the arena
+    for the largest size - nothing executes: weights, BatchNorm statistics and step counters are untouched - and afterwards neither the eager warm-up passes nor
+    the captures of ANY size grow the process's reserved memory by more than the static inputs / gradients a plan owns; results equal the arena-less path."""
+    import train as y2train
+    import utils
+    sizes = (96, 160, 224, 288)
+    data = {}
+    for S in sizes:
+        d = {k: v.to(dev()) for k, v in synth.labels(4, S, 20, nmax=6, seed=S).items()}
+        d['tensor'] = synth.images(4, S, seed=S).to(dev())
+        data[S] = d
+    runs = {}
+    for arena in (True, False):
+        y2train.ARENA = arena
+        try:
+            inf, anchors = build('darknet')
+            opt = utils.optim.SGD(inf.parameters(), 1e-3, momentum=0.9)
+            before = {k: v.clone() for k, v in inf.dnn.state_dict().items()}
+            if arena:
+                got = y2train.reserve(inf, data[max(sizes)], oloss.HPARAM, 0.6, anchors)
+                assert got is not None
+                torch.cuda.synchronize()
+                for k, v in inf.dnn.state_dict().items():
+                    assert torch.equal(v, before[k]), k                                   # a reservation executes nothing
+            torch.cuda.synchronize()
+            base = torch.cuda.memory_reserved()
+            losses = []
+            for S in sizes:                      # ascending: every size is larger than all before it - the order that used to grow the pool every time
+                for _ in range(5):
+                    losses.append(float(y2train.iterate(inf, opt, data[S], oloss.HPARAM, 0.6, anchors)['loss_total']))
+            for S in sizes:
+                losses.append(float(y2train.iterate(inf, opt, data[S], oloss.HPARAM, 0.6, anchors)['loss_total']))
+            torch.cuda.synchronize()
+            runner = inf.__dict__['_y2_step_runner']
+            assert runner.captures == len(sizes) and not runner.broken and not runner.eager_only
+            runs[arena] = (losses, torch.cuda.memory_reserved() - base, {k: v.clone() for k, v in inf.dnn.state_dict().items()})
+            if arena:
+                assert runner.arena is not None
+                # what may still be allocated per plan: its static image batch, label rows, result views and the gradient tensors (~2 x the model); never activations
+                own = sum(4 * 3 * S * S * 4 for S in sizes) + len(sizes) * 3 * sum(p.numel() * 4 for p in inf.parameters())
+                assert runs[arena][1] <= own + (64 << 20), (runs[arena][1], own)
+            del inf, opt, runner
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+        finally:
+            y2train.ARENA = True
+    np.testing.assert_allclose(np.array(runs[True][0]), np.array(runs[False][0]), rtol=3e-4)
+    for k, v in runs[True][2].items():
+        if v.dtype.is_floating_point:
+            assert rel(v, runs[False][2][k]) <= 2e-3, (k, rel(v, runs[False][2][k]))
+
+
 def test_eval_and_detect_see_the_weights_a_replayed_step_wrote():
     """The replayed graph updates parameters (through the eager optimizer) and BatchNorm buffers (inside the graph, raw pointers):
     the eval-mode caches must follow (version counters advanced per replay)."""

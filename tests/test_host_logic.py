@@ -109,8 +109,9 @@ def test_step_runner_keeps_one_plan_per_shape_and_degrades_per_shape(monkeypatch
     class FakePlan(object):
         WARM = 3
 
-        def __init__(self, inference, anchors, hparam, threshold, dp=None, pool=None, shared=None):
+        def __init__(self, inference, anchors, hparam, threshold, dp=None, pool=None, shared=None, arena=None, scope=None):
             self.ops, self.capture_error, self.calls, self.static, self.params, self.last_grads = None, None, 0, None, [], {}
+            self.used_last = None
             self.fail = None
             made.append(self)
 

@@ -177,8 +177,38 @@ def check(rc, what):
         raise RuntimeError('%s: %s' % (what, ERRORS.get(rc, rc)))
 
 
+_LAUNCH = None      # a torch.cuda.Stream the library's launches go to instead of torch's current stream (launch_on)
+
+
 def stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return c_void_p((_LAUNCH if _LAUNCH is not None else torch.cuda.current_stream()).cuda_stream)
+
+
+class launch_on(object):
+    """Library launches inside the block go to stream `s` while torch's CURRENT stream - the one the caching allocator tags new blocks with - stays what
+    it is.  The training backward forks its weight gradients this way: their kernels run on a side stream, what they write is allocated on the main
+    stream like everything else of the step, so a step's memory has ONE allocation stream (a freed block is reusable at once, by the next plan too: no
+    record_stream, no per-stream free lists in the step's arena).  The caller orders the two streams with events and keeps what the side stream reads
+    alive until the main stream has waited for it."""
+
+    def __init__(self, s):
+        self.s, self.prev = s, None
+
+    def __enter__(self):
+        global _LAUNCH
+        self.prev, _LAUNCH = _LAUNCH, self.s
+        return self.s
+
+    def __exit__(self, *exc):
+        global _LAUNCH
+        _LAUNCH = self.prev
+        return False
+
+
+def _timing_stream():
+    """Context for a block that TIMES launches with torch events: the events must sit on the stream the launches go to."""
+    import contextlib
+    return torch.cuda.stream(_LAUNCH) if _LAUNCH is not None else contextlib.nullcontext()
 
 
 def ptr(t):
@@ -294,9 +324,17 @@ def workspace(dev, nbytes):
     ws = _cache(_WS)
     t = ws.get(key)
     if t is None or t.numel() * 4 < nbytes:
+        _retire(t)
         t = torch.empty(max(int(nbytes) // 4 + 4, 1024), dtype=torch.float32, device=dev)
         ws[key] = t
     return t
+
+
+def _retire(t):
+    """A scratch buffer is being replaced by a larger one while a capture scope is active: graphs captured earlier into the same scope (the plans of other
+    input sizes share one, train.StepRunner) hold the OLD address - it stays alive with the scope."""
+    if t is not None and SCOPE is not None:
+        SCOPE.setdefault(('_hip', 'retired'), []).append(t)
 
 
 def conv_workspace(params, dev):
@@ -398,7 +436,7 @@ def load_tune_defaults(dev, path=None):
         try:
             import json as _json
             d = _json.load(open(path))
-            if d.get('kernels') is not None and d.get('kernels') == kernel_hash():
+            if d.get('kernels') is not None and (d.get('kernels') == kernel_hash() or os.environ.get('Y2_TUNE_STALE_OK') == '1'):      # (the override: development runs between a kernel edit and the table's regeneration)
                 for k, v in d['entries']:
                     kk = tuple(key if e == '@dev' else e for e in k)
                     if kk not in _TUNE:
@@ -743,11 +781,14 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
     if not eligible:
         direct()
         return dwp
-    need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
-    ws = _cache(_WGRAD_WS).get(str(dev))
-    if ws is None or ws.numel() * 4 < need:
-        ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=dev)
-        _cache(_WGRAD_WS)[str(dev)] = ws
+    ws = None
+    if choice != 0:      # (a layer whose measured choice is the direct kernel needs no Winograd scratch: the 208x208 layer alone would size it at 4-9 GB)
+        need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
+        ws = _cache(_WGRAD_WS).get(str(dev))
+        if ws is None or ws.numel() * 4 < need:
+            _retire(ws)
+            ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=dev)
+            _cache(_WGRAD_WS)[str(dev)] = ws
 
     def wino():
         check(L.y2_wino_wgrad(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, ptr(v), ptr(ws), ws.numel() * 4, st), 'y2_wino_wgrad')
@@ -759,16 +800,17 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
         else:
             times = []
             for fn in (direct, wino) + ((wino6,) if WGRAD_F34 else ()):
-                fn()
-                t = float('inf')
-                for _ in range(2):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
+                with _timing_stream():
                     fn()
-                    fn()
-                    e1.record()
-                    e1.synchronize()
-                    t = min(t, e0.elapsed_time(e1))
+                    t = float('inf')
+                    for _ in range(2):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        fn()
+                        fn()
+                        e1.record()
+                        e1.synchronize()
+                        t = min(t, e0.elapsed_time(e1))
                 times.append(t)
             if v is not None and H * W >= 52 * 52 and len(times) > 1:
                 # The 2x2-tile reduction reads the forward's transformed input V: choosing it makes the FORWARD of this layer keep V, i.e. run
@@ -781,7 +823,8 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
             TUNE_MISSES.append(key)
             _TUNE[key] = choice
             _tune_save()
-            dwp.zero_()          # the timing launches of the direct kernel accumulated into dwp
+            with _timing_stream():
+                dwp.zero_()          # the timing launches of the direct kernel accumulated into dwp
     (direct, wino, wino6)[choice]()
     return dwp
 

@@ -580,9 +580,10 @@ def _darknet_bwd(ctx, dout):
 
     def flush_weight_grads(keep=0):
         while len(late) > keep:
-            prm, g, evt = late.pop(0)
+            prm, g, evt, held = late.pop(0)
             if evt is not None:
                 main.wait_event(evt)
+            del held                 # (the main stream is behind the side stream's reads now: these blocks may be reused by what it launches next)
             ready(prm, g)
     for i in order:
         blk = blocks[i]
@@ -661,20 +662,21 @@ def _darknet_bwd(ctx, dout):
                 _hip.check(L.y2_unpack_weight_grad(_hip.ptr(tgt), _hip.ptr(dw), cop, cin, k, st_w), 'y2_unpack_weight_grad')
             return real(dw)
 
-        if side is not None:
+        if side is not None and not e.padded and (not blk.first or i in wg):       # (the rare paths above mix torch-native kernels in: not forked)
             ev = torch.cuda.Event()
             ev.record(main)                           # dz (and everything before it) is complete on the main stream
-            with torch.cuda.stream(side):
+            with _hip.launch_on(side):
+                # Kernels on the side stream, ALLOCATIONS on the main stream (torch's current stream does not change): the step's memory has one
+                # allocation stream, so nothing needs record_stream - whose deferred frees kept every activation of a captured step allocated until
+                # the capture ended (14 GB instead of ~8 at 416x416) and left the blocks of a shared arena in "pending free" limbo.  What the side
+                # stream reads stays referenced from `late` until the main stream has waited for this weight gradient (two layers on).
                 side.wait_event(ev)
                 gw = weight_grad(_hip.stream())
-                for tns in (dz, blk.x, blk.wino_v, ctx.x) + ((blk.z, sp) if fuse0 else ()):       # read on the side stream: the allocator must not recycle them under it
-                    if tns is not None:
-                        tns.record_stream(side)
                 done = torch.cuda.Event()
                 done.record(side)
-            gw.record_stream(main)
+            held = (dz, blk.x, blk.wino_v, ctx.x) + ((blk.z, sp) if fuse0 else ())
             flush_weight_grads(keep=1)
-            late.append([weight, gw, done])
+            late.append([weight, gw, done, held])
         else:
             ready(weight, weight_grad(st))
         blk.wino_v = None
@@ -1445,8 +1447,11 @@ class StepPlan(object):
     every later one replays.  Results are views of static buffers: valid until the next step."""
     WARM = 3
 
-    def __init__(self, inference, anchors, hparam, threshold, dp=None, pool=None, shared=None):
-        """shared: a dict owned by the caller (train.StepRunner) for the prepared GEMM-operand buffers: plans replay strictly one after the
+    def __init__(self, inference, anchors, hparam, threshold, dp=None, pool=None, shared=None, arena=None, scope=None):
+        """arena: a torch.cuda.MemPool owned by the caller (train.StepRunner) - the ONE activation arena of all its plans: the eager warm-up passes allocate from it
+        too (on the capture stream: the allocator reuses a freed block only on the stream that allocated it), so a plan's intermediates live in the memory the
+        previous plan's did (plans run strictly one after the other) instead of in a pool of their own next to the default allocator's cached copy of the same.
+        shared: a dict owned by the caller (train.StepRunner) for the prepared GEMM-operand buffers: plans replay strictly one after the
         other and every replay rewrites the operands it reads at its head, so the plans of all input sizes can use ONE set of buffers
         (ten multi-scale sizes would otherwise hold ten copies: ~1 GB each)."""
         import model
@@ -1456,8 +1461,12 @@ class StepPlan(object):
         self.darknet = isinstance(self.dnn, _yolo2.Darknet) and not isinstance(self.dnn, _yolo2.Tiny)
         self.params = [p for p in self.dnn.parameters()]
         self.buffers = [b for b in self.dnn.buffers()]
-        self.pool = pool if pool is not None else torch.cuda.graph_pool_handle()       # all segments (and, shared by the runner, all shapes) allocate from one pool
-        self.scope = {}
+        self.arena = arena
+        self.pool = arena.id if arena is not None else (pool if pool is not None else torch.cuda.graph_pool_handle())       # all segments (and, shared by the runner, all shapes) allocate from one pool
+        # scope: what a captured step holds by address besides its intermediates - kernel scratch (_hip.SCOPE), the packed staging of the 3x3 weight gradients,
+        # cached constants.  None: private to this plan.  The runner of an arena hands ONE dict to all its plans: none of it depends on the input size except
+        # the scratch, which only ever grows (a replaced buffer stays alive in the dict: _hip._retire) - ten sizes hold one set, not ten
+        self.scope = scope if scope is not None else {}
         self.shared = shared if shared is not None else self.scope
         self.used_last = None       # (block, operand form) pairs the last eager pass read: what the captured step prepares
         self.only = None
@@ -1518,7 +1527,12 @@ class StepPlan(object):
                 return dp.graph_slot(p)
             t = grads.get(('dest', id(p)))
             if t is None:
-                t = grads[('dest', id(p))] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                # with an arena the gradient tensors are the runner's, one set for the plans of all sizes (p.grad is the same tensor whatever size ran last)
+                home = self.scope if self.arena is not None else grads
+                t = home.get(('dest', id(p)))
+                if t is None:
+                    t = home[('dest', id(p))] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                grads[('dest', id(p))] = t
             return t
 
         def ready(p, g):
@@ -1647,6 +1661,19 @@ class StepPlan(object):
                 torch.cuda.synchronize()
         if self.ops is None or not capture:          # (capture=False with a captured plan: this one step launch by launch - per-kernel event tables)
             grads = {}
+            if self.arena is not None:
+                # an eager pass in the arena: on the capture stream (see __init__), joined with the caller's stream on both sides
+                cur, side = torch.cuda.current_stream(), _capture_stream(self.static['x'].device)
+                side.wait_stream(cur)
+                prev_scope, _hip.SCOPE = _hip.SCOPE, self.scope          # kernel scratch: the captured steps' own (one set, at its largest size once the arena is reserved)
+                try:
+                    with torch.cuda.stream(side), torch.cuda.use_mem_pool(self.arena):
+                        result, launched = self._chain(None, grads)
+                        self._finish(grads, launched)
+                finally:
+                    _hip.SCOPE = prev_scope
+                cur.wait_stream(side)
+                return result
             result, launched = self._chain(None, grads)
             self._finish(grads, launched)
             return result

@@ -303,7 +303,7 @@ class DataParallelRCCL(nn.Module):
             self._pending = False
             self._reset()
 
-    def _tick(self, training=True):
+    def _tick(self, training=False):
         """Start of a step (forward() or a StepPlan's graph_begin): clean bookkeeping and - for TRAINING steps only - the step count and the
         tune exchange it triggers."""
         # a backward that raised leaves the bookkeeping half-filled: start every step from a clean slate
@@ -329,7 +329,7 @@ class DataParallelRCCL(nn.Module):
     # plan writes every gradient into its bucket slice and tells the wrapper where the segments end.  Collectives, their order and their
     # payloads are those of the hook path - a rank replaying a graph and a rank still warming up on another input size match.
     def graph_begin(self):
-        self._tick()
+        self._tick(training=False)          # (the step is counted where the hook path counts it: in front of the first bucket's all-reduce, graph_launch)
 
     def graph_slot(self, p):
         w = self._where.get(id(p))
@@ -345,6 +345,10 @@ class DataParallelRCCL(nn.Module):
         """All-reduce buckets lo .. hi-1 (complete on this rank), in index order."""
         for bi in range(lo, hi):
             assert bi == self._next, (bi, self._next)
+            if bi == 0:
+                # the same point of the collective sequence as _start() on the hook path - behind the loss's positive-count all-reduce, in front of bucket 0 - so
+                # a rank replaying graph segments and a rank on the hook path meet the tune broadcast at the same place
+                self._count_step()
             flat = self._flat[bi]
             flat[flat.numel() - len(self._buckets[bi]):].fill_(1.0)
             self._works[bi] = self._all_reduce(flat)
@@ -467,10 +471,93 @@ class StepRunner(object):
         self.warm = {}
         self.used = {}              # input shape -> (block, operand form) pairs the last eager pass of that shape read (StepPlan.used_last)
         self.pool = None
+        self.arena = None           # torch.cuda.MemPool: the one activation arena of all plans (Y2_TRAIN_ARENA=0: a graph pool per capture generation, as before)
+        self.shared_scope = {}      # with an arena: kernel scratch / gradient staging / constants of the captured steps, one set for all plans (StepPlan.scope)
         self.shared_ops = {}        # prepared GEMM-operand buffers, one set for the plans of all input shapes (they replay serially; each rewrites what it reads)
         self.broken = None          # a capture failed for a reason other than memory: no more captures (steps keep running as eager plans)
         self.eager_only = set()     # shapes whose capture failed
         self.captures = 0
+
+    def _new_plan(self):
+        from model import train_graph
+        if ARENA and self.arena is None:
+            try:
+                self.arena = torch.cuda.MemPool()       # lives as long as this runner: the plans of all input shapes (eager passes and captures alike) allocate from it
+            except Exception as e:                      # (an allocator without pools: every plan falls back to the graph-pool handle below)
+                logging.warning('training-step arena unavailable (%s: %s)' % (type(e).__name__, e))
+                self.arena = False
+        if not self.arena and (self.pool is None or not any(p.ops is not None for p in self.plans.values())):
+            # (a bare pool handle lives as long as a graph captured into it: once the last one is gone it is dead - torch asserts on reuse)
+            self.pool = torch.cuda.graph_pool_handle()
+        return train_graph.StepPlan(self.inference, self.anchors, self.hparam, self.threshold, dp=self.dp, pool=self.pool, shared=self.shared_ops, arena=self.arena or None,
+                                    scope=self.shared_scope if self.arena else None)
+
+    def reserve(self, data, plans=10, margin=1.03):
+        """Size the activation arena ONCE for the largest problem shape the job will meet (`[data] sizes` lists them up front, /root/reference/config.ini:39;
+        utils/data.py:135-141 changes the size every `maintain` batches): `data` = a batch of that shape (only shapes matter: NOTHING EXECUTES - weights,
+        BatchNorm statistics and step counters are untouched).  `plans`: how many input sizes will follow (each keeps its static inputs and results).
+          1. the step is captured into a throw-away pool: what that pool ends up holding is the step's footprint P (intermediates at their high-water mark,
+             kernel scratch, GEMM operands); capture and pool are dropped;
+          2. the arena gets ONE allocation of margin * P + the plans' own tensors, freed at once: a single segment, so the plans of every size carve their
+             intermediates from it and the pieces coalesce again when a capture ends (separately grown segments never merge: ten sizes met in ascending order
+             held 224 GiB, and 71 GiB with per-tensor growth from a first capture, for a 23 GiB working set);
+          3. the step is captured once more, into the arena and the plans' shared scope: scratch and operand buffers exist at their largest size from here on.
+        Without a reservation the arena grows as larger sizes arrive.  Returns the arena's bytes (None: no arena / not eligible / a capture failed)."""
+        import gc
+
+        import model
+        from model import train_graph
+        if not self.eligible(data) or not GRAPH:
+            return None
+        self._new_plan()          # (creates the arena)
+        if not self.arena:
+            return None
+        n = data['yx_min'].shape[1]
+        npad = 16
+        while npad < n:
+            npad *= 2
+        # the step's small host-to-device constants are made on first use and cached - a copy no capture may contain (the eager warm-up passes of an ordinary
+        # plan make them; here nothing runs first): anchors, the loss weights as the chain orders them
+        dev = data['tensor'].device
+        model._device_anchors(self.anchors, dev)
+        base = ['foreground', 'background', 'center', 'size']
+        for keys in (base, base + ['cls']):           # (single-class heads have no cls term: both forms of the weight vector, a few bytes each)
+            if all(k in self.hparam for k in keys):
+                train_graph._hparam_tensor(tuple(float(self.hparam[k]) for k in keys) + (0.0,) * (5 - len(keys)), dev)
+
+        def pool_bytes(pool):
+            return sum(seg['total_size'] for seg in torch.cuda.memory_snapshot() if tuple(seg.get('segment_pool_id', ())) == tuple(pool.id))
+
+        def capture(arena, scope, shared):
+            plan = train_graph.StepPlan(self.inference, self.anchors, self.hparam, self.threshold, dp=self.dp, shared=shared, arena=arena, scope=scope)
+            plan._alloc(data, npad)
+            plan._load(data)
+            plan._capture()          # (under the data-parallel wrapper too: a capture issues no collective, it only notes where they belong)
+            torch.cuda.synchronize()
+            own = sum(t.numel() * t.element_size() for t in plan.static.values() if isinstance(t, torch.Tensor))
+            return own
+        try:
+            probe = torch.cuda.MemPool()
+            own = capture(probe, {}, {})
+            gc.collect()
+            need = pool_bytes(probe)
+            del probe
+            gc.collect()
+            torch.cuda.empty_cache()
+            params = sum(p.numel() * p.element_size() for p in self.inference.parameters())
+            # (a plan's static inputs and the operand buffers are ordinary allocations outside the arena; inside it a plan keeps its result views: ~0.1 GB)
+            slab_bytes = int(margin * need) + max(0, plans - 1) * (128 << 20) + params
+            with torch.cuda.stream(train_graph._capture_stream(dev)), torch.cuda.use_mem_pool(self.arena):
+                slab = torch.empty(slab_bytes, dtype=torch.uint8, device=dev)          # ONE segment ...
+                del slab                                                                # ... of free arena from here on
+            capture(self.arena, self.shared_scope, self.shared_ops)
+            gc.collect()
+        except Exception as e:          # never fatal: the arena then grows as the sizes arrive
+            logging.warning('training-step arena not reserved (%s: %s)' % (type(e).__name__, str(e)[:200]))
+            torch.cuda.synchronize()
+            return None
+        self.reserved = dict(step_bytes=need, slab_bytes=slab_bytes)
+        return pool_bytes(self.arena)
 
     def _param_ids(self, dnn):
         """ids of every parameter slot of the module tree as it was when the plans were made (a module ADDED later has no plan-side gradient either way:
@@ -549,10 +636,7 @@ class StepRunner(object):
             for k in mine:
                 del self.plans[k]
             key = shape + (npad,) + tail
-            if self.pool is None or not any(p.ops is not None for p in self.plans.values()):
-                # (a pool lives as long as a graph captured into it: once the last one is gone its handle is dead - torch asserts on reuse)
-                self.pool = torch.cuda.graph_pool_handle()
-            plan = train_graph.StepPlan(self.inference, self.anchors, self.hparam, self.threshold, dp=self.dp, pool=self.pool, shared=self.shared_ops)
+            plan = self._new_plan()
             plan._alloc(data, npad)
             plan.calls = self.warm.get(shape, 0)      # the per-layer measurements depend on the shape, not on the box count
             plan.used_last = self.used.get(shape)     # ... and so do the operand forms the chosen algorithms read: a successor plan (more boxes, a new tune epoch) captures the pruned step too
@@ -585,6 +669,7 @@ class StepRunner(object):
         return out
 
 
+ARENA = os.environ.get('Y2_TRAIN_ARENA', '1') != '0'      # 0: no shared activation arena (A/B)
 PLAN = os.environ.get('Y2_TRAIN_PLAN', '1') != '0'      # 0: iterate never uses StepPlans (not even eagerly): the reference's three autograd calls
 
 
@@ -596,6 +681,14 @@ def _runner(inference, anchors, hparam, threshold):
         r = StepRunner(inner, dp, anchors, hparam, threshold)
         inner.__dict__['_y2_step_runner'] = r
     return r
+
+
+def reserve(inference, data, loss_hparam, threshold, anchors):
+    """Before the first step of a multi-scale job: size the training steps' activation arena for the LARGEST input size (`data`: a batch of that shape, e.g. the
+    first batch resized like the collate function does - nothing executes, StepRunner.reserve).  Optional: without it the arena grows as larger sizes arrive."""
+    if not (PLAN and isinstance(data.get('tensor'), torch.Tensor) and data['tensor'].is_cuda):
+        return None
+    return _runner(inference, anchors, loss_hparam, threshold).reserve(data)
 
 
 def iterate(inference, optimizer, data, loss_hparam, threshold, anchors, clip=None):
