@@ -727,7 +727,8 @@ def test_eval_matching_like_reference():
     assert ev.matching(torch.zeros(0, 2, device=d), torch.zeros(0, 2, device=d), torch.from_numpy(p_min).to(d), torch.from_numpy(p_max).to(d), 0.5).sum() == 0
 
 
-@pytest.mark.parametrize('B,cin,cout,H,W', [(2, 64, 32, 13, 13), (1, 128, 64, 26, 26), (3, 32, 48, 7, 10), (2, 512, 256, 13, 13), (1, 16, 20, 4, 4), (2, 8, 12, 1, 3)])
+@pytest.mark.parametrize('B,cin,cout,H,W', [(2, 64, 32, 13, 13), (1, 128, 64, 26, 26), (3, 32, 48, 7, 10), (2, 512, 256, 13, 13), (1, 16, 20, 4, 4), (2, 8, 12, 1, 3),
+                                            (11, 16, 24, 13, 13), (9, 8, 8, 13, 11), (16, 12, 8, 26, 26)])      # (the last three: mosaic tile grids - 2 x 6 with a missing image, 3 x 3, 4 x 4)
 def test_conv_fwd_winograd_f43_for_gradients(B, cin, cout, H, W):
     """Y2_ALGO_WINOGRAD_F43 (Winograd F(4x4,3x3), three kernels, 36 GEMMs; offered to the training step's data gradients): against the fp64
     reference at the single-Winograd-layer tolerance (its larger transform constants: ~1e-5 x rms instead of ~2e-6), ragged 4x4 tiles,

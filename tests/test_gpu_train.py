@@ -60,7 +60,7 @@ def test_conv_wgrad_and_dgrad(B, cin, cout, H, W, k):
     assert rel(dx.permute(0, 3, 1, 2), x.grad) <= TOL
 
 
-@pytest.mark.parametrize('B,cin,cout,H,W', [(2, 32, 64, 8, 12), (3, 256, 128, 13, 13), (1, 128, 256, 26, 26), (2, 40, 72, 7, 5), (4, 512, 1024, 13, 13)])
+@pytest.mark.parametrize('B,cin,cout,H,W', [(2, 32, 64, 8, 12), (3, 256, 128, 13, 13), (1, 128, 256, 26, 26), (2, 40, 72, 7, 5), (4, 512, 1024, 13, 13), (11, 16, 24, 13, 13), (9, 8, 12, 13, 11)])
 def test_winograd_wgrad_and_dgrad(B, cin, cout, H, W):
     """y2_wino_wgrad (16 grouped reductions over tiles) and the Winograd data gradient (algo = 1 on the rotated filter)
     against fp64 autograd; odd sizes exercise the ragged last tile row / column."""

@@ -1318,26 +1318,34 @@ struct Wino6Args {
     float* dst;           // [36][T][C]
     int B, H, W, C, ld, th, tw, T;
     y2_fastdiv d_c, d_tt, d_tw;
-    int tall;             // 0, or H + 1: "tall" tiling (see Wino6Grid)
-    y2_fastdiv d_tall;
+    int tall, wide, gx;   // 0, or H + 1 / W + 1 / images per mosaic row: "mosaic" tiling (see Wino6Grid)
+    y2_fastdiv d_tall, d_wide;
 };
 
 // Tile grid of the 4x4-tile forms.  Per image, a map of H rows takes ceil(H / 4) tile rows: 13 rows pay for 16 (the 13x13 layers at 416x416: 34 % of the
-// multiply-adds of their 36 GEMMs are spent on rows and columns that do not exist).  "Tall" tiling stacks the batch's images into ONE image of B * (H + 1) - 1
-// rows with a single zero row between neighbours - that row IS the bottom padding of the image above and the top padding of the image below, so every 3x3
-// neighbourhood of the tall image is the neighbourhood of its own image - and cuts THAT into tile rows: 64 x 14 - 1 = 895 rows = 224 tile rows instead of 256
-// (13x13: T 1024 -> 896, -12.5 %; 26x26: -3.6 %).  Only the tile -> pixel maps of the three transform kernels change (tall row r -> image r / (H + 1), row
-// r % (H + 1), a row H does not exist: reads give zero, writes are dropped); the GEMMs see fewer rows.  Chosen when it makes T smaller (Y2_WINO6_TALL=0: never).
-struct Wino6Grid { int th, tw, tall; long long T; };
+// multiply-adds of their 36 GEMMs are spent on rows and columns that do not exist).  "Mosaic" tiling lays the batch's images out as ONE image - gy rows of gx
+// images with a single zero row / zero column between neighbours; that line IS the bottom (right) padding of one image and the top (left) padding of the next,
+// so every 3x3 neighbourhood of the mosaic is the neighbourhood of its own image - and cuts THAT into 4x4 tiles: 64 images of 13x13 as 8 x 8 -> 111 x 111
+// pixels -> 28 x 28 = 784 tiles instead of 64 x 16 = 1024 (-23 %; 26x26: 3136 -> 2916).  Only the tile -> pixel maps of the three transform kernels change
+// (mosaic row r -> image row r / (H + 1), pixel row r % (H + 1); a row H does not exist: reads give zero, writes are dropped; columns alike); the GEMMs see
+// fewer rows.  gx is chosen to minimise the tile count; the per-image grid stays when nothing is smaller (Y2_WINO6_TALL=0: always).
+struct Wino6Grid { int th, tw, tall, wide, gx; long long T; };
 inline Wino6Grid wino6_grid(int B, int H, int W) {
     static const bool allow = getenv("Y2_WINO6_TALL") == nullptr || atoi(getenv("Y2_WINO6_TALL")) != 0;
     Wino6Grid g;
     g.tw = (W + 3) / 4;
     g.th = (H + 3) / 4;
-    g.tall = 0;
+    g.tall = g.wide = 0;
+    g.gx = 1;
     g.T = (long long)B * g.th * g.tw;
-    const long long rows = (long long)B * (H + 1) - 1, tht = (rows + 3) / 4;
-    if (allow && tht * g.tw < g.T && rows < 0x7fffffff) { g.tall = H + 1; g.th = (int)tht; g.T = tht * g.tw; }
+    if (!allow) return g;
+    for (int gx = 1; gx <= B && gx <= 4096; ++gx) {
+        const long long gy = (B + gx - 1) / gx;
+        const long long rows = gy * (H + 1) - 1, cols = (long long)gx * (W + 1) - 1;
+        const long long th = (rows + 3) / 4, tw = (cols + 3) / 4;
+        if (rows >= 0x7fffffff || cols >= 0x7fffffff) continue;
+        if (th * tw < g.T) { g.T = th * tw; g.th = (int)th; g.tw = (int)tw; g.tall = H + 1; g.wide = gx > 1 ? W + 1 : 0; g.gx = gx; }
+    }
     return g;
 }
 
@@ -1353,7 +1361,7 @@ __global__ __launch_bounds__(256) void wino6_in_kernel(const Wino6Args a) {
     if (t >= (uint32_t)a.T) return;
     const int c = (int)(idx - t * (uint32_t)a.C);
     int b = 0, ty, tx;
-    if (a.tall) {                      // tile rows run over the stacked batch (Wino6Grid)
+    if (a.tall) {                      // tiles of the batch's mosaic (Wino6Grid)
         ty = (int)y2_div(t, a.d_tw);
         tx = (int)t - ty * a.tw;
     } else {
@@ -1363,21 +1371,35 @@ __global__ __launch_bounds__(256) void wino6_in_kernel(const Wino6Args a) {
         tx = r - ty * a.tw;
     }
     const int y0 = 4 * ty - (GRAD ? 0 : 1), x0 = 4 * tx - (GRAD ? 0 : 1);
+    int colx[NI], colb[NI];            // pixel column and image-within-mosaic-row of the patch's columns (colx < 0: no such pixel)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        int xx = x0 + j, bx = 0;
+        bool ok = (unsigned)xx < (unsigned)a.W;
+        if (a.wide) {
+            ok = (unsigned)xx < (unsigned)(a.gx * a.wide);
+            bx = ok ? (int)y2_div((uint32_t)xx, a.d_wide) : 0;
+            xx -= bx * a.wide;
+            ok = ok && xx < a.W;
+        }
+        colx[j] = ok ? xx : -1;
+        colb[j] = bx;
+    }
     float d[NI][NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        int yy = y0 + i, bb = b;
+        int yy = y0 + i, by = 0;
         bool rowok = (unsigned)yy < (unsigned)a.H;
         if (a.tall) {
-            rowok = (unsigned)yy < (unsigned)(a.B * a.tall);
-            bb = rowok ? (int)y2_div((uint32_t)yy, a.d_tall) : 0;
-            yy -= bb * a.tall;
+            rowok = yy >= 0;
+            by = rowok ? (int)y2_div((uint32_t)yy, a.d_tall) : 0;
+            yy -= by * a.tall;
             rowok = rowok && yy < a.H;
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int xx = x0 + j;
-            d[i][j] = (rowok && (unsigned)xx < (unsigned)a.W) ? a.src[((size_t)(bb * a.H + yy) * a.W + xx) * a.ld + c] : 0.f;
+            const int bb = a.tall ? by * a.gx + colb[j] : b;
+            d[i][j] = (rowok && colx[j] >= 0 && bb < a.B) ? a.src[((size_t)(bb * a.H + yy) * a.W + colx[j]) * a.ld + c] : 0.f;
         }
     }
     float sm[6][NI];               // rows transformed
@@ -1497,8 +1519,8 @@ struct Wino6OutArgs {
     int B, H, W, C, ldy, coff, th, tw, T;
     float slope;
     y2_fastdiv d_c, d_tt, d_tw;
-    int tall;             // see Wino6Grid
-    y2_fastdiv d_tall;
+    int tall, wide, gx;   // see Wino6Grid
+    y2_fastdiv d_tall, d_wide;
 };
 
 __global__ __launch_bounds__(256) void wino6_out_kernel(const Wino6OutArgs a) {
@@ -1534,15 +1556,28 @@ __global__ __launch_bounds__(256) void wino6_out_kernel(const Wino6OutArgs a) {
                 if (AT[i][u] != 0.f) s[i][v] += AT[i][u] * x;
         }
     const float sc = a.scale != nullptr ? a.scale[c] : 1.f, sh = a.shift != nullptr ? a.shift[c] : 0.f;
+    int colx[4], colb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int xx = 4 * tx + j, bx = 0;
+        bool ok = xx < a.W;
+        if (a.wide) {
+            ok = xx < a.gx * a.wide;
+            bx = ok ? (int)y2_div((uint32_t)xx, a.d_wide) : 0;
+            xx -= bx * a.wide;
+            ok = ok && xx < a.W;
+        }
+        colx[j] = ok ? xx : -1;
+        colb[j] = bx;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int yy = 4 * ty + i, bb = b;
+        int yy = 4 * ty + i, by = 0;
         bool rowok = yy < a.H;
         if (a.tall) {
-            rowok = yy < a.B * a.tall;
-            bb = rowok ? (int)y2_div((uint32_t)yy, a.d_tall) : 0;
-            yy -= bb * a.tall;
-            rowok = rowok && yy < a.H;
+            by = (int)y2_div((uint32_t)yy, a.d_tall);
+            yy -= by * a.tall;
+            rowok = yy < a.H;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1550,10 +1585,10 @@ __global__ __launch_bounds__(256) void wino6_out_kernel(const Wino6OutArgs a) {
 #pragma unroll
             for (int q = 0; q < 6; ++q)
                 if (AT[j][q] != 0.f) v += AT[j][q] * s[i][q];
-            const int xx = 4 * tx + j;
-            if (rowok && xx < a.W) {
+            const int bb = a.tall ? by * a.gx + colb[j] : b;
+            if (rowok && colx[j] >= 0 && bb < a.B) {
                 const float uu = v * sc + sh;
-                a.y[((size_t)(bb * a.H + yy) * a.W + xx) * a.ldy + a.coff + c] = uu > 0.f ? uu : uu * a.slope;
+                a.y[((size_t)(bb * a.H + yy) * a.W + colx[j]) * a.ldy + a.coff + c] = uu > 0.f ? uu : uu * a.slope;
             }
         }
     }
@@ -1614,7 +1649,8 @@ int y2_internal_wino6_conv(const y2_conv_params* p, y2_stream_t stream, size_t* 
     Wino6Args ia;
     ia.B = p->B; ia.H = p->H; ia.W = p->W; ia.th = th; ia.tw = tw; ia.T = (int)T;
     ia.d_tt = y2_make_fastdiv((uint32_t)(th * tw)); ia.d_tw = y2_make_fastdiv((uint32_t)tw);
-    ia.tall = g6.tall; ia.d_tall = y2_make_fastdiv((uint32_t)(g6.tall > 0 ? g6.tall : 1));
+    ia.tall = g6.tall; ia.wide = g6.wide; ia.gx = g6.gx;
+    ia.d_tall = y2_make_fastdiv((uint32_t)(g6.tall > 0 ? g6.tall : 1)); ia.d_wide = y2_make_fastdiv((uint32_t)(g6.wide > 0 ? g6.wide : 1));
     ia.src = p->x; ia.dst = V; ia.C = p->Cin; ia.ld = p->ldx; ia.d_c = y2_make_fastdiv((uint32_t)p->Cin);
     Y2_LAUNCH("wino6_in_kernel", 0.0, wino6_in_kernel<false>, dim3((unsigned)y2_cdiv(T * p->Cin, 256)), dim3(256), 0, s, ia);
     q.x = V; q.w = p->w; q.y = M;
@@ -1625,7 +1661,7 @@ int y2_internal_wino6_conv(const y2_conv_params* p, y2_stream_t stream, size_t* 
     Wino6OutArgs oa;
     oa.m = M; oa.scale = p->scale; oa.shift = p->shift; oa.y = p->y;
     oa.B = p->B; oa.H = p->H; oa.W = p->W; oa.C = p->Cout; oa.ldy = p->ldy; oa.coff = p->coff; oa.th = th; oa.tw = tw; oa.T = (int)T; oa.slope = p->slope;
-    oa.d_c = y2_make_fastdiv((uint32_t)p->Cout); oa.d_tt = ia.d_tt; oa.d_tw = ia.d_tw; oa.tall = ia.tall; oa.d_tall = ia.d_tall;
+    oa.d_c = y2_make_fastdiv((uint32_t)p->Cout); oa.d_tt = ia.d_tt; oa.d_tw = ia.d_tw; oa.tall = ia.tall; oa.wide = ia.wide; oa.gx = ia.gx; oa.d_tall = ia.d_tall; oa.d_wide = ia.d_wide;
     Y2_LAUNCH("wino6_out_kernel", 0.0, wino6_out_kernel, dim3((unsigned)y2_cdiv(T * p->Cout, 256)), dim3(256), 0, s, oa);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
@@ -1908,7 +1944,8 @@ static int wino6_wgrad(const float* x, const float* dz, float* dw, int B, int H,
     Wino6Args a;
     a.B = B; a.H = H; a.W = W; a.th = th; a.tw = tw; a.T = (int)T;
     a.d_tt = y2_make_fastdiv((uint32_t)(th * tw)); a.d_tw = y2_make_fastdiv((uint32_t)tw);
-    a.tall = g6.tall; a.d_tall = y2_make_fastdiv((uint32_t)(g6.tall > 0 ? g6.tall : 1));
+    a.tall = g6.tall; a.wide = g6.wide; a.gx = g6.gx;
+    a.d_tall = y2_make_fastdiv((uint32_t)(g6.tall > 0 ? g6.tall : 1)); a.d_wide = y2_make_fastdiv((uint32_t)(g6.wide > 0 ? g6.wide : 1));
     a.src = x; a.dst = V; a.C = Cin; a.ld = ldx; a.d_c = y2_make_fastdiv((uint32_t)Cin);
     Y2_LAUNCH("wino6_in_kernel", 0.0, wino6_in_kernel<false>, dim3((unsigned)y2_cdiv(T * Cin, 256)), dim3(256), 0, s, a);
     a.src = dz; a.dst = DM; a.C = Cout; a.ld = ldz; a.d_c = y2_make_fastdiv((uint32_t)Cout);
