@@ -92,7 +92,7 @@ def test_training_step_at_unaligned_channel_counts(widths, bn):
     w.update(widths)
     # (seed 1 for the bias-only net at the 'early' widths: seed 0 draws a layers1.9 pre-activation of 1.2e-7 there, whose LeakyReLU branch
     # differs between fp32 and fp64 - one flipped element of a 432-pixel map moves that layer's weight gradient by 20 % of its rms;
-    # tools/debug/taps.py shows every kernel of the block exact on its own inputs)
+    # a per-block tap (train_graph.DEBUG_TAP) showed every kernel of the block exact on its own inputs)
     sd = odark.init_state_dict(5, 20, seed=1 if (not bn and 'layers1.16' in widths and 'layers1.0' in widths) else 0, channels=w, head_scale=1 / 8.0, bn=bn)
     inf, anchors = build(sd, bn=bn)
     inf.train()

@@ -1911,8 +1911,8 @@ extern "C" int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, 
 }
 
 // Zero fill of the split accumulators by a KERNEL, not hipMemsetAsync: captured into a hipGraph in front of the kernels that accumulate into the buffer,
-// the memset node did its job at the graph's first launch and not at the later ones on this runtime (ROCm 7.0 / 7.2: tools/debug/replay_wgrad.py - every
-// later replay accumulated onto whatever the scratch held; a memset node with nothing behind it replays fine, tools/debug/replay_memcpy.py, so it is the
+// the memset node did its job at the graph's first launch and not at the later ones on this runtime (ROCm 7.0 / 7.2: a round-4 replay probe, docs/history - every
+// later replay accumulated onto whatever the scratch held; a memset node with nothing behind it replays fine, same probe, so it is the
 // ordering against the following kernel nodes that is lost).  The training step is a replayed graph (model.train_graph.StepPlan).
 __global__ void zero_fill_kernel(float4* __restrict__ p, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);

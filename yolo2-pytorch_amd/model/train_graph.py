@@ -46,7 +46,7 @@ def _side_stream(dev):
 GRAPH_FORK = {'1': True, '0': False}.get(os.environ.get('Y2_GRAPH_FORK', 'auto'), 'auto')
 GRAD_F43 = os.environ.get('Y2_GRAD_F43', '1') != '0'        # offer Winograd F(4x4,3x3) to the data gradients of the deep layers (A/B)
 FUSE_CONV0 = os.environ.get('Y2_FUSE_CONV0', '1') != '0'      # 0: materialise the first layer's dz and run the two-kernel form (A/B runs)
-DEBUG_TAP = None        # tools/debug: callable(block name, dz, dx) invoked per block of the Darknet backward
+DEBUG_TAP = None        # debugging hook: callable(block name, dz, dx) invoked per block of the Darknet backward
 
 SYNC_POSITIVES = True   # data parallel: all-reduce the positive count so the cls mean is over the global batch
 
