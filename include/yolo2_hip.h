@@ -158,6 +158,8 @@ typedef struct y2_conv_params {
                                       F(2x2,3x3) on even maps; w = y2_wino6_weight output [36][Cout][Cin]; y only (no pool / statistics).  Error 8-9e-6 x rms
                                       per layer in an fp32 model (F(2x2,3x3): 1.3e-6): meant for GRADIENTS (the training step's data gradients), not
                                       for the inference path, whose tolerance it would use up */
+#define Y2_ALGO_WINOGRAD_F43_PRE 7 /* as F43, but x IS the transformed input [36][T][Cin] (ldx == Cin, T = y2_wino6_tiles(B, H, W)), written by
+                                      y2_bn_act_bwd_wino6: no input-transform launch, no transformed input in the workspace */
 #define Y2_ALGO_WINOGRAD_SPLIT_F16 5 /* as SPLIT with fp16 plane PAIRS (hi = fp16(s x), lo = fp16(s x - hi): 2 x 11 bits + the residual's sign) and three
                                       products (hi x hi, hi x lo, lo x hi): half the matrix instructions and 4 instead of 6 operand bytes of SPLIT.
                                       fp16 has 5 exponent bits: the operands carry fixed power-of-two scales (V x 2^-4, w x 2^8 - pass 256 to
@@ -200,7 +202,8 @@ int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, int32_t B, 
 /* ... native_layout bit 0: the result is written as dw[Cout][Cin][3][3] - nn.Conv2d.weight.grad's own layout (model/yolo2.py:57), no
  * y2_unpack_weight_grad pass behind it.  Bit 1: Winograd F(3x3, 4x4) - 36 reductions over 4x4 gradient tiles (1.78x fewer multiply-adds than
  * the 2x2 form on even maps); needs x (not v_transformed); its larger transform constants cost accuracy (1.2-1.4e-5 x rms of the gradient in
- * fp32 against 2.7e-6): for weight gradients only. */
+ * fp32 against 2.7e-6): for weight gradients only.  Bit 2 (with bit 1): `dz` IS the transformed gradient [36][T][Cout] that
+ * y2_bn_act_bwd_wino6 wrote (T = y2_wino6_tiles(B, H, W)); ldz is ignored. */
 int y2_wino_wgrad_ex(const float* x, const float* dz, float* dw, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t ldx,
                      int32_t Cout, int32_t ldz, const float* v_transformed, float* workspace, long long workspace_bytes, int32_t native_layout,
                      y2_stream_t stream);
@@ -401,6 +404,20 @@ int y2_bn_act_bwd_ex(const float* z, const float* scale, const float* shift, con
                      float slope, const float* dy_full, int ldf, int foff, int fmode, const float* dy_pool, int ldp, int poff,
                      const float* dy_full2, int ld2, const float* residual, int ldr, float* dres, int lddr,
                      double* sums, float* dz, int ldd, int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream);
+
+/* Tile count T of the 4x4-tile Winograd forms for a batch of B maps of H x W (per-image grid, or the batch mosaic where that is smaller: csrc/common.h,
+ * Wino6Grid) - the row count of the transformed operands [36][T][C] of Y2_ALGO_WINOGRAD_F43(_PRE) / y2_wino_wgrad_ex (bits 1, 2). */
+long long y2_wino6_tiles(int32_t B, int32_t H, int32_t W);
+/* y2_bn_act_bwd for a block whose gradient dz is consumed ONLY through the two 4x4-tile Winograd transforms (autograd of conv -> BatchNorm(batch
+ * statistics) -> LeakyReLU, model/yolo2.py:57-65, in front of a 3x3 convolution whose weight gradient runs F(3x3,4x4) and whose data gradient runs
+ * F(4x4,3x3)): pass 1 (sums [2C], pre-zeroed) as y2_bn_act_bwd, then ONE kernel forms dz per pixel and stores v6 = B^T dz B [36][T][C] (the operand of
+ * Y2_ALGO_WINOGRAD_F43_PRE) and / or m6 = G dz G^T [36][T][C] (the operand of y2_wino_wgrad_ex bit 2) - bit-identical to y2_bn_act_bwd followed by the
+ * transform kernels of those two entry points, without the dz tensor (written once, read twice) and two launches.  Un-pooled gradient source with plain
+ * addressing only (dy_full, pixel stride ldf, channel offset foff).  dz: optional plain gradient [B,H,W,C] (pixel stride ldd) for a third consumer, or NULL.
+ * The buffer of v6 (else m6) is scratch for pass 1 before it is written.  Not available in deterministic mode. */
+int y2_bn_act_bwd_wino6(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,
+                        float slope, const float* dy_full, int ldf, int foff, double* sums, float* v6, float* m6, float* dz, int ldd,
+                        int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream);
 
 /* Backward of y2_maxpool_fwd (overlapping windows allowed): dx[B,H,W,C] from dy (+ optional dy2) [B,Ho,Wo,C]; the gradient of a
  * window goes to its first maximum (ATen semantics). */

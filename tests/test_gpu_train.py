@@ -790,3 +790,68 @@ def test_deterministic_wgrad_matches_fp64_and_repeats():
         assert torch.allclose(st[:2 * cout], ref, rtol=1e-12, atol=1e-9) and float(st[2 * cout:].abs().max()) == 0.0
     finally:
         _hip.set_deterministic(False)
+
+
+@pytest.mark.parametrize('B,cin,cout,H,W,ldf,foff,has_bn', [(4, 16, 24, 13, 13, 24, 0, 1), (11, 8, 16, 13, 13, 32, 8, 1), (2, 32, 16, 26, 26, 16, 0, 1), (3, 12, 8, 8, 12, 8, 0, 2),
+                                                            (1, 8, 8, 5, 7, 8, 0, 0), (9, 8, 12, 13, 11, 12, 0, 1)])
+def test_bn_backward_fused_with_both_4x4_tile_transforms(B, cin, cout, H, W, ldf, foff, has_bn):
+    """y2_bn_act_bwd_wino6 (BatchNorm / LeakyReLU backward pass 1 + pass 2 + both 4x4-tile Winograd transforms of dz in one kernel; autograd of
+    model/yolo2.py:57-65 in front of a 3x3 convolution) against the forms it replaces: y2_bn_act_bwd (dz tensor) -> y2_conv_fwd F(4x4,3x3) on dz and
+    y2_wino_wgrad_ex F(3x3,4x4) on (x, dz).  Same arithmetic, operation for operation; what differs is the order in which pass 1's fp32 partial sums meet
+    (atomics), so everything agrees to 1e-5 x rms, not bit for bit.  Mosaic tile grids (11 and 9 images), channel windows in the gradient source, frozen statistics, no BN."""
+    import _hip
+    L, d = _hip.lib(), dev()
+    g = torch.Generator().manual_seed(B * 100 + cin + cout + H)
+    z = torch.randn(B, H, W, cout, generator=g).to(d)
+    dy_buf = torch.randn(B, H, W, ldf, generator=g).to(d)
+    x = torch.randn(B, H, W, cin, generator=g).to(d)
+    gamma, beta = (torch.rand(cout, generator=g) + 0.5).to(d), (torch.randn(cout, generator=g) * 0.1).to(d)
+    mean = z.mean(dim=(0, 1, 2)).contiguous()
+    invstd = torch.rsqrt(z.var(dim=(0, 1, 2), unbiased=False) + 1e-5).contiguous()
+    scale = (gamma * invstd).contiguous() if has_bn else torch.ones(cout, device=d)
+    shift = (beta - mean * scale).contiguous() if has_bn else beta
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).to(d).contiguous()          # forward weight [cout][cin]: its data gradient maps cout -> cin channels
+    wd = torch.empty(w.numel(), device=d)
+    _hip.check(L.y2_pack_weight(_hip.ptr(w), _hip.ptr(wd), cout, cin, 3, 1, _hip.stream()), 'pack1')
+    u6 = _hip.wino6_weight(wd, cin, cout)
+    args = (_hip.ptr(z), _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(mean) if has_bn else None, _hip.ptr(invstd) if has_bn else None, _hip.ptr(gamma) if has_bn else None, 0.1)
+    # ---- three-kernel forms
+    sums0 = torch.zeros(2 * cout, dtype=torch.float64, device=d)
+    dz = torch.empty(B, H, W, cout, device=d)
+    _hip.check(L.y2_bn_act_bwd(*args, _hip.ptr(dy_buf), ldf, foff, 0, None, 0, 0, _hip.ptr(sums0), _hip.ptr(dz), cout, B, H, W, cout, cout, has_bn, _hip.stream()), 'bn_act_bwd')
+
+    def dgrad(src, algo, ldx):
+        dx = torch.empty(B, H, W, cin, device=d)
+        p = _hip.ConvParams()
+        p.x, p.w, p.y = src.data_ptr(), u6.data_ptr(), dx.data_ptr()
+        p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize, p.ldy, p.slope, p.algo, p.tile = B, H, W, cout, ldx, cin, 3, cin, 1.0, algo, 0
+        assert _hip.conv_workspace(p, d) >= 0
+        _hip.check(L.y2_conv_fwd(ctypes.byref(p), _hip.stream()), 'conv algo %d' % algo)
+        return dx
+    need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
+    ws = torch.empty(need // 4 + 4, device=d)
+
+    def wgrad(src, flags):
+        dw = torch.full((cout, cin, 3, 3), 5.0, device=d)
+        _hip.check(L.y2_wino_wgrad_ex(_hip.ptr(x), _hip.ptr(src), _hip.ptr(dw), B, H, W, cin, cin, cout, cout, None, _hip.ptr(ws), ws.numel() * 4, flags, _hip.stream()), 'wino6 wgrad')
+        return dw
+    dx0, dw0 = dgrad(dz, 6, cout), wgrad(dz, 3)
+    # ---- fused
+    T = int(L.y2_wino6_tiles(B, H, W))
+    assert 0 < T <= B * ((H + 3) // 4) * ((W + 3) // 4)
+    sums1 = torch.zeros(2 * cout, dtype=torch.float64, device=d)
+    v6, m6 = torch.full((36 * T * cout,), 7.0, device=d), torch.full((36 * T * cout,), 7.0, device=d)
+    dz1 = torch.full((B, H, W, cout), 7.0, device=d)
+    _hip.check(L.y2_bn_act_bwd_wino6(*args, _hip.ptr(dy_buf), ldf, foff, _hip.ptr(sums1), _hip.ptr(v6), _hip.ptr(m6), _hip.ptr(dz1), cout, B, H, W, cout, cout, has_bn, _hip.stream()), 'bn_act_bwd_wino6')
+    dx1, dw1 = dgrad(v6, 7, cout), wgrad(m6, 7)
+    torch.cuda.synchronize()
+    # pass 1 is the same kernel; its fp32 partial sums meet in another order (LDS / fp64 atomics, parked per-workgroup partials), and dz depends on them
+    assert rel(sums1, sums0.cpu()) <= 1e-5
+    assert rel(dz1, dz.cpu()) <= 1e-5 and rel(dx1, dx0.cpu()) <= 1e-5 and rel(dw1, dw0.cpu()) <= 1e-5
+    # only one of the two operands, and no plain gradient
+    sums2 = torch.zeros(2 * cout, dtype=torch.float64, device=d)
+    m6b = torch.empty(36 * T * cout, device=d)
+    _hip.check(L.y2_bn_act_bwd_wino6(*args, _hip.ptr(dy_buf), ldf, foff, _hip.ptr(sums2), None, _hip.ptr(m6b), None, 0, B, H, W, cout, cout, has_bn, _hip.stream()), 'bn_act_bwd_wino6')
+    assert rel(m6b, m6.cpu()) <= 1e-5
+    assert L.y2_bn_act_bwd_wino6(*args, _hip.ptr(dy_buf), ldf, foff, _hip.ptr(sums2), None, None, None, 0, B, H, W, cout, cout, has_bn, _hip.stream()) != 0
+    assert L.y2_wino_wgrad_ex(_hip.ptr(x), _hip.ptr(m6), _hip.ptr(dw1), B, H, W, cin, cin, cout, cout, None, _hip.ptr(ws), ws.numel() * 4, 5, _hip.stream()) != 0      # bit 2 without bit 1

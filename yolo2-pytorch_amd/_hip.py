@@ -106,6 +106,9 @@ SIGNATURES = {
     'y2_bn_act_bwd_ex': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
                          c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                          c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'y2_wino6_tiles': [c_int, c_int, c_int],
+    'y2_bn_act_bwd_wino6': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                            c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'y2_maxpool_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'y2_colsum': [c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p, c_void_p],
     'y2_f64_to_f32': [c_void_p, c_void_p, c_int, ctypes.c_double, c_void_p],
@@ -160,6 +163,7 @@ def lib():
             fn.restype = c_int
         l.y2_conv_fwd_workspace_bytes.restype = ctypes.c_longlong
         l.y2_wino_wgrad_workspace_bytes.restype = ctypes.c_longlong
+        l.y2_wino6_tiles.restype = ctypes.c_longlong
         l.y2_build_info.argtypes = []
         l.y2_build_info.restype = ctypes.c_char_p
         _lib = l
@@ -553,7 +557,7 @@ class OperandMissing(RuntimeError):
     warm-up passes used: model.train_graph)."""
 
 
-def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, split_plane=0, f43=None, wino_eligible=None):
+def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, split_plane=0, f43=None, wino_eligible=None, peek=False):
     """Measure-don't-guess algorithm + tile selection for one y2_conv_fwd problem: the first time a problem shape is seen,
     every tile configuration of the direct kernel - and, when `wino_w` (y2_wino_weight output) is given, of the Winograd
     path - is timed (HIP events, best of 2 x 3 launches) and the fastest is cached for the process; later calls only
@@ -578,6 +582,17 @@ def autotune_conv(params, dev, wino_w=None, implicit_ok=True, wino_split=None, s
         if not f43_t:
             f43_t.append(f43() if callable(f43) else f43)
         return f43_t[0]
+    if peek:
+        # the answer a later call with the same problem will get, when it is already known (pinned, or in the table): (algo, tile) or None.  Nothing is
+        # measured, nothing is written to params
+        if FORCE_GRAD is not None and f43 is not None:
+            return (6, 5) if (FORCE_GRAD == 'f43' and f43_ok) else (0, 0)
+        if FORCE_ALGO is not None or DETERMINISTIC:
+            return None
+        if str(dev) not in _DEFAULTS_SEEN:
+            load_tune_defaults(dev)
+        hit = _TUNE.get(key)
+        return None if hit is None else (tuple(hit) if isinstance(hit, (list, tuple)) else (0, hit))
     implicit_ok = bool(implicit_ok and IMPLICIT) and params.Cin % 32 == 0
     w_direct = params.w
 
@@ -743,11 +758,26 @@ def wgrad_choice(B, H, W, cin, ldx, cout, ldz, k, has_v, dev):
     return _TUNE.get(('wgrad', B, H, W, cin, ldx, cout, ldz, bool(has_v), str(dev)))
 
 
+def _wgrad_scratch(dev, need):
+    """The Winograd weight gradients' scratch (transformed operands, dU): one buffer per device (or per capture scope), grown by replacement.  The weight
+    gradients run on the launch stream of launch_on() while this buffer - like everything - is allocated on torch's current stream: before the old buffer
+    is dropped the current stream waits for the launch stream, or the allocator would hand its block to the next main-stream tensor while the previous
+    layer's weight gradient is still using it (seen as a garbage gradient of one layer in the first backward of a process, where the scratch grows layer by layer)."""
+    ws = _cache(_WGRAD_WS).get(str(dev))
+    if ws is None or ws.numel() * 4 < need:
+        if ws is not None and _LAUNCH is not None:
+            torch.cuda.current_stream().wait_stream(_LAUNCH)
+        _retire(ws)
+        ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=dev)
+        _cache(_WGRAD_WS)[str(dev)] = ws
+    return ws
+
+
 def eligible_wino(cout, cin, k, ldx, ldz):
     return wino_eligible(cout, cin, k) and not (ldx % 4) and not (ldz % 4)
 
 
-def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=False, native=None):
+def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=False, native=None, dz_pre=False):
     """Packed weight gradient dw[cout][k*k][cin] of a stride-1 "same" convolution: y2_conv_wgrad (9 shifted reductions
     over pixels) or, for 3x3 layers where it measures faster, y2_wino_wgrad (16 reductions over 2x2 tiles).  The choice
     is timed once per problem shape and cached.  `v`: the layer's transformed input kept from a Winograd forward (see
@@ -758,16 +788,22 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
     L, st, dev = lib(), stream(), x.device
     nw = cout * cin * k * k
     choice = wgrad_choice(B, H, W, cin, ldx, cout, ldz, k, v is not None, dev)
+    if dz_pre:
+        # `dz` is the transformed gradient [36][T][cout] of the 4x4-tile form (y2_bn_act_bwd_wino6): the caller looked the choice up before it built it
+        if choice != 2:
+            raise RuntimeError('conv_wgrad: a transformed gradient serves the 4x4-tile form only (choice %r)' % (choice,))
+        need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
+        ws = _wgrad_scratch(dev, need)
+        dst = native if native is not None else (out if out is not None else torch.empty(nw, dtype=torch.float32, device=dev))
+        check(L.y2_wino_wgrad_ex(ptr(x), ptr(dz), ptr(dst), B, H, W, cin, ldx, cout, cout, None, ptr(ws), ws.numel() * 4, 7 if native is not None else 6, st), 'y2_wino_wgrad_ex')
+        return dst
     eligible = wino_eligible(cout, cin, k) and not (ldx % 4) and not (ldz % 4)
     key = ('wgrad', B, H, W, cin, ldx, cout, ldz, v is not None, str(dev))
     # the direct kernel accumulates split partial sums into a zeroed buffer; the Winograd path overwrites (no fill needed)
     if native is not None and choice in (1, 2) and eligible_wino(cout, cin, k, ldx, ldz):
         assert native.numel() == nw and native.is_contiguous()
         need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
-        ws = _cache(_WGRAD_WS).get(str(dev))
-        if ws is None or ws.numel() * 4 < need:
-            ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=dev)
-            _cache(_WGRAD_WS)[str(dev)] = ws
+        ws = _wgrad_scratch(dev, need)
         check(L.y2_wino_wgrad_ex(ptr(x), ptr(dz), ptr(native), B, H, W, cin, ldx, cout, ldz, ptr(v) if choice == 1 else None, ptr(ws), ws.numel() * 4,
                                  1 if choice == 1 else 3, st), 'y2_wino_wgrad_ex')
         return native
@@ -784,11 +820,7 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
     ws = None
     if choice != 0:      # (a layer whose measured choice is the direct kernel needs no Winograd scratch: the 208x208 layer alone would size it at 4-9 GB)
         need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
-        ws = _cache(_WGRAD_WS).get(str(dev))
-        if ws is None or ws.numel() * 4 < need:
-            _retire(ws)
-            ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=dev)
-            _cache(_WGRAD_WS)[str(dev)] = ws
+        ws = _wgrad_scratch(dev, need)
 
     def wino():
         check(L.y2_wino_wgrad(ptr(x), ptr(dz), ptr(dwp), B, H, W, cin, ldx, cout, ldz, ptr(v), ptr(ws), ws.numel() * 4, st), 'y2_wino_wgrad')

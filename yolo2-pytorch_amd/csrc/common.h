@@ -110,3 +110,31 @@ __device__ __forceinline__ uint32_t y2_div(uint32_t n, const y2_fastdiv& f) {
     const uint32_t t = __umulhi(n, f.mul);
     return (t + ((n - t) >> 1)) >> f.sh;
 }
+
+#include <stdlib.h>
+// Tile grid of the 4x4-tile forms.  Per image, a map of H rows takes ceil(H / 4) tile rows: 13 rows pay for 16 (the 13x13 layers at 416x416: 34 % of the
+// multiply-adds of their 36 GEMMs are spent on rows and columns that do not exist).  "Mosaic" tiling lays the batch's images out as ONE image - gy rows of gx
+// images with a single zero row / zero column between neighbours; that line IS the bottom (right) padding of one image and the top (left) padding of the next,
+// so every 3x3 neighbourhood of the mosaic is the neighbourhood of its own image - and cuts THAT into 4x4 tiles: 64 images of 13x13 as 8 x 8 -> 111 x 111
+// pixels -> 28 x 28 = 784 tiles instead of 64 x 16 = 1024 (-23 %; 26x26: 3136 -> 2916).  Only the tile -> pixel maps of the three transform kernels change
+// (mosaic row r -> image row r / (H + 1), pixel row r % (H + 1); a row H does not exist: reads give zero, writes are dropped; columns alike); the GEMMs see
+// fewer rows.  gx is chosen to minimise the tile count; the per-image grid stays when nothing is smaller (Y2_WINO6_TALL=0: always).
+struct Wino6Grid { int th, tw, tall, wide, gx; long long T; };
+inline Wino6Grid wino6_grid(int B, int H, int W) {
+    static const bool allow = getenv("Y2_WINO6_TALL") == nullptr || atoi(getenv("Y2_WINO6_TALL")) != 0;
+    Wino6Grid g;
+    g.tw = (W + 3) / 4;
+    g.th = (H + 3) / 4;
+    g.tall = g.wide = 0;
+    g.gx = 1;
+    g.T = (long long)B * g.th * g.tw;
+    if (!allow) return g;
+    for (int gx = 1; gx <= B && gx <= 4096; ++gx) {
+        const long long gy = (B + gx - 1) / gx;
+        const long long rows = gy * (H + 1) - 1, cols = (long long)gx * (W + 1) - 1;
+        const long long th = (rows + 3) / 4, tw = (cols + 3) / 4;
+        if (rows >= 0x7fffffff || cols >= 0x7fffffff) continue;
+        if (th * tw < g.T) { g.T = th * tw; g.th = (int)th; g.tw = (int)tw; g.tall = H + 1; g.wide = gx > 1 ? W + 1 : 0; g.gx = gx; }
+    }
+    return g;
+}

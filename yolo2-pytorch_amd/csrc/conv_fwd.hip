@@ -1272,7 +1272,7 @@ int choose_tile(long long M, int Cout, int nk) {
 
 static int conv_fwd_impl(const y2_conv_params* p, y2_stream_t stream, size_t* ws_need, int groups = 1, long long gx = 0, long long gw = 0, long long gy = 0) {
     if (ws_need != nullptr) *ws_need = 0;
-    if (p != nullptr && p->algo == Y2_ALGO_WINOGRAD_F43 && groups == 1) return y2_internal_wino6_conv(p, stream, ws_need);
+    if (p != nullptr && (p->algo == Y2_ALGO_WINOGRAD_F43 || p->algo == Y2_ALGO_WINOGRAD_F43_PRE) && groups == 1) return y2_internal_wino6_conv(p, stream, ws_need);
     if (p != nullptr && (p->algo == Y2_ALGO_WINOGRAD || p->algo == Y2_ALGO_WINOGRAD_FUSED || p->algo == Y2_ALGO_WINOGRAD_IMPLICIT || p->algo == Y2_ALGO_WINOGRAD_SPLIT || p->algo == Y2_ALGO_WINOGRAD_SPLIT_F16) && groups == 1) return y2_internal_wino_conv(p, stream, ws_need);
     if (p != nullptr && p->algo != Y2_ALGO_DIRECT && groups == 1) return Y2_EINVAL;
     if (p == nullptr || p->x == nullptr || p->w == nullptr) return Y2_EINVAL;

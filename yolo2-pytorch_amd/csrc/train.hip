@@ -308,6 +308,165 @@ __global__ __launch_bounds__(1024) void bn_bwd_block_reduce_kernel(const float* 
     }
 }
 
+// ---- BatchNorm / LeakyReLU backward, second pass, fused with BOTH 4x4-tile Winograd transforms of the gradient it produces (round 6).
+// A deep 3x3 layer whose weight gradient runs F(3x3,4x4) and whose data gradient runs F(4x4,3x3) consumes dz only through two transforms:
+// V6 = B^T d B on 6x6 patches (the data gradient's input operand) and M6 = G d G^T on the 4x4 tile inside (the weight gradient's "filter" operand).
+// The three-kernel form wrote dz (pass 2), read it twice and wrote 2 x 2.25 |dz|; here one thread = (tile, channel) forms dz at the 36 pixels of its
+// patch from (z, dy) and the pass-1 sums - the arithmetic of bn_act_bwd_kernel<.., APPLY = true>, operation for operation - and stores both transforms,
+// the operations of wino6_in_kernel<false> / <true> in their order: BIT-IDENTICAL operands, no dz tensor, two launches fewer.  Un-pooled gradient source
+// with plain addressing only (dy_full, fmode 0); the pooled layers keep the three-kernel form.  Tile grid: Wino6Grid (common.h), like the kernels it replaces.
+struct BnWino6Args {
+    const float* z; const float* scale; const float* shift; const float* mean; const float* invstd; const float* gamma;
+    const float* dy; const double* sums;
+    float* v6; float* m6;          // [36][T][C] each; either may be NULL
+    float* dz;                     // optional plain gradient [B,H,W,C] (pixel stride ldd): for a consumer that reads it untransformed
+    int B, H, W, C, ldz, ldf, foff, ldd, has_bn;
+    float slope;
+    double n;
+    int th, tw, T, tall, wide, gx;
+    y2_fastdiv d_c, d_tt, d_tw, d_tall, d_wide;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_wino6_kernel(const BnWino6Args a) {
+    constexpr float BT[6][6] = {{1.f, 1.5f, -2.f, -1.5f, 1.f, 0.f}, {0.f, -1.f, -2.5f, -0.5f, 1.f, 0.f}, {0.f, 1.f, 0.5f, -2.5f, 1.f, 0.f},
+                                {0.f, -0.5f, -1.f, 0.5f, 1.f, 0.f}, {0.f, 2.f, -1.f, -2.f, 1.f, 0.f}, {0.f, 1.f, 1.5f, -2.f, -1.5f, 1.f}};
+    constexpr float GM[6][4] = {{1.f, 0.f, 0.f, 0.f}, {-1.f / 3, -1.f / 3, -1.f / 3, -1.f / 3}, {1.f / 3, -1.f / 3, 1.f / 3, -1.f / 3},
+                                {1.f / 15, 2.f / 15, 4.f / 15, 8.f / 15}, {-16.f / 15, 8.f / 15, -4.f / 15, 2.f / 15}, {0.f, 0.f, 0.f, 1.f}};
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t t = y2_div(idx, a.d_c);
+    if (t >= (uint32_t)a.T) return;
+    const int c = (int)(idx - t * (uint32_t)a.C);
+    // per-channel constants of the apply pass (bn_act_bwd_kernel)
+    const float sc = a.scale ? a.scale[c] : 1.f, sh = a.shift ? a.shift[c] : 0.f;
+    const float mu = a.has_bn ? a.mean[c] : 0.f, is = a.has_bn ? a.invstd[c] : 1.f;
+    float gs = 1.f, ma = 0.f, mb = 0.f;
+    if (a.has_bn == 1) { gs = a.gamma[c] * is; ma = (float)(a.sums[c] / a.n); mb = (float)(a.sums[a.C + c] / a.n); }
+    else if (a.has_bn == 2) { gs = a.gamma[c] * is; }
+    int b = 0, ty, tx;
+    if (a.tall) {
+        ty = (int)y2_div(t, a.d_tw);
+        tx = (int)t - ty * a.tw;
+    } else {
+        b = (int)y2_div(t, a.d_tt);
+        const int r = (int)t - b * a.th * a.tw;
+        ty = (int)y2_div((uint32_t)r, a.d_tw);
+        tx = r - ty * a.tw;
+    }
+    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+    int colx[6], colb[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        int xx = x0 + j, bx = 0;
+        bool ok = (unsigned)xx < (unsigned)a.W;
+        if (a.wide) {
+            ok = (unsigned)xx < (unsigned)(a.gx * a.wide);
+            bx = ok ? (int)y2_div((uint32_t)xx, a.d_wide) : 0;
+            xx -= bx * a.wide;
+            ok = ok && xx < a.W;
+        }
+        colx[j] = ok ? xx : -1;
+        colb[j] = bx;
+    }
+    // loads first, unconditionally (a pixel that does not exist reads pixel 0 and is discarded by the select below): as conditional loads every one of the
+    // 36 pixels was a basic block of its own - load, wait, arithmetic - and the kernel ran at the latency of 36 dependent round trips (3.9 TB/s on the
+    // 52x52 layer against 6 TB/s for the kernels it replaces)
+    float d[6][6];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {          // two batches of 18 pixels: 36 loads in flight, half the address / value registers of one batch of 36
+        uint32_t pixs[3][6];
+        bool oks[3][6];
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii) {
+            int yy = y0 + 3 * half + ii, by = 0;
+            bool rowok = (unsigned)yy < (unsigned)a.H;
+            if (a.tall) {
+                rowok = yy >= 0;
+                by = rowok ? (int)y2_div((uint32_t)yy, a.d_tall) : 0;
+                yy -= by * a.tall;
+                rowok = rowok && yy < a.H;
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int bb = a.tall ? by * a.gx + colb[j] : b;
+                const bool ok = rowok && colx[j] >= 0 && bb < a.B;
+                oks[ii][j] = ok;
+                pixs[ii][j] = ok ? (uint32_t)((bb * a.H + yy) * a.W + colx[j]) : 0u;
+            }
+        }
+        float zs[3][6], gsrc[3][6];
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                zs[ii][j] = a.z[(size_t)pixs[ii][j] * a.ldz + c];
+                gsrc[ii][j] = a.dy[(size_t)pixs[ii][j] * a.ldf + a.foff + c];
+            }
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int i = 3 * half + ii;
+                const float zv = zs[ii][j];
+                const float g = 0.f + gsrc[ii][j];
+                const float yv = zv * sc + sh;
+                const float ge = g * (yv > 0.f ? 1.f : a.slope);
+                const float zh = (zv - mu) * is;
+                const float v = oks[ii][j] ? gs * (ge - ma - zh * mb) : 0.f;
+                if (a.dz != nullptr && oks[ii][j] && i >= 1 && i <= 4 && j >= 1 && j <= 4) a.dz[(size_t)pixs[ii][j] * a.ldd + c] = v;      // (the tile's own pixels: every pixel belongs to one tile)
+                d[i][j] = v;
+            }
+    }
+    const size_t plane = (size_t)a.T * a.C;
+    if (a.v6 != nullptr) {          // wino6_in_kernel<false>
+        float sm[6][6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float v = 0.f;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    if (BT[u][i] != 0.f) v += BT[u][i] * d[i][j];
+                sm[u][j] = v;
+            }
+        float* dst = a.v6 + (size_t)t * a.C + c;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int v6 = 0; v6 < 6; ++v6) {
+                float v = 0.f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    if (BT[v6][j] != 0.f) v += BT[v6][j] * sm[u][j];
+                dst[(size_t)(6 * u + v6) * plane] = v;
+            }
+    }
+    if (a.m6 != nullptr) {          // wino6_in_kernel<true> on the 4x4 tile inside the patch
+        float sm[6][4];
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (GM[u][i] != 0.f) v += GM[u][i] * d[i + 1][j + 1];
+                sm[u][j] = v;
+            }
+        float* dst = a.m6 + (size_t)t * a.C + c;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int v6 = 0; v6 < 6; ++v6) {
+                float v = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (GM[v6][j] != 0.f) v += GM[v6][j] * sm[u][j];
+                dst[(size_t)(6 * u + v6) * plane] = v;
+            }
+    }
+}
+
 // nn.MaxPool2d(k, stride, padding) backward on NHWC, gather form: an input element receives the gradient of every window whose
 // FIRST maximum (scan order, strict >, like ATen) it is; windows overlap when k > stride (model/resnet.py:114).
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ dy2, float* __restrict__ dx,
@@ -682,10 +841,12 @@ extern "C" int y2_bn_act_fwd_ex(const float* z, const float* scale, const float*
     return Y2_OK;
 }
 
-extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,
-                                float slope, const float* dy_full, int ldf, int foff, int fmode, const float* dy_pool, int ldp, int poff,
-                                const float* dy_full2, int ld2, const float* residual, int ldr, float* dres, int lddr,
-                                double* sums, float* dz, int ldd, int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream) {
+// park / park_floats: with dz == NULL (pass 1 only), a caller-owned buffer that nothing reads before the caller's own next kernel writes it: the
+// per-workgroup partial sums are parked there instead of 2C fp64 atomics per workgroup (what a dense dz buffer is used for otherwise)
+static int bn_act_bwd_impl(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,
+                           float slope, const float* dy_full, int ldf, int foff, int fmode, const float* dy_pool, int ldp, int poff,
+                           const float* dy_full2, int ld2, const float* residual, int ldr, float* dres, int lddr,
+                           double* sums, float* dz, int ldd, int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream, float* park, long long park_floats) {
     if (!z || (!dy_full && !dy_pool) || !sums || B <= 0 || H <= 0 || W <= 0 || C <= 0) return Y2_EINVAL;      // dz == NULL: the sums only (pass 1)
     if (dz == nullptr && dres != nullptr) return Y2_EINVAL;
     if (has_bn < 0 || has_bn > 2 || (has_bn && (!mean || !invstd || !gamma))) return Y2_EINVAL;
@@ -723,6 +884,7 @@ extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float*
     const bool aliased = dz != nullptr && (overlaps(z, npix * ldz) || overlaps(dy_full, (fmode == 1 ? npix / 4 : npix) * (long long)ldf) || overlaps(dy_pool, opix * ldp) ||
                                            overlaps(dy_full2, npix * ld2) || overlaps(residual, npix * ldr) || overlaps(dres, npix * lddr));
     a.block_partial = (dz != nullptr && !aliased && !y2_det.on && ldd == C && grid > 16 && (long long)grid * 2 * C <= npix * ldd) ? dz : nullptr;
+    if (dz == nullptr && park != nullptr && !y2_det.on && grid > 16 && (long long)grid * 2 * C <= park_floats && y2_aligned16(park)) a.block_partial = park;
     const long long prow = (long long)grid * 256 / Cg;            // rows of per-thread partials (grid * 256 is a multiple of Cg)
     if (y2_det.on) {
         if ((size_t)prow * 2 * C * sizeof(float) > y2_det.bytes || prow > 0x7fffffffLL) return Y2_EINVAL;
@@ -742,6 +904,43 @@ extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float*
     if (pool) { if (vec) Y2_BWD(true, 4); else Y2_BWD(true, 1); }
     else { if (vec) Y2_BWD(false, 4); else Y2_BWD(false, 1); }
 #undef Y2_BWD
+    Y2_LAUNCH_CHECK();
+    return Y2_OK;
+}
+
+extern "C" int y2_bn_act_bwd_ex(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,
+                                float slope, const float* dy_full, int ldf, int foff, int fmode, const float* dy_pool, int ldp, int poff,
+                                const float* dy_full2, int ld2, const float* residual, int ldr, float* dres, int lddr,
+                                double* sums, float* dz, int ldd, int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream) {
+    return bn_act_bwd_impl(z, scale, shift, mean, invstd, gamma, slope, dy_full, ldf, foff, fmode, dy_pool, ldp, poff, dy_full2, ld2, residual, ldr, dres, lddr,
+                           sums, dz, ldd, B, H, W, C, ldz, has_bn, stream, nullptr, 0);
+}
+
+extern "C" long long y2_wino6_tiles(int32_t B, int32_t H, int32_t W) {
+    if (B <= 0 || H <= 0 || W <= 0) return Y2_EINVAL;
+    return wino6_grid(B, H, W).T;
+}
+
+extern "C" int y2_bn_act_bwd_wino6(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* gamma,
+                                   float slope, const float* dy_full, int ldf, int foff, double* sums, float* v6, float* m6, float* dz, int ldd,
+                                   int B, int H, int W, int C, int ldz, int has_bn, y2_stream_t stream) {
+    if (!z || !dy_full || !sums || (v6 == nullptr && m6 == nullptr) || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ldz < C || ldf < foff + C) return Y2_EINVAL;
+    if (dz != nullptr && ldd < C) return Y2_EINVAL;
+    if (y2_det.on) return Y2_ENOSUP;
+    const Wino6Grid g6 = wino6_grid(B, H, W);
+    if (g6.T * C >= 0xffffffffLL || g6.T > 0x7fffffff || (long long)B * H * W >= 0x7fffffffLL) return Y2_ENOSUP;
+    // pass 1 (the sums), its per-workgroup partials parked in the transform buffer this call writes afterwards
+    float* park = v6 != nullptr ? v6 : m6;
+    if (const int rc = bn_act_bwd_impl(z, scale, shift, mean, invstd, gamma, slope, dy_full, ldf, foff, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0,
+                                       sums, nullptr, 0, B, H, W, C, ldz, has_bn, stream, park, 36LL * g6.T * C)) return rc;
+    BnWino6Args a;
+    a.z = z; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.dy = dy_full; a.sums = sums;
+    a.v6 = v6; a.m6 = m6; a.dz = dz; a.ldd = ldd;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.ldz = ldz; a.ldf = ldf; a.foff = foff; a.has_bn = has_bn; a.slope = slope; a.n = (double)B * H * W;
+    a.th = g6.th; a.tw = g6.tw; a.T = (int)g6.T; a.tall = g6.tall; a.wide = g6.wide; a.gx = g6.gx;
+    a.d_c = y2_make_fastdiv((uint32_t)C); a.d_tt = y2_make_fastdiv((uint32_t)(g6.th * g6.tw)); a.d_tw = y2_make_fastdiv((uint32_t)g6.tw);
+    a.d_tall = y2_make_fastdiv((uint32_t)(g6.tall > 0 ? g6.tall : 1)); a.d_wide = y2_make_fastdiv((uint32_t)(g6.wide > 0 ? g6.wide : 1));
+    Y2_LAUNCH("bn_bwd_wino6_kernel", 0.0, bn_bwd_wino6_kernel, dim3((unsigned)y2_cdiv(g6.T * C, 256)), dim3(256), 0, y2_s(stream), a);
     Y2_LAUNCH_CHECK();
     return Y2_OK;
 }

@@ -1322,32 +1322,7 @@ struct Wino6Args {
     y2_fastdiv d_tall, d_wide;
 };
 
-// Tile grid of the 4x4-tile forms.  Per image, a map of H rows takes ceil(H / 4) tile rows: 13 rows pay for 16 (the 13x13 layers at 416x416: 34 % of the
-// multiply-adds of their 36 GEMMs are spent on rows and columns that do not exist).  "Mosaic" tiling lays the batch's images out as ONE image - gy rows of gx
-// images with a single zero row / zero column between neighbours; that line IS the bottom (right) padding of one image and the top (left) padding of the next,
-// so every 3x3 neighbourhood of the mosaic is the neighbourhood of its own image - and cuts THAT into 4x4 tiles: 64 images of 13x13 as 8 x 8 -> 111 x 111
-// pixels -> 28 x 28 = 784 tiles instead of 64 x 16 = 1024 (-23 %; 26x26: 3136 -> 2916).  Only the tile -> pixel maps of the three transform kernels change
-// (mosaic row r -> image row r / (H + 1), pixel row r % (H + 1); a row H does not exist: reads give zero, writes are dropped; columns alike); the GEMMs see
-// fewer rows.  gx is chosen to minimise the tile count; the per-image grid stays when nothing is smaller (Y2_WINO6_TALL=0: always).
-struct Wino6Grid { int th, tw, tall, wide, gx; long long T; };
-inline Wino6Grid wino6_grid(int B, int H, int W) {
-    static const bool allow = getenv("Y2_WINO6_TALL") == nullptr || atoi(getenv("Y2_WINO6_TALL")) != 0;
-    Wino6Grid g;
-    g.tw = (W + 3) / 4;
-    g.th = (H + 3) / 4;
-    g.tall = g.wide = 0;
-    g.gx = 1;
-    g.T = (long long)B * g.th * g.tw;
-    if (!allow) return g;
-    for (int gx = 1; gx <= B && gx <= 4096; ++gx) {
-        const long long gy = (B + gx - 1) / gx;
-        const long long rows = gy * (H + 1) - 1, cols = (long long)gx * (W + 1) - 1;
-        const long long th = (rows + 3) / 4, tw = (cols + 3) / 4;
-        if (rows >= 0x7fffffff || cols >= 0x7fffffff) continue;
-        if (th * tw < g.T) { g.T = th * tw; g.th = (int)th; g.tw = (int)tw; g.tall = H + 1; g.wide = gx > 1 ? W + 1 : 0; g.gx = gx; }
-    }
-    return g;
-}
+// (Wino6Grid / wino6_grid(): common.h - the fused BatchNorm-backward + transform kernel of train.hip cuts the same grid)
 
 template <bool GRAD>
 __global__ __launch_bounds__(256) void wino6_in_kernel(const Wino6Args a) {
@@ -1639,12 +1614,16 @@ int y2_internal_wino6_conv(const y2_conv_params* p, y2_stream_t stream, size_t* 
         size_t inner = 0;
         const int rc = y2_internal_conv_grouped(&q, 36, T * p->Cin, (long long)p->Cout * p->Cin, T * p->Cout, stream, &inner);
         if (rc != Y2_OK) return rc;
-        *ws_need = vbytes + mbytes + inner;
+        *ws_need = (p->algo == Y2_ALGO_WINOGRAD_F43_PRE ? 0 : vbytes) + mbytes + inner;
         return Y2_OK;
     }
-    if (p->workspace == nullptr || !y2_aligned16(p->workspace) || (size_t)p->workspace_bytes < vbytes + mbytes) return Y2_EINVAL;
-    float* V = p->workspace;
-    float* M = V + vbytes / sizeof(float);
+    // Y2_ALGO_WINOGRAD_F43_PRE: x IS the transformed input [36][T][Cin] (y2_bn_act_bwd_wino6 wrote it): no input transform, no V in the workspace
+    const bool pre = p->algo == Y2_ALGO_WINOGRAD_F43_PRE;
+    if (pre && (p->ldx != p->Cin || !y2_aligned16(p->x))) return Y2_EINVAL;
+    if (p->workspace == nullptr || !y2_aligned16(p->workspace) || (size_t)p->workspace_bytes < (pre ? 0 : vbytes) + mbytes) return Y2_EINVAL;
+    float* V = pre ? const_cast<float*>(p->x) : p->workspace;
+    float* M = pre ? p->workspace : V + vbytes / sizeof(float);
+    const size_t vused = pre ? 0 : vbytes;
     hipStream_t s = y2_s(stream);
     Wino6Args ia;
     ia.B = p->B; ia.H = p->H; ia.W = p->W; ia.th = th; ia.tw = tw; ia.T = (int)T;
@@ -1652,10 +1631,10 @@ int y2_internal_wino6_conv(const y2_conv_params* p, y2_stream_t stream, size_t* 
     ia.tall = g6.tall; ia.wide = g6.wide; ia.gx = g6.gx;
     ia.d_tall = y2_make_fastdiv((uint32_t)(g6.tall > 0 ? g6.tall : 1)); ia.d_wide = y2_make_fastdiv((uint32_t)(g6.wide > 0 ? g6.wide : 1));
     ia.src = p->x; ia.dst = V; ia.C = p->Cin; ia.ld = p->ldx; ia.d_c = y2_make_fastdiv((uint32_t)p->Cin);
-    Y2_LAUNCH("wino6_in_kernel", 0.0, wino6_in_kernel<false>, dim3((unsigned)y2_cdiv(T * p->Cin, 256)), dim3(256), 0, s, ia);
+    if (!pre) Y2_LAUNCH("wino6_in_kernel", 0.0, wino6_in_kernel<false>, dim3((unsigned)y2_cdiv(T * p->Cin, 256)), dim3(256), 0, s, ia);
     q.x = V; q.w = p->w; q.y = M;
     q.workspace = M + mbytes / sizeof(float);
-    q.workspace_bytes = (long long)((size_t)p->workspace_bytes - vbytes - mbytes);
+    q.workspace_bytes = (long long)((size_t)p->workspace_bytes - vused - mbytes);
     const int rc = y2_internal_conv_grouped(&q, 36, T * p->Cin, (long long)p->Cout * p->Cin, T * p->Cout, stream, nullptr);
     if (rc != Y2_OK) return rc;
     Wino6OutArgs oa;
@@ -1927,7 +1906,7 @@ static int zero_fill(float* p, size_t bytes, hipStream_t s) {      // bytes % 16
 }
 
 // F(3x3, 4x4): x and dz transformed on 4x4 gradient tiles, 36 grouped reductions, dW = A^T dU A (see wino6_in_kernel)
-static int wino6_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int ldx, int Cout, int ldz, float* workspace, bool native, y2_stream_t stream) {
+static int wino6_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int ldx, int Cout, int ldz, float* workspace, bool native, y2_stream_t stream, bool dz_pre = false) {
     if (x == nullptr) return Y2_EINVAL;                  // (a transformed input of the 2x2 form is of no use here)
     if (y2_det.on) return Y2_ENOSUP;
     const Wino6Grid g6 = wino6_grid(B, H, W);
@@ -1948,9 +1927,11 @@ static int wino6_wgrad(const float* x, const float* dz, float* dw, int B, int H,
     a.d_tall = y2_make_fastdiv((uint32_t)(g6.tall > 0 ? g6.tall : 1)); a.d_wide = y2_make_fastdiv((uint32_t)(g6.wide > 0 ? g6.wide : 1));
     a.src = x; a.dst = V; a.C = Cin; a.ld = ldx; a.d_c = y2_make_fastdiv((uint32_t)Cin);
     Y2_LAUNCH("wino6_in_kernel", 0.0, wino6_in_kernel<false>, dim3((unsigned)y2_cdiv(T * Cin, 256)), dim3(256), 0, s, a);
-    a.src = dz; a.dst = DM; a.C = Cout; a.ld = ldz; a.d_c = y2_make_fastdiv((uint32_t)Cout);
-    Y2_LAUNCH("wino6_in_kernel[dz]", 0.0, wino6_in_kernel<true>, dim3((unsigned)y2_cdiv(T * Cout, 256)), dim3(256), 0, s, a);
-    const int rc = y2_internal_wgrad_grouped(V, DM, DU, T, Cin, Cout, 36, T * Cin, T * Cout, (long long)Cout * Cin, stream);
+    if (!dz_pre) {          // (dz_pre: `dz` IS the transformed gradient [36][T][Cout], written by y2_bn_act_bwd_wino6)
+        a.src = dz; a.dst = DM; a.C = Cout; a.ld = ldz; a.d_c = y2_make_fastdiv((uint32_t)Cout);
+        Y2_LAUNCH("wino6_in_kernel[dz]", 0.0, wino6_in_kernel<true>, dim3((unsigned)y2_cdiv(T * Cout, 256)), dim3(256), 0, s, a);
+    }
+    const int rc = y2_internal_wgrad_grouped(V, dz_pre ? dz : DM, DU, T, Cin, Cout, 36, T * Cin, T * Cout, (long long)Cout * Cin, stream);
     if (rc != Y2_OK) return rc;
     const long long n = (long long)Cout * Cin;
     if (native) Y2_LAUNCH("wino6_dw_kernel", 0.0, wino6_dw_kernel<true>, dim3((unsigned)y2_cdiv(n, 256)), dim3(256), 0, s, DU, dw, Cout, Cin);
@@ -1968,7 +1949,8 @@ extern "C" int y2_wino_wgrad_ex(const float* x, const float* dz, float* dw_packe
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldz < Cout) return Y2_EINVAL;
     if ((Cin & 3) || (Cout & 3) || (ldx & 3) || (ldz & 3) || !y2_aligned16(x) || !y2_aligned16(dz) || !y2_aligned16(workspace)) return Y2_EALIGN;
     if (workspace_bytes < y2_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return Y2_EINVAL;
-    if (native_layout & 2) return wino6_wgrad(v_transformed != nullptr && x == v_transformed ? nullptr : x, dz, dw_packed, B, H, W, Cin, ldx, Cout, ldz, workspace, (native_layout & 1) != 0, stream);
+    if ((native_layout & 4) && !(native_layout & 2)) return Y2_EINVAL;          // a transformed gradient exists for the 4x4-tile form only
+    if (native_layout & 2) return wino6_wgrad(v_transformed != nullptr && x == v_transformed ? nullptr : x, dz, dw_packed, B, H, W, Cin, ldx, Cout, ldz, workspace, (native_layout & 1) != 0, stream, (native_layout & 4) != 0);
     const int th = (H + 1) / 2, tw = (W + 1) / 2;
     const long long T = (long long)B * th * tw;
     if (T * (Cin / 4) >= 0xffffffffLL || T * (Cout / 4) >= 0xffffffffLL || T > 0x7fffffff) return Y2_ENOSUP;

@@ -45,6 +45,7 @@ def _side_stream(dev):
 # same thread issues the RCCL collectives between graph segments and eight ranks share one host - unmeasured on 8-GPU hardware.
 GRAPH_FORK = {'1': True, '0': False}.get(os.environ.get('Y2_GRAPH_FORK', 'auto'), 'auto')
 GRAD_F43 = os.environ.get('Y2_GRAD_F43', '1') != '0'        # offer Winograd F(4x4,3x3) to the data gradients of the deep layers (A/B)
+FUSE_WINO6 = os.environ.get('Y2_FUSE_WINO6', '1') != '0'      # 0: BatchNorm-backward pass 2 always writes dz and the 4x4-tile transforms read it (A/B; csrc/train.hip: bn_bwd_wino6_kernel)
 FUSE_CONV0 = os.environ.get('Y2_FUSE_CONV0', '1') != '0'      # 0: materialise the first layer's dz and run the two-kernel form (A/B runs)
 DEBUG_TAP = None        # debugging hook: callable(block name, dz, dx) invoked per block of the Darknet backward
 
@@ -86,7 +87,7 @@ OperandPruned = _hip.OperandMissing      # a captured step prepares only the GEM
 
 
 def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=None, slope=1.0, stats=None, y_pool=None, ldp=0, coff=0, out_mode=0, keep_v=False, u=False,
-          us=None, us_plane=0, grad=False, note=None, u_eligible=None, u6=None):
+          us=None, us_plane=0, grad=False, note=None, u_eligible=None, u6=None, peek=False, pre=None, dev=None):
     """One y2_conv_fwd.  keep_v: when the Winograd algorithm is chosen, run it in a workspace of its own and return that tensor -
     its head is the transformed input V, which the weight gradient of the same layer reuses (y2_wino_wgrad v_transformed).
     u: the layer's Winograd filter transform when the caller prepared it (y2_prep_weights), None = not eligible, False = derive it here.
@@ -95,11 +96,14 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
     algorithm table - same key, same offer of the 4x4-tile gradient form - and only a choice that READS u fails).
     note: callable('w' | 'u' | '6') told which filter operand the chosen algorithm reads (packed, 2x2-tile transform, 4x4-tile transform).
     u6: the 4x4-tile transform when the caller prepared it; else it is derived from wp when that algorithm is timed or chosen."""
+    # peek: return the (algo, tile) this problem is known to take, or None - nothing is launched (x / y may be None).
+    # pre: the transformed input [36][T][cin] of the 4x4-tile form, built by y2_bn_act_bwd_wino6 because peek said the problem takes that form: the launch reads
+    # it instead of transforming x (which may be None then)
     p = _hip.ConvParams()
-    p.x, p.w = x.data_ptr(), (wp.data_ptr() if wp is not None else None)
+    p.x, p.w = (x.data_ptr() if x is not None else 256), (wp.data_ptr() if wp is not None else None)
     p.scale = scale.data_ptr() if scale is not None else None
     p.shift = shift.data_ptr() if shift is not None else None
-    p.y = y.data_ptr() if y is not None else None
+    p.y = y.data_ptr() if y is not None else (256 if peek else None)
     p.y_pool = y_pool.data_ptr() if y_pool is not None else None
     p.stats = stats.data_ptr() if stats is not None else None
     p.B, p.H, p.W, p.Cin, p.ldx, p.Cout, p.ksize = B, H, W, cin, ldx, cout, k
@@ -120,11 +124,18 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
         return _hip.wino6_weight(wp, cout, cin)
     eligible = (u is not None) if u_eligible is None else (bool(u_eligible) and out_mode == 0)
     f43 = f43_operand if (grad and GRAD_F43 and eligible and cin >= 128 and H * W <= 52 * 52) else None      # (offered; the measurement decides: 13x13 ... 26x26 at 416, 19x19 ... 38x38 at 608)
-    _hip.autotune_conv(p, x.device, wino_w=u, implicit_ok=not keep_v, wino_split=us if u is not None else None, split_plane=us_plane, f43=f43, wino_eligible=eligible)
-    if wp is None and (p.algo == 0 or (p.algo == 6 and u6 is None)):
+    dev = dev if dev is not None else (x if x is not None else (pre if pre is not None else y)).device
+    if peek:
+        return _hip.autotune_conv(p, dev, wino_w=u, implicit_ok=not keep_v, wino_split=us if u is not None else None, split_plane=us_plane, f43=f43, wino_eligible=eligible, peek=True)
+    _hip.autotune_conv(p, dev, wino_w=u, implicit_ok=not keep_v, wino_split=us if u is not None else None, split_plane=us_plane, f43=f43, wino_eligible=eligible)
+    if pre is not None:
+        if p.algo != 6:
+            raise RuntimeError('_conv: a transformed input serves the 4x4-tile form only (algorithm %d chosen)' % p.algo)
+        p.algo, p.x, p.ldx = 7, pre.data_ptr(), cin          # Y2_ALGO_WINOGRAD_F43_PRE
+    if wp is None and (p.algo == 0 or (p.algo in (6, 7) and u6 is None)):
         raise OperandPruned('algorithm %d reads the packed weight, which this step did not prepare' % p.algo)
     if note is not None:
-        note('w' if p.algo == 0 else '6' if p.algo == 6 else 'u')
+        note('w' if p.algo == 0 else '6' if p.algo in (6, 7) else 'u')
     kept = None
     if keep_v and p.algo in (1, 2):
         T = B * ((H + 1) // 2) * ((W + 1) // 2)
@@ -133,7 +144,7 @@ def _conv(L, st, x, wp, y, B, H, W, cin, ldx, cout, k, ldy, scale=None, shift=No
             kept = torch.empty(need // 4 + 4, dtype=torch.float32, device=x.device)
             p.workspace, p.workspace_bytes = kept.data_ptr(), kept.numel() * 4
     if kept is None:
-        _hip.conv_workspace(p, x.device)
+        _hip.conv_workspace(p, dev)
     _hip.check(L.y2_conv_fwd(ctypes.byref(p), st), 'y2_conv_fwd')
     return kept
 
@@ -574,7 +585,7 @@ def _darknet_bwd(ctx, dout):
             t = persistent((blk.name, 'dwp'), cop * blk.cin * blk.k * blk.k)
         if choice == 0:
             zero.append(t)
-        wg[i] = (t, final, choice == 0)
+        wg[i] = (t, final, choice == 0, choice)
     _hip.multi([(_hip.MULTI_ZERO, t, None) for t in zero], st)
     sums_used = 0
 
@@ -601,14 +612,31 @@ def _darknet_bwd(ctx, dout):
         need_dx = bool(getattr(ctx, 'need_dx', False))
         fuse0 = (FUSE_CONV0 and blk.first and i in wg and sf is None and sp is not None and not (h & 1) and not (w & 15)
                  and B * h * w * cout * 4 < 0xffff0000 and not need_dx)
-        dz = None if fuse0 else (dzs[i] if i in dzs else _new(dev, B, h, w, cop))
+        # A deep 3x3 block whose weight gradient AND data gradient both run the 4x4-tile Winograd forms reads dz only through their two transforms:
+        # y2_bn_act_bwd_wino6 writes those instead of dz (pass 2 + wino6_in x 2 in one kernel, bit-identical operands; csrc/train.hip).  Known in advance
+        # from the algorithm table (nothing is measured here: an unknown problem takes the three-kernel form and gets measured there).
+        ready_ops = ctx.prepared.get(blk.mod) if not blk.first else None
+        fused6 = None
+        if (FUSE_WINO6 and k == 3 and not blk.first and ready_ops is not None and sp is None and sf is not None and sf[3] == 0 and cop == cout and not e.padded
+                and i in wg and wg[i][3] == 2 and DEBUG_TAP is None and not _hip.DETERMINISTIC and not _hip.split_mode()):
+            hit = _conv(L, st, None, ready_ops['wd'], None, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'], grad=True, u_eligible=ready_ops['ud_ok'], u6=ready_ops.get('u6d'), peek=True, dev=dev)
+            if hit is not None and hit[0] == 6:
+                T6 = int(L.y2_wino6_tiles(B, h, w))
+                fused6 = (_new(dev, 36 * T6 * cout), _new(dev, 36 * T6 * cout))
+        dz = None if (fuse0 or fused6) else (dzs[i] if i in dzs else _new(dev, B, h, w, cop))
         if DEBUG_TAP is not None:
             DEBUG_TAP(blk.name + ':in', blk.z, blk.shift, sf, sp)
-        _hip.check(L.y2_bn_act_bwd(_hip.ptr(blk.z), _hip.ptr(blk.scale), _hip.ptr(blk.shift), _hip.ptr(blk.mean), _hip.ptr(blk.invstd),
-                                   _hip.ptr(e.gamma) if blk.has_bn else None, blk.slope,
-                                   _hip.ptr(sf[0]) if sf else None, sf[1] if sf else 0, sf[2] if sf else 0, sf[3] if sf else 0,
-                                   _hip.ptr(sp), cout, 0, _hip.ptr(sums), _hip.ptr(dz), cop, B, h, w, cout, cout,
-                                   (2 if ctx.frozen else 1) if blk.has_bn else 0, st), 'y2_bn_act_bwd')
+        if fused6:
+            _hip.check(L.y2_bn_act_bwd_wino6(_hip.ptr(blk.z), _hip.ptr(blk.scale), _hip.ptr(blk.shift), _hip.ptr(blk.mean), _hip.ptr(blk.invstd),
+                                             _hip.ptr(e.gamma) if blk.has_bn else None, blk.slope, _hip.ptr(sf[0]), sf[1], sf[2], _hip.ptr(sums),
+                                             _hip.ptr(fused6[0]), _hip.ptr(fused6[1]), None, 0, B, h, w, cout, cout,
+                                             (2 if ctx.frozen else 1) if blk.has_bn else 0, st), 'y2_bn_act_bwd_wino6')
+        else:
+            _hip.check(L.y2_bn_act_bwd(_hip.ptr(blk.z), _hip.ptr(blk.scale), _hip.ptr(blk.shift), _hip.ptr(blk.mean), _hip.ptr(blk.invstd),
+                                       _hip.ptr(e.gamma) if blk.has_bn else None, blk.slope,
+                                       _hip.ptr(sf[0]) if sf else None, sf[1] if sf else 0, sf[2] if sf else 0, sf[3] if sf else 0,
+                                       _hip.ptr(sp), cout, 0, _hip.ptr(sums), _hip.ptr(dz), cop, B, h, w, cout, cout,
+                                       (2 if ctx.frozen else 1) if blk.has_bn else 0, st), 'y2_bn_act_bwd')
         # parameter gradients of the affine part = the fp64 sums of pass 1: converted for ALL layers by one launch after the loop
         # (they are a few KB per layer; 23 separate 5-microsecond conversions were pure launch latency)
         if blk.has_bn:
@@ -649,11 +677,14 @@ def _darknet_bwd(ctx, dout):
                 dw4 = _new(dev, cop, 4, k, k)
                 _hip.check(L.y2_unpack_weight_grad(_hip.ptr(dwp), _hip.ptr(dw4), cop, 4, k, st_w), 'y2_unpack_weight_grad')
                 return dw4[:e.cout_r, :cin].contiguous()
-            tgt, final, zeroed = wg[i]
+            tgt, final, zeroed = wg[i][:3]
             dw = None
             if k == 3:
                 dw = dest(weight) if (cop == cout and not e.padded) else _new(dev, cop, cin, k, k)
-            got = _hip.conv_wgrad(blk.x, dz, B, h, w, cin, blk.ldx, cop, cop, k, v=blk.wino_v, out=tgt, zeroed=zeroed, native=dw)     # direct or Winograd, by measurement
+            if fused6:
+                got = _hip.conv_wgrad(blk.x, fused6[1], B, h, w, cin, blk.ldx, cop, cop, k, v=blk.wino_v, out=tgt, zeroed=zeroed, native=dw, dz_pre=True)
+            else:
+                got = _hip.conv_wgrad(blk.x, dz, B, h, w, cin, blk.ldx, cop, cop, k, v=blk.wino_v, out=tgt, zeroed=zeroed, native=dw)     # direct or Winograd, by measurement
             if final:
                 return tgt.view(cout, cin, 1, 1)
             if k == 1:
@@ -674,7 +705,7 @@ def _darknet_bwd(ctx, dout):
                 gw = weight_grad(_hip.stream())
                 done = torch.cuda.Event()
                 done.record(side)
-            held = (dz, blk.x, blk.wino_v, ctx.x) + ((blk.z, sp) if fuse0 else ())
+            held = (dz, blk.x, blk.wino_v, ctx.x) + ((blk.z, sp) if fuse0 else ()) + ((fused6[1],) if fused6 else ())
             flush_weight_grads(keep=1)
             late.append([weight, gw, done, held])
         else:
@@ -696,7 +727,10 @@ def _darknet_bwd(ctx, dout):
             # data gradient -> the producer's gradient source
             dx = _new(dev, B, h, w, cin)
             ready_ops = ctx.prepared.get(blk.mod)
-            if ready_ops is not None:        # rotated / in-out-swapped operands prepared with the forward's (same parameter version)
+            if fused6:
+                _conv(L, st, None, ready_ops['wd'], dx, B, h, w, cop, cop, cin, k, cin, u=ready_ops['ud'], grad=True,
+                      note=lambda kind, m=blk.mod: ctx.used.add((m, 'wd' if kind == 'w' else 'u6d' if kind == '6' else 'ud')), u_eligible=ready_ops['ud_ok'], u6=ready_ops.get('u6d'), pre=fused6[0])
+            elif ready_ops is not None:        # rotated / in-out-swapped operands prepared with the forward's (same parameter version)
                 # (the fp16 split mode is for activations: its fixed operand scales assume O(1) values, and gradients are 1e-5 and smaller -
                 # their fp16 planes would be subnormal; data gradients stay on the fp32 / bf16-split algorithms)
                 dg_split = ready_ops['uds'] if _hip.split_mode() == 'bf16' else None
