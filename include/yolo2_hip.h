@@ -197,6 +197,8 @@ int y2_wino6_weight(const float* w_packed, float* u6, int32_t Cout, int32_t Cin,
  * weight gradient; 16 reductions over ceil(H/2)*ceil(W/2) tiles per image instead of 9 over H*W pixels.  Cin, Cout, ldx,
  * ldz multiples of 4; workspace of y2_wino_wgrad_workspace_bytes() bytes (transformed input, transformed gradient, dU). */
 long long y2_wino_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
+/* The same for ONE form (native_layout as y2_wino_wgrad_ex takes it; what that entry point requires): the 4x4-tile form needs 36/64 of the 2x2-tile form's rows. */
+long long y2_wino_wgrad_workspace_bytes_ex(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t native_layout);
 int y2_wino_wgrad(const float* x, const float* dz, float* dw_packed, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t ldx,
                   int32_t Cout, int32_t ldz, const float* v_transformed, float* workspace, long long workspace_bytes, y2_stream_t stream);
 /* ... native_layout bit 0: the result is written as dw[Cout][Cin][3][3] - nn.Conv2d.weight.grad's own layout (model/yolo2.py:57), no

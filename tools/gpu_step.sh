@@ -1,3 +1,10 @@
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-for i in 1 2 3 4 5 6; do timeout 600 python -u -m pytest tests/test_gpu_dp.py -q -m gpu --tb=line -rf --timeout=300 -k "equals_concatenated" 2>&1 | grep -v "^WARNING\|WARNING  root\|Gloo\|amdgpu.ids\|socket.cpp" | tail -2; done
+bash tools/gpu_final.sh tune
+echo "=== arena probe"; timeout 600 python tools/arena_probe.py reserve > gpurun_out/arena_reserve.json 2> gpurun_out/arena_reserve.err; python - <<'PY'
+import json
+d=json.load(open('gpurun_out/arena_reserve.json'))
+print({k:v for k,v in d.items() if k not in ('per_size',)})
+for r in d['per_size']: print(r['size'], r['first_visit_ms'], r['ms_per_step'], r['reserved_gib'], r['allocated_gib'])
+PY
+grep -v amdgpu.ids gpurun_out/arena_reserve.err | tail -5

@@ -81,6 +81,7 @@ SIGNATURES = {
     'y2_opt_grad_sumsq': [ctypes.POINTER(OptTensor), c_int, c_void_p, c_void_p],
     'y2_opt_clip_grads': [ctypes.POINTER(OptTensor), c_int, c_void_p, c_float, c_void_p],
     'y2_wino_wgrad_workspace_bytes': [c_int, c_int, c_int, c_int, c_int],
+    'y2_wino_wgrad_workspace_bytes_ex': [c_int, c_int, c_int, c_int, c_int, c_int],
     'y2_wino_wgrad': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_longlong, c_void_p],
     'y2_wino_wgrad_ex': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_void_p],
     'y2_conv_fwd_batch': [ctypes.POINTER(ConvParams), c_int, c_void_p],
@@ -164,6 +165,7 @@ def lib():
         l.y2_conv_fwd_workspace_bytes.restype = ctypes.c_longlong
         l.y2_wino_wgrad_workspace_bytes.restype = ctypes.c_longlong
         l.y2_wino6_tiles.restype = ctypes.c_longlong
+        l.y2_wino_wgrad_workspace_bytes_ex.restype = ctypes.c_longlong
         l.y2_build_info.argtypes = []
         l.y2_build_info.restype = ctypes.c_char_p
         _lib = l
@@ -792,7 +794,7 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
         # `dz` is the transformed gradient [36][T][cout] of the 4x4-tile form (y2_bn_act_bwd_wino6): the caller looked the choice up before it built it
         if choice != 2:
             raise RuntimeError('conv_wgrad: a transformed gradient serves the 4x4-tile form only (choice %r)' % (choice,))
-        need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
+        need = L.y2_wino_wgrad_workspace_bytes_ex(B, H, W, cin, cout, 6)
         ws = _wgrad_scratch(dev, need)
         dst = native if native is not None else (out if out is not None else torch.empty(nw, dtype=torch.float32, device=dev))
         check(L.y2_wino_wgrad_ex(ptr(x), ptr(dz), ptr(dst), B, H, W, cin, ldx, cout, cout, None, ptr(ws), ws.numel() * 4, 7 if native is not None else 6, st), 'y2_wino_wgrad_ex')
@@ -802,7 +804,7 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
     # the direct kernel accumulates split partial sums into a zeroed buffer; the Winograd path overwrites (no fill needed)
     if native is not None and choice in (1, 2) and eligible_wino(cout, cin, k, ldx, ldz):
         assert native.numel() == nw and native.is_contiguous()
-        need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
+        need = L.y2_wino_wgrad_workspace_bytes_ex(B, H, W, cin, cout, 1 if choice == 1 else 3)
         ws = _wgrad_scratch(dev, need)
         check(L.y2_wino_wgrad_ex(ptr(x), ptr(dz), ptr(native), B, H, W, cin, ldx, cout, ldz, ptr(v) if choice == 1 else None, ptr(ws), ws.numel() * 4,
                                  1 if choice == 1 else 3, st), 'y2_wino_wgrad_ex')
@@ -819,7 +821,7 @@ def conv_wgrad(x, dz, B, H, W, cin, ldx, cout, ldz, k, v=None, out=None, zeroed=
         return dwp
     ws = None
     if choice != 0:      # (a layer whose measured choice is the direct kernel needs no Winograd scratch: the 208x208 layer alone would size it at 4-9 GB)
-        need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout)
+        need = L.y2_wino_wgrad_workspace_bytes(B, H, W, cin, cout) if choice is None else L.y2_wino_wgrad_workspace_bytes_ex(B, H, W, cin, cout, 2 if choice == 2 else 0)
         ws = _wgrad_scratch(dev, need)
 
     def wino():
