@@ -1,10 +1,7 @@
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-bash tools/gpu_final.sh tune
-echo "=== arena probe"; timeout 600 python tools/arena_probe.py reserve > gpurun_out/arena_reserve.json 2> gpurun_out/arena_reserve.err; python - <<'PY'
-import json
-d=json.load(open('gpurun_out/arena_reserve.json'))
-print({k:v for k,v in d.items() if k not in ('per_size',)})
-for r in d['per_size']: print(r['size'], r['first_visit_ms'], r['ms_per_step'], r['reserved_gib'], r['allocated_gib'])
-PY
-grep -v amdgpu.ids gpurun_out/arena_reserve.err | tail -5
+bash tools/gpu_final.sh tests smoke
+PROFILE_ROUND=r06 bash tools/gpu_profile.sh 2>&1 | tail -6
+Y2_BWD_STREAMS=1 timeout 300 python tools/train_table.py 64 > gpurun_out/r06_train_b64_layer_table.txt 2>/dev/null; tail -1 gpurun_out/r06_train_b64_layer_table.txt
+for f in detect_b32_traffic.json train_b64_traffic.json; do cp gpurun_out/prof/$f profiles/r06_$f; done
+bash tools/gpu_final.sh driver bench contention
