@@ -14,13 +14,14 @@ Legs (every timed region: W untimed warm-up steps, barrier + synchronize, EXACTL
            (lr 1e-3, momentum 0.9; quick_start.sh:71).  N > 1: data parallel through train.ensure_model (bucketed RCCL
            all-reduce overlapped with backward, positive-count all-reduce), weak scaling; the same step WITHOUT the wrapper is
            timed beside it on every rank (`train.single_gpu_images_per_sec`: the denominator of the DP scaling efficiency).
-  Headline `value`: detect at N = 1 (BASELINE configs[1]); the data-parallel train step at N > 1 (north_star: ">= 6x DP
-           scaling 1 -> 8"), with the other leg reported beside it (`detect` / `train` objects).  --headline overrides.
+  Headline `value`: the batch-64 training step (BASELINE configs[2]) at EVERY N - one workload for the whole scaling curve (north_star:
+           ">= 6x DP scaling 1 -> 8"); detect is reported beside it (`roofline.detect_*` / `summary.detect_*`).  --headline overrides.
 
 Roofline (N = 1, measured in this run with the library's per-kernel HIP-event hooks, y2_prof_*, on the launch stream):
-  roofline         dominant kernel of the detect step: executed multiply-add FLOPs per launch / average launch duration against
-                   the fp32-input MFMA peak (157.3 TFLOP/s) -> frac <= 1 by construction; `top_kernels` lists every kernel
-                   with >= 1 % of the step; `conv_chain` gives the whole 23-conv chain (executed and direct-equivalent rates).
+  roofline         dominant MFMA kernel TEMPLATE of the headline step: executed multiply-add FLOPs per step of all its launches / its time per step against
+                   the fp32-input MFMA peak (157.3 TFLOP/s).  `frac`: time from the committed rocprofv3 trace of the timed schedule (profiles/*_traffic.json,
+                   same kernel sources, same launches per step; else the event-hook figure, see `frac_source`); `frac_uncontended`: HIP event pairs per launch
+                   in this run (eager, single stream); `step_frac_executed` / `step_frac_direct_equiv`: the whole timed step in executed / SURVEY 8d FLOPs.
   conv3x3_b64      north_star's target quantity: the 3x3 convolutions at batch 64, per-layer event pairs, Winograd on and off.
   train.roofline   the same per-kernel table for the training step (executed FLOPs of fprop / dgrad / wgrad kernels).
   cpu_baseline     the CPU oracle (port of the reference path) on this box's host cores, bounded sample, rank 0 at N = 1 only: batch-16 chunks, the
