@@ -431,12 +431,11 @@ def detect_leg(args, ctx):
     d2h_dt = None
     if ctx.world == 1 and getattr(measure, 'runs', None):
         # the reference hands the survivors to the host (utils/postprocess.py:34-49 returns a Python list; detect.py:69-79 indexes with it): the same replays, each
-        # followed by the per-class expansion (y2_expand_classes), the host round trip for the counts and the copy of every image's detections to host memory
+        # followed by the per-class expansion (y2_expand_classes) and the copy of the batch's detections to host memory (one copy per result buffer, one synchronisation)
         runs, nd = measure.runs, min(args.steps, 24)
 
         def to_host(i):
-            res = detect.postprocess_batch(runs[i % len(runs)].run(), fix=True, threshold_cls=kw['threshold_cls'])
-            return [None if r is None else tuple(t.cpu() for t in r) for r in res]
+            return detect.postprocess_batch(runs[i % len(runs)].run(), fix=True, threshold_cls=kw['threshold_cls'], to_host=True)
         to_host(0)
         d2h_dt = ctx.timed(to_host, nd)[0] / nd
     images = args.batch * args.steps * ctx.world

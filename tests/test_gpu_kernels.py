@@ -596,6 +596,13 @@ def test_detect_batch_random_configurations_vs_oracle(rows, cols, C, B, fix, thr
         if ref is not None:
             for got, want in zip(res[b], ref[:5]):
                 np.testing.assert_array_equal(got.cpu().numpy(), want)
+    # the same detections handed over on the host (one copy per result buffer instead of five per image): identical values
+    host = detect.postprocess_batch(d, fix=fix, to_host=True, **(dict(threshold_cls=thr) if fix else {}))
+    for b in range(B):
+        assert (host[b] is None) == (res[b] is None)
+        if host[b] is not None:
+            for got, want in zip(host[b], res[b]):
+                assert not got.is_cuda and torch.equal(got, want.cpu())
 
 
 # ------------------------------------------------------------------ general convolution (ResNet plugin: model/resnet.py)

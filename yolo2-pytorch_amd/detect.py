@@ -107,15 +107,23 @@ def detect_batch(feature_nhwc, anchors, fix=False, threshold=0.3, threshold_cls=
     return d
 
 
-def postprocess_batch(d, fix=False, threshold_cls=0.005):
+def postprocess_batch(d, fix=False, threshold_cls=0.005, to_host=False):
     """a22 (detect.py:69-79) for every image of a detect_batch result: ONE launch (y2_expand_classes: gather of the survivors and, with
     `fix`, their expansion into (box, class) detections in row-major order) and one host synchronisation for the counts.
-    Returns a list (per image) of None or (iou, yx_min, yx_max, cls, score) GPU tensors (views of the batch's result buffers)."""
+    Returns a list (per image) of None or (iou, yx_min, yx_max, cls, score) GPU tensors (views of the batch's result buffers).
+    to_host: the tuples hold CPU tensors - the whole batch's result buffers cross PCIe in ONE copy per buffer (six copies, one synchronisation) and are sliced
+    on the host, instead of five small copies and a synchronisation per image (what calling .cpu() on the GPU views costs: the consumer of the reference's
+    postprocess works on the host, utils/postprocess.py:34-49 returns a Python list)."""
     keep = d['keep']
     B, limit = keep.shape
     n = d['iou'].numel() // B
     k_iou, k_min, k_max, e_min, e_max, e_score, e_cls, e_count = _expand(d['iou'].view(B, n), d['prob'].view(B, n, -1), d['yx_min'].view(B, n, 2), d['yx_max'].view(B, n, 2),
                                                                         d['index'], keep, d['keep_count'], fix, threshold_cls)
+    if to_host and fix:
+        bufs = [t.to('cpu', non_blocking=True) for t in (torch.stack([d['keep_count'], e_count]), k_iou, e_min, e_max, e_cls, e_score)]
+        torch.cuda.current_stream().synchronize()
+        counts, h_iou, h_min, h_max, h_cls, h_score = bufs[0].tolist(), bufs[1], bufs[2], bufs[3], bufs[4], bufs[5]
+        return [None if counts[0][b] == 0 else (h_iou[b, :counts[0][b]], h_min[b, :counts[1][b]], h_max[b, :counts[1][b]], h_cls[b, :counts[1][b]], h_score[b, :counts[1][b]]) for b in range(B)]
     counts = (torch.stack([d['keep_count'], e_count]) if fix else d['keep_count'].view(1, B)).tolist()      # the one host round trip
     out = []
     for b in range(B):
@@ -128,6 +136,8 @@ def postprocess_batch(d, fix=False, threshold_cls=0.005):
         else:
             src = d['index'][b].long()[keep[b, :k].long()]
             out.append((k_iou[b, :k], k_min[b, :k], k_max[b, :k], d['cls'].view(B, n)[b][src].long(), k_iou[b, :k]))
+    if to_host:
+        out = [None if r is None else tuple(t.cpu() for t in r) for r in out]
     return out
 
 
