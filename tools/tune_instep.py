@@ -47,12 +47,17 @@ def main():
     ap.add_argument('--only', default='all', choices=['all', 'wgrad', 'conv'])
     ap.add_argument('--min-hw', type=int, default=0, help='only entries of maps with at least this many pixels per side')
     ap.add_argument('--write', action='store_true')
+    ap.add_argument('--detect', action='store_true', help='the batch-32 detect step (BASELINE configs[1]: conv stack + decode + filter + NMS, one captured graph, serial replays) instead of the training step')
     args = ap.parse_args()
+    if args.detect and args.batch == 64:
+        args.batch = 32
     dev = torch.device('cuda', 0)
     _hip.load_tune_defaults(dev)
     table = Recording(_hip._TUNE)
     _hip._TUNE = table
     inf, anchors = bench_data.build_model(args.classes, dev, 'darknet')
+    if args.detect:
+        return detect_descent(args, dev, table, inf, anchors)
     inf.train()
     opt = utils.optim.SGD(inf.parameters(), 0.0, momentum=0.9)          # learning rate 0: every trial runs the same arithmetic on the same weights
     data = {k: v.to(dev) for k, v in bench_data.labels(args.batch, args.size, args.classes, seed=2).items()}
@@ -133,6 +138,69 @@ def main():
         old = json.load(open(path))
         n = _hip.save_tune_defaults(note=old.get('note', '') + '; %d entries re-decided in the timed step by tools/tune_instep.py (batch %d, %dx%d)' % (len(changed), args.batch, args.size, args.size))
         print('wrote %s (%d entries)' % (path, n))
+
+
+def detect_descent(args, dev, table, inf, anchors):
+    import detect
+    inf.eval()
+    dnn = inf.dnn
+    x = bench_data.images(args.batch, args.size, seed=1).to(dev)
+    kw = dict(fix=True, threshold_cls=0.005, overlap=0.45, limit=200)
+
+    def measure():
+        dnn._plan_cache = None                        # the plan is rebuilt on the current table
+        run = detect.GraphedDetector(dnn, anchors, x, static_input=True, **kw)
+        for _ in range(5):
+            run.run()
+        torch.cuda.synchronize()
+        best = float('inf')
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                run.run()
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) / args.steps)
+        return best
+    table.seen = []
+    with torch.no_grad():
+        detect.detect_batch(dnn.forward_nhwc(x), anchors, **kw)
+    torch.cuda.synchronize()
+    keys = []
+    for k in table.seen:
+        if k in table and k not in keys and k[0] != 'wgrad':
+            keys.append(k)
+    table.seen = None
+    base = measure()
+    print('baseline %.4f ms per detect step (serial replays), %d table entries read' % (base, len(keys)), flush=True)
+    changed = []
+    for k in keys:
+        cur = table[k]
+        algo, tile = (tuple(cur) if isinstance(cur, (list, tuple)) else (0, cur))
+        ksize, wino_ok, implicit_ok = k[6], k[18], k[19]
+        cands = [(0, t) for t in (1, 2, 3, 5)] + ([(0, t) for t in (11, 12, 13, 15)] if ksize == 1 and not k[8] else [])
+        if ksize == 3 and wino_ok:
+            cands += [(1, 5), (1, 3), (1, 2), (2, 0), (2, 3)] + ([(3, 0), (3, 3)] if implicit_ok else [])
+        for alt in [c for c in cands if tuple(c) != (algo, tile)]:
+            table[k] = list(alt)
+            try:
+                t = measure()
+            except Exception as e:
+                t = float('inf')
+            if t < base - args.margin:
+                print('KEEP %s: %s -> %s  %.4f -> %.4f ms' % (list(k[:10]), cur, alt, base, t), flush=True)
+                changed.append((k, cur, alt, base, t))
+                base, cur = t, list(alt)
+            else:
+                table[k] = cur
+    final = measure()
+    print('after one pass: %.4f ms per detect step, %d entries changed' % (final, len(changed)), flush=True)
+    if args.write and changed:
+        _hip._TUNE = dict(table)
+        old = json.load(open(_hip.DEFAULTS_PATH))
+        n = _hip.save_tune_defaults(note=old.get('note', '') + '; %d detect entries re-decided in the timed step by tools/tune_instep.py --detect' % len(changed))
+        print('wrote %s (%d entries)' % (_hip.DEFAULTS_PATH, n))
 
 
 if __name__ == '__main__':
