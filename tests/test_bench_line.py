@@ -127,3 +127,32 @@ def test_static_traffic_equals_the_per_kernel_table():
         total_gb = float(re.search(r'total ([0-9.]+) GB per step', tab).group(1))
         # the table covers EVERY kernel of the run (decode / NMS included: a few MB), the figure the conv chain - they agree to the table's rounding
         assert abs(total_gb - want['traffic_bytes_per_step'] / 1e9) <= 0.06 + 0.005 * total_gb, (tag, total_gb, want['traffic_bytes_per_step'])
+
+
+def test_trace_families_names_kernel_templates_like_the_hook_table(tmp_path):
+    """tools/trace_families.py groups the dispatches of a rocprofv3 trace by kernel TEMPLATE (the name bench.roofline_from derives from the library's hook names):
+    a synthetic rocpd database with two steps of two kernels, one warm-up dispatch in front of the window."""
+    import sqlite3
+    db = str(tmp_path / 't.db')
+    con = sqlite3.connect(db)
+    con.execute('create table rocpd_info_kernel_symbol_x (id integer, kernel_name text)')
+    con.execute('create table rocpd_kernel_dispatch_x (kernel_id integer, start integer, end integer)')
+    names = {1: '_ZN12_GLOBAL__N_119conv_fwd_dma_kernelILi64ELi128ELi2ELb0ELb0ELi2ELb0ELi256ELb0EEEvNS_8ConvArgsE.kd', 2: '_ZN12_GLOBAL__N_115loss_fwd_kernelENS_8LossArgsEPdS1_.kd',
+             3: '_Z16zero_fill_kernelP15HIP_vector_typeIfLj4EEm.kd'}
+    for i, n in names.items():
+        con.execute('insert into rocpd_info_kernel_symbol_x values (?, ?)', (i, n))
+    t = 0
+    rows = [(3, 5000)]                                                   # a warm-up dispatch
+    for step in range(3):                                               # three step markers = two whole steps in the window
+        rows += [(2, 1000), (1, 300000), (1, 200000)]
+    for kid, dur in rows:
+        con.execute('insert into rocpd_kernel_dispatch_x values (?, ?, ?)', (kid, t, t + dur))
+        t += dur + 100
+    con.commit()
+    con.close()
+    out = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, 'tools', 'trace_families.py'), db, 'loss_fwd_kernel', '0.0']))
+    assert out['steps'] == 2
+    f = out['families']
+    assert f['conv_fwd_dma_kernel'] == {'calls': 4, 'total_us': 1000.0} and f['loss_fwd_kernel']['calls'] == 2 and 'zero_fill_kernel' not in f
+    import bench
+    assert bench.family('conv_fwd_dma_kernel[grouped]') == 'conv_fwd_dma_kernel'
