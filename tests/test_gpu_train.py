@@ -506,8 +506,11 @@ def test_maxpool3x3s2_forward_backward():
     import _hip
     L = _hip.lib()
     d = dev()
-    for (B, C, H, W) in ((2, 8, 12, 14), (1, 6, 9, 9)):
+    # (the 32-channel-multiple shapes take the LDS-tiled backward kernel: tiles of 8 x 32 pixels, ragged edges, several tiles per dimension, ties)
+    for (B, C, H, W) in ((2, 8, 12, 14), (1, 6, 9, 9), (2, 32, 12, 14), (1, 64, 19, 23), (3, 32, 8, 32), (1, 32, 40, 70), (2, 64, 33, 65)):
         x = torch.randn(B, C, H, W, dtype=torch.float64, requires_grad=True)
+        if C == 32 and H == 40:
+            x = (x * 2).round().div(2).detach().requires_grad_(True)          # many equal values: the FIRST maximum in scan order takes the gradient
         y = F.max_pool2d(x, 3, 2, 1)
         dy = torch.randn(y.shape, dtype=torch.float64)
         dy2 = torch.randn(y.shape, dtype=torch.float64)

@@ -555,6 +555,92 @@ __global__ void maxpool_bwd4_kernel(const float* __restrict__ x, const float* __
     }
 }
 
+// nn.MaxPool2d(3, stride 2, padding 1) backward (the stem pool of model/resnet.py:114), LDS-tiled.  The gather kernels above re-derive the arg-max of up to four
+// windows PER INPUT PIXEL - 36 16-byte loads and as many compares per thread (1.63 ms for 757 MB of input at batch 32, 608x608: a fifth of the HBM rate).  Here a
+// workgroup owns an 8 x 32-pixel x 32-channel tile: the input rows / columns its windows touch ((8 + 3) x (32 + 3) pixels, 128 contiguous bytes per pixel) are
+// staged in LDS once, every window's first maximum (scan order, strict >: ATen's) is found once and kept as a byte, and a pixel then looks up the at most four
+// windows it belongs to.  x is read once, dy once, dx written once.
+constexpr int MP_TH = 8, MP_TW = 32, MP_CH = 32;
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ dy2, float* __restrict__ dx,
+                                                            int H, int W, int Ho, int Wo, int cgroups, int ldx, int ldy, int lddx) {
+    constexpr int RH = MP_TH + 3, RW = MP_TW + 3;                 // staged rows / columns: y0 - 1 .. y0 + TH + 1
+    constexpr int WH = MP_TH / 2 + 1, WW = MP_TW / 2 + 1;         // windows that contain a pixel of the tile
+    __shared__ __attribute__((aligned(16))) float xs[RH * RW * MP_CH];
+    __shared__ unsigned char arg[WH * WW * MP_CH];
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * MP_TW, y0 = blockIdx.y * MP_TH;
+    const int b = blockIdx.z / cgroups, c0 = (blockIdx.z - b * cgroups) * MP_CH;
+    const float* xb = x + (size_t)b * H * W * ldx + c0;
+    // ---- stage the input (pixels outside the image are never looked at below)
+    for (int i = t; i < RH * RW * (MP_CH / 4); i += 256) {
+        const int c4 = i % (MP_CH / 4), p = i / (MP_CH / 4);
+        const int px = p % RW, py = p / RW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *reinterpret_cast<const float4*>(xb + ((size_t)gy * W + gx) * ldx + 4 * c4);
+        *reinterpret_cast<float4*>(xs + (py * RW + px) * MP_CH + 4 * c4) = v;
+    }
+    __syncthreads();
+    // ---- first maximum of every window (oy, ox) = (y0 / 2 + wy, x0 / 2 + wx): input rows 2 oy - 1 .. 2 oy + 1 = staged rows 2 wy .. 2 wy + 2
+    for (int i = t; i < WH * WW * MP_CH; i += 256) {
+        const int c = i % MP_CH, w = i / MP_CH;
+        const int wx = w % WW, wy = w / WW;
+        const int oy = y0 / 2 + wy, ox = x0 / 2 + wx;
+        int at = 255;
+        if (oy < Ho && ox < Wo) {
+            float best = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int gy = 2 * oy - 1 + ky;
+                if ((unsigned)gy >= (unsigned)H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int gx = 2 * ox - 1 + kx;
+                    if ((unsigned)gx >= (unsigned)W) continue;
+                    const float v = xs[((2 * wy + ky) * RW + 2 * wx + kx) * MP_CH + c];
+                    if (at == 255 || v > best) { best = v; at = ky * 3 + kx; }
+                }
+            }
+        }
+        arg[i] = (unsigned char)at;
+    }
+    __syncthreads();
+    // ---- every pixel of the tile: the gradient of each window whose first maximum it is
+    const float* dyb = dy + (size_t)b * Ho * Wo * ldy + c0;
+    const float* dy2b = dy2 != nullptr ? dy2 + (size_t)b * Ho * Wo * ldy + c0 : nullptr;
+    for (int i = t; i < MP_TH * MP_TW * (MP_CH / 4); i += 256) {
+        const int c4 = i % (MP_CH / 4), p = i / (MP_CH / 4);
+        const int lx = p % MP_TW, ly = p / MP_TW;
+        const int yy = y0 + ly, xx = x0 + lx;
+        if (yy >= H || xx >= W) continue;
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        // windows: oy in {ceil((yy - 1) / 2) .. (yy + 1) / 2}: local wy = oy - y0 / 2
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int oy = (yy + 1) / 2 - a;
+            if (oy < 0 || oy >= Ho || 2 * oy - 1 > yy || 2 * oy + 1 < yy) continue;
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int ox = (xx + 1) / 2 - bb;
+                if (ox < 0 || ox >= Wo || 2 * ox - 1 > xx || 2 * ox + 1 < xx) continue;
+                const int mine = (yy - (2 * oy - 1)) * 3 + (xx - (2 * ox - 1));
+                const unsigned char* aw = arg + ((oy - y0 / 2) * WW + (ox - x0 / 2)) * MP_CH + 4 * c4;
+                const bool m0 = aw[0] == mine, m1 = aw[1] == mine, m2 = aw[2] == mine, m3 = aw[3] == mine;
+                if (m0 || m1 || m2 || m3) {
+                    const size_t o = ((size_t)oy * Wo + ox) * ldy + 4 * c4;
+                    float4 d = *reinterpret_cast<const float4*>(dyb + o);
+                    if (dy2b != nullptr) { const float4 e = *reinterpret_cast<const float4*>(dy2b + o); d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
+                    if (m0) g[0] += d.x;
+                    if (m1) g[1] += d.y;
+                    if (m2) g[2] += d.z;
+                    if (m3) g[3] += d.w;
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(dx + ((size_t)(b * H + yy) * W + xx) * lddx + c0 + 4 * c4) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+}
+
 // per-channel column sums of a [M, C] (stride ld) matrix -> fp64 atomics (conv-bias gradient of blocks without BN)
 __global__ void colsum_kernel(const float* __restrict__ x, long long M, int C, int ld, double* out) {
     extern __shared__ float red[];
@@ -1054,6 +1140,14 @@ extern "C" int y2_maxpool_bwd(const float* x, const float* dy, const float* dy2,
     const int Ho = (H + pad + pad_end - ksize) / stride + 1, Wo = (W + pad + pad_end - ksize) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return Y2_EINVAL;
     const long long total = (long long)B * H * W * C;
+    const bool aligned = !(C & 3) && !(ldx & 3) && !(ldy & 3) && !(lddx & 3) && y2_aligned16(x) && y2_aligned16(dy) && y2_aligned16(dx) && (!dy2 || y2_aligned16(dy2));
+    static const bool tiled_env = getenv("Y2_POOL_BWD_TILED") == nullptr || atoi(getenv("Y2_POOL_BWD_TILED")) != 0;
+    if (tiled_env && aligned && ksize == 3 && stride == 2 && pad == 1 && !(C % MP_CH) && (long long)B * (C / MP_CH) < 65535 && (long long)H * W * ldx < 0x7fffffffLL) {
+        const dim3 grid((unsigned)y2_cdiv(W, MP_TW), (unsigned)y2_cdiv(H, MP_TH), (unsigned)(B * (C / MP_CH)));
+        Y2_LAUNCH("maxpool_bwd_kernel", 0.0, maxpool3s2_bwd_kernel, grid, dim3(256), 0, y2_s(stream), x, dy, dy2, dx, H, W, Ho, Wo, C / MP_CH, ldx, ldy, lddx);
+        Y2_LAUNCH_CHECK();
+        return Y2_OK;
+    }
     if (!(C & 3) && !(ldx & 3) && !(ldy & 3) && !(lddx & 3) && y2_aligned16(x) && y2_aligned16(dy) && y2_aligned16(dx) && (!dy2 || y2_aligned16(dy2)) && (long long)B * H < 65535
         && (long long)H * W * ldx < 0x7fffffffLL) {
         const int per_row = W * (C / 4);
