@@ -359,6 +359,50 @@ def test_conv0_matches_fp64_reference(B, cin, cout, H, W):
     np.testing.assert_allclose(st[cout:].cpu().numpy(), (z * z).sum((0, 2, 3)).numpy(), rtol=1e-5)
 
 
+@pytest.mark.parametrize('cout', [32, 64])
+def test_conv0_specialised_epilogues_equal_the_general_kernel(cout):
+    """The tile-aligned first layer runs straight-line variants of conv0_kernel (csrc/conv0_fwd.hip launch0): pooled-only takes the 2x2 max BEFORE affine + LeakyReLU
+    with the sign of the scale folded into the weights (claimed exact, scales of both signs here), the training forward stores raw z with packed statistics.
+    All outputs of one call (out mask 7) come from the general kernel: the reference for every variant."""
+    import _hip
+    L = _hip.lib()
+    d = dev()
+    g = torch.Generator().manual_seed(17 + cout)
+    B, H, W = 3, 48, 96
+    x = torch.randn(B, 3, H, W, generator=g).to(d)
+    w = (torch.randn(cout, 3, 3, 3, generator=g) * 0.3).to(d)
+    sc = torch.randn(cout, generator=g).to(d)
+    sh = (torch.randn(cout, generator=g) * 0.1).to(d)
+    assert (sc < 0).any() and (sc > 0).any()
+
+    def call(scale, shift, want_y, want_pool, want_stats, slope):
+        y = torch.full((B, H, W, cout), -7.0, device=d) if want_y else None
+        yp = torch.full((B, H // 2, W // 2, cout), -7.0, device=d) if want_pool else None
+        st = torch.zeros(32 * 2 * cout, dtype=torch.float64, device=d) if want_stats else None
+        _hip.check(L.y2_conv0_fwd(_hip.ptr(x), _hip.ptr(w), _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(y), _hip.ptr(yp), _hip.ptr(st),
+                                  B, H, W, 3, cout, cout if want_y else 0, cout if want_pool else 0, slope, _hip.stream()), 'conv0')
+        torch.cuda.synchronize()
+        return y, yp, (st.view(32, -1).sum(0) if want_stats else None)
+
+    for slope in (0.1, 1.0, 0.0):
+        y7, p7, _ = call(sc, sh, True, True, True, slope)
+        _, p2, _ = call(sc, sh, False, True, False, slope)             # pool-first
+        assert torch.equal(p2, p7), 'pooled-only (slope %g)' % slope
+        y1, _, _ = call(sc, sh, True, False, False, slope)
+        assert torch.equal(y1, y7)
+    _, pneg, _ = call(sc, sh, False, True, False, -0.5)                # a non-monotone activation: the general kernel
+    y7n, p7n, _ = call(sc, sh, True, True, True, -0.5)
+    assert torch.equal(pneg, p7n)
+    # training forward: raw z + statistics
+    z7, _, st7 = call(None, None, True, True, True, 1.0)
+    z5, _, st5 = call(None, None, True, False, True, 1.0)
+    assert torch.equal(z5, z7)
+    np.testing.assert_allclose(st5.cpu().numpy(), st7.cpu().numpy(), rtol=2e-6, atol=1e-4)
+    ref = z7.double()
+    np.testing.assert_allclose(st5[:cout].cpu().numpy(), ref.sum((0, 1, 2)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(st5[cout:].cpu().numpy(), (ref * ref).sum((0, 1, 2)).cpu().numpy(), rtol=1e-5)
+
+
 def test_maxpool2():
     import _hip
     for C in (16, 6):   # 16-B vector path and scalar path (pruned widths)

@@ -1,2 +1,2 @@
 #!/bin/bash
-cd "$(dirname "$0")" && "${HIPCC:-/opt/rocm/bin/hipcc}" --offload-arch=gfx950 -O2 -shared -fPIC spin.hip -o libspin.so && echo built libspin.so
+cd "$(dirname "$0")" && for f in spin mfma_peak; do "${HIPCC:-/opt/rocm/bin/hipcc}" --offload-arch=gfx950 -O2 -shared -fPIC $f.hip -o lib$f.so && echo built lib$f.so; done

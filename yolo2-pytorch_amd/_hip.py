@@ -420,6 +420,9 @@ def kernel_hash():
     for f in files:
         h.update(os.path.basename(f).encode())
         for line in open(f, 'r', errors='replace'):
+            if line.startswith('// y2-build-flags:'):          # per-file code generation options (csrc/build.sh) are code
+                h.update(line.strip().encode())
+                h.update(b'\n')
             # code only: a // comment (outside a string literal) and blank lines do not make measured choices or profiles stale
             cut = line.find('//')
             while cut >= 0 and line.count('"', 0, cut) % 2:

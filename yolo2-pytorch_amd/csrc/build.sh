@@ -13,7 +13,8 @@ pids=()
 for f in "$HERE"/*.hip; do
     o="$OBJ/$(basename "${f%.hip}").o"
     if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$ROOT/include/yolo2_hip.h" -nt "$o" ]; then
-        $HIPCC $FLAGS -c "$f" -o "$o" &
+        extra="$(sed -n 's|^// y2-build-flags: ||p' "$f" | head -1)"          # per-file code generation options, stated in the source
+        $HIPCC $FLAGS $extra -c "$f" -o "$o" &
         pids+=($!)
     fi
 done

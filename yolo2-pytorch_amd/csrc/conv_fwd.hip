@@ -29,6 +29,8 @@
 // one lane in accumulator registers 4g..4g+3 (MFMA C layout: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) are
 // exactly one pooling window: the pool is 3 v_max per output in-lane, and m>>2 is the pooled pixel's
 // ordinary row-major index.
+// y2-build-flags: -mllvm -amdgpu-mfma-vgpr-form
+//   (accumulators in ordinary VGPRs: the epilogues (affine / activation / statistics / pooled stores) read every accumulator once; from AGPRs that is a v_accvgpr_read apiece, and the kernels need 4 - 40 fewer registers)
 #include <stdlib.h>
 #include "common.h"
 

@@ -15,6 +15,8 @@
 // lane (i = l&31, k = 2s + (l>>5)) reads one dword at [k][i] — 32 consecutive banks per half-wave, conflict-free.
 // Workgroup = 4 waves (2x2), tile 128 (co) x 128 (j), wave tile 64x64 = 2x2 MFMA 32x32x2 blocks; 64 MFMAs per slab per
 // wave against 16 KB + 16 KB of DMA: the same MFMA-bound balance as the forward kernel.
+// y2-build-flags: -mllvm -amdgpu-mfma-vgpr-form
+//   (accumulators in ordinary VGPRs: same reason as conv_fwd.hip: no v_accvgpr_read in front of the partial-sum stores, up to 43 fewer registers)
 #include <stdlib.h>
 #include "common.h"
 
