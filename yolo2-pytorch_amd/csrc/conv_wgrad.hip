@@ -254,22 +254,32 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + buf * STAGE + KS * TI + wave * 256 + (j - PA) * RB * TJ), 16, (int)nvb[j - PA], 0, 0, 0);
     };
     auto compute_slab_spread = [&](int buf, int nbuf, int next_slab = 0) {
-        const float* sbuf = smem + buf * STAGE;
+        // volatile: the operand reads stay single ds_read_b32 with 16-bit immediate offsets.  Merged into ds_read2_b32 (8-bit offsets) every pair needs a v_add for
+        // its base, and a vector instruction beside fp32 MFMAs costs its issue time (tools/mfma_peak.py): 0.5 of the kernel's 1.1 vector instructions per MFMA
+        const volatile __attribute__((address_space(3))) float* sbuf = (const volatile __attribute__((address_space(3))) float*)(smem + buf * STAGE);
         constexpr int TOTAL = (KS / 2) * IB * JB, NPIECES = PA + PB;
         constexpr int EVERY = (TOTAL / 2) / NPIECES > 0 ? (TOTAL / 2) / NPIECES : 1;
         int cnt = 0;
+        // operands of step s + 1 are read (in program order: the reads are volatile) in front of the MFMAs of step s: the LDS round trip runs under four MFMAs
+        // instead of in front of them
+        float av[2][IB], bv[2][JB];
+#pragma unroll
+        for (int i = 0; i < IB; ++i) av[0][i] = sbuf[fa + 32 * i];
+#pragma unroll
+        for (int j = 0; j < JB; ++j) bv[0][j] = sbuf[fb + 32 * j];
 #pragma unroll
         for (int s = 0; s < KS / 2; ++s) {
-            float av[IB], bv[JB];
+            if (s + 1 < KS / 2) {
 #pragma unroll
-            for (int i = 0; i < IB; ++i) av[i] = sbuf[fa + s * 2 * TI + 32 * i];
+                for (int i = 0; i < IB; ++i) av[(s + 1) & 1][i] = sbuf[fa + (s + 1) * 2 * TI + 32 * i];
 #pragma unroll
-            for (int j = 0; j < JB; ++j) bv[j] = sbuf[fb + s * 2 * TJ + 32 * j];
+                for (int j = 0; j < JB; ++j) bv[(s + 1) & 1][j] = sbuf[fb + (s + 1) * 2 * TJ + 32 * j];
+            }
 #pragma unroll
             for (int i = 0; i < IB; ++i)
 #pragma unroll
                 for (int j = 0; j < JB; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
                     if (cnt % EVERY == 0 && cnt / EVERY < NPIECES) {
                         issue_piece(nbuf, cnt / EVERY);
                         __builtin_amdgcn_sched_barrier(0);
