@@ -359,6 +359,33 @@ def test_conv0_matches_fp64_reference(B, cin, cout, H, W):
     np.testing.assert_allclose(st[cout:].cpu().numpy(), (z * z).sum((0, 2, 3)).numpy(), rtol=1e-5)
 
 
+@pytest.mark.parametrize('B,H,W,cout', [(9, 416, 416, 32), (40, 208, 224, 32), (3, 330, 500, 16)])
+def test_conv0_persistent_workgroups_walk_several_tiles(B, H, W, cout):
+    """More 16 x 32-pixel tiles than the persistent grid has workgroups (2,048): a workgroup computes its 2nd, 3rd ... tile out of the patches it staged two tiles
+    ahead (three LDS buffers, csrc/conv0_fwd.hip).  Inference form (pooled output only), training form (raw z + statistics) and - ragged size, 16 channels -
+    the general kernel against the fp64 reference."""
+    import _hip
+    L = _hip.lib()
+    d = dev()
+    g = torch.Generator().manual_seed(B + W)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(cout, 3, 3, 3, generator=g) * 0.3
+    scale, shift = torch.randn(cout, generator=g), torch.randn(cout, generator=g) * 0.1
+    z, ref = ref_conv(x, w, scale, shift, 0.1, 3)
+    xd, wd, sc, sh = x.to(d), w.to(d), scale.to(d), shift.to(d)
+    yp = torch.empty(B, H // 2, W // 2, cout, device=d)
+    _hip.check(L.y2_conv0_fwd(_hip.ptr(xd), _hip.ptr(wd), _hip.ptr(sc), _hip.ptr(sh), None, _hip.ptr(yp), None, B, H, W, 3, cout, 0, cout, 0.1, _hip.stream()), 'pool')
+    assert rel_err(yp.permute(0, 3, 1, 2), F.max_pool2d(ref, 2)) <= CONV_TOL
+    zz = torch.empty(B, H, W, cout, device=d)
+    st = torch.zeros(32 * 2 * cout, dtype=torch.float64, device=d)
+    _hip.check(L.y2_conv0_fwd(_hip.ptr(xd), _hip.ptr(wd), None, None, _hip.ptr(zz), None, _hip.ptr(st), B, H, W, 3, cout, cout, 0, 1.0, _hip.stream()), 'train')
+    torch.cuda.synchronize()
+    assert rel_err(zz.permute(0, 3, 1, 2), z) <= CONV_TOL
+    st = st.view(32, -1).sum(0).cpu()
+    np.testing.assert_allclose(st[:cout].numpy(), z.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=2e-2)
+    np.testing.assert_allclose(st[cout:].numpy(), (z * z).sum((0, 2, 3)).numpy(), rtol=1e-5)
+
+
 @pytest.mark.parametrize('cout', [32, 64])
 def test_conv0_specialised_epilogues_equal_the_general_kernel(cout):
     """The tile-aligned first layer runs straight-line variants of conv0_kernel (csrc/conv0_fwd.hip launch0): pooled-only takes the 2x2 max BEFORE affine + LeakyReLU
